@@ -1,0 +1,232 @@
+"""ctypes driver for oracle/libss_oracle.so (TEST INFRASTRUCTURE ONLY -- see ss_oracle.h).
+
+Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Never by the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libss_oracle.so")
+
+ORC_OK, ORC_ERR_SHORT_SIGNAL, ORC_ERR_BAD_CONFIG, ORC_ERR_ARG = 0, 1, 2, 3
+FRAMING = {"contract": 0, "literal": 1}
+DCT_NORM = {"reference": 0, "ortho": 1}
+WINDOW = {"rect": 0, "hann": 1, "vorbis": 2}
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("sample_rate", C.c_uint32),
+        ("fft_points", C.c_uint32),
+        ("frame_length", C.c_float),
+        ("frame_stride", C.c_float),
+        ("num_cepstral", C.c_uint32),
+        ("num_filters", C.c_uint32),
+        ("low_frequency", C.c_float),
+        ("high_frequency", C.c_float),
+        ("dc_elimination", C.c_int32),
+        ("framing", C.c_int32),
+        ("spectrum_exponent", C.c_int32),
+        ("dct_norm", C.c_int32),
+        ("dct2_gain", C.c_float),
+        ("mfcc_window", C.c_int32),
+        ("preemph_coef", C.c_float),
+        ("preemph_shift", C.c_int32),
+    ]
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code: int):
+        super().__init__(f"oracle error {code}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "ss_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "libss_oracle.so"], check=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stride=0.01, num_cepstral=13,
+                num_filters=40, low_frequency=0.0, high_frequency=None, dc_elimination=True,
+                framing="contract", spectrum_exponent=1, dct_norm="reference", dct2_gain=2.0,
+                mfcc_window="rect", preemph_coef=0.0, preemph_shift=1) -> OrcParams:
+    p = OrcParams()
+    lib().orc_params_default(C.byref(p), C.c_uint32(sample_rate))
+    p.fft_points = fft_points
+    p.frame_length = frame_length
+    p.frame_stride = frame_stride
+    p.num_cepstral = num_cepstral
+    p.num_filters = num_filters
+    p.low_frequency = low_frequency
+    p.high_frequency = sample_rate / 2.0 if high_frequency is None else high_frequency
+    p.dc_elimination = int(bool(dc_elimination))
+    p.framing = FRAMING[framing]
+    p.spectrum_exponent = spectrum_exponent
+    p.dct_norm = DCT_NORM[dct_norm]
+    p.dct2_gain = dct2_gain
+    p.mfcc_window = WINDOW[mfcc_window]
+    p.preemph_coef = preemph_coef
+    p.preemph_shift = preemph_shift
+    return p
+
+
+def _chk(rc):
+    if rc != ORC_OK:
+        raise OracleError(rc)
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def frame_sizes(p):
+    a, b = C.c_size_t(), C.c_size_t()
+    _chk(lib().orc_frame_sizes(C.byref(p), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def num_frames(p, n):
+    t = C.c_size_t()
+    _chk(lib().orc_num_frames(C.byref(p), C.c_size_t(n), C.byref(t)))
+    return t.value
+
+
+def num_frames_padded(p, n):
+    t = C.c_size_t()
+    _chk(lib().orc_num_frames_padded(C.byref(p), C.c_size_t(n), C.byref(t)))
+    return t.value
+
+
+def stft_sizes(p):
+    h, npad, wn = C.c_size_t(), C.c_size_t(), C.c_float()
+    _chk(lib().orc_stft_sizes(C.byref(p), C.byref(h), C.byref(npad), C.byref(wn)))
+    return h.value, npad.value, wn.value
+
+
+def stft_rows(p, n):
+    r, rr = C.c_size_t(), C.c_size_t()
+    _chk(lib().orc_stft_rows(C.byref(p), C.c_size_t(n), C.byref(r), C.byref(rr)))
+    return r.value, rr.value
+
+
+def vorbis_window(n):
+    w = np.empty(n, dtype=np.float32)
+    lib().orc_vorbis_window(C.c_size_t(n), _ptr(w, C.c_float))
+    return w
+
+
+def hann_window(n):
+    w = np.empty(n, dtype=np.float32)
+    lib().orc_hann_window(C.c_size_t(n), _ptr(w, C.c_float))
+    return w
+
+
+def filterbank(p):
+    M, F = p.num_filters, p.fft_points // 2 + 1
+    fb = np.empty((M, F), dtype=np.float32)
+    idx = np.empty(M + 2, dtype=np.int32)
+    _chk(lib().orc_filterbank(C.byref(p), _ptr(fb, C.c_float), _ptr(idx, C.c_int32)))
+    return fb, idx
+
+
+def power_spectrum(p, x):
+    x = _f32(x)
+    T, F = num_frames(p, x.size), p.fft_points // 2 + 1
+    out = np.empty((T, F), dtype=np.float64)
+    _chk(lib().orc_power_spectrum(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(out, C.c_double)))
+    return out
+
+
+def mfe(p, x):
+    x = _f32(x)
+    T = num_frames(p, x.size)
+    feat = np.empty((T, p.num_filters), dtype=np.float64)
+    en = np.empty(T, dtype=np.float64)
+    _chk(lib().orc_mfe(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(feat, C.c_double), _ptr(en, C.c_double)))
+    return feat, en
+
+
+def mfcc(p, x):
+    x = _f32(x)
+    T = num_frames(p, x.size)
+    out = np.empty((T, p.num_cepstral), dtype=np.float64)
+    _chk(lib().orc_mfcc(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(out, C.c_double)))
+    return out
+
+
+def stft(p, x):
+    x = np.atleast_2d(_f32(x))
+    ch, n = x.shape
+    R, _ = stft_rows(p, n)
+    F = p.fft_points // 2 + 1
+    out = np.empty((ch, R, F, 2), dtype=np.float64)
+    _chk(lib().orc_stft(C.byref(p), _ptr(x, C.c_float), C.c_size_t(ch), C.c_size_t(n), _ptr(out, C.c_double)))
+    return out[..., 0] + 1j * out[..., 1]
+
+
+def mel_spectrogram(p, x):
+    one_d = np.asarray(x).ndim == 1
+    x = np.atleast_2d(_f32(x))
+    ch, n = x.shape
+    R, _ = stft_rows(p, n)
+    out = np.empty((ch, p.num_filters, R), dtype=np.float64)
+    _chk(lib().orc_mel_spectrogram(C.byref(p), _ptr(x, C.c_float), C.c_size_t(ch), C.c_size_t(n), _ptr(out, C.c_double)))
+    return out[0] if one_d else out
+
+
+def preemphasis(x, shift=1, cof=0.98):
+    x = _f32(x)
+    y = np.empty(x.size, dtype=np.float64)
+    _chk(lib().orc_preemphasis(_ptr(x, C.c_float), C.c_size_t(x.size), C.c_long(shift), C.c_float(cof), _ptr(y, C.c_double)))
+    return y
+
+
+# ---- reference-shaped f32 port (timed CPU baseline) ----
+
+def port_mfcc(p, x):
+    x = _f32(x)
+    T = num_frames(p, x.size)
+    out = np.empty((T, p.num_cepstral), dtype=np.float32)
+    _chk(lib().port_mfcc_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(out, C.c_float)))
+    return out
+
+
+def port_mfe(p, x):
+    x = _f32(x)
+    T = num_frames(p, x.size)
+    feat = np.empty((T, p.num_filters), dtype=np.float32)
+    en = np.empty(T, dtype=np.float32)
+    _chk(lib().port_mfe_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(feat, C.c_float), _ptr(en, C.c_float)))
+    return feat, en
+
+
+def port_mel_spectrogram(p, x):
+    one_d = np.asarray(x).ndim == 1
+    x = np.atleast_2d(_f32(x))
+    ch, n = x.shape
+    R, _ = stft_rows(p, n)
+    out = np.empty((ch, p.num_filters, R), dtype=np.float32)
+    _chk(lib().port_mel_spectrogram_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(ch), C.c_size_t(n), _ptr(out, C.c_float)))
+    return out[0] if one_d else out
