@@ -1,0 +1,177 @@
+/*
+ * speechsauce_amd.h -- C ABI of the MI355X-native MFCC / mel-spectrogram hot path.
+ *
+ * The reference crate (secretsauceai/mfcc-rust, `speechsauce`) has no FFI of its own: the path
+ * sits behind plain Rust functions and a PyO3 module.  This header is the `extern "C"` layer a
+ * maintainer binds instead of those functions; every entry point cites the reference item it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows the Rust / Python
+ * side of the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; f32 everywhere (the crate is f32-only, README.md:17);
+ *     row-major, contiguous; batches carry an explicit leading dimension `ld` (in elements).
+ *   - the caller allocates outputs (sizes from the query functions); the library owns only the
+ *     opaque config handle and its device-resident tables.
+ *   - every function returns an ss_status; nothing unwinds across the boundary.  The reference
+ *     panics where these return an error (usize underflow processing.rs:101,105; config.rs:162;
+ *     functions.rs:136; asserts feature.rs:47-51).
+ *   - `*_device` variants take device pointers and a hipStream_t (passed as void*) and are
+ *     asynchronous; the others take host pointers and are synchronous (H2D + kernels + D2H).
+ *   - a config handle is immutable after creation (no STFT carry-over state, unlike
+ *     config.rs:126,130) and may be used from several threads / streams concurrently.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with SS_ERR_HIP.
+ */
+#ifndef SPEECHSAUCE_AMD_H
+#define SPEECHSAUCE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+typedef enum ss_status {
+    SS_OK = 0,
+    SS_ERR_SHORT_SIGNAL = 1, /* fewer samples than one frame / zero frames (reference: usize underflow panic) */
+    SS_ERR_BAD_CONFIG = 2,   /* parameter combination the reference asserts on or underflows with */
+    SS_ERR_ARG = 3,          /* null pointer, bad leading dimension, ... */
+    SS_ERR_HIP = 4,          /* HIP runtime error or no device (see ss_last_error_string) */
+    SS_ERR_UNSUPPORTED = 5   /* valid in the reference but not built here (e.g. non power-of-two fft_points) */
+} ss_status;
+
+enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1 };
+enum { SS_DCT_REFERENCE = 0, SS_DCT_ORTHO = 1 };
+enum { SS_WINDOW_RECT = 0, SS_WINDOW_HANN = 1, SS_WINDOW_VORBIS = 2 };
+
+/* DCT-II gain of the un-vendored ndrustfft `nddct2` (feature.rs:123): scipy's un-normalised
+ * convention y[k] = 2 * sum x[n] cos(pi k (2n+1) / 2N).  One named constant; "parity unpinned". */
+#define SS_DCT2_GAIN 2.0f
+
+/*
+ * ss_params: the nine arguments of SpeechConfig::new (config.rs:140-150) one-for-one, followed by
+ * the switches of SURVEY.md section 0.  ss_params_default() fills SpeechConfigBuilder::new's
+ * defaults (config.rs:35-47) and the reference-mode switches.
+ */
+typedef struct ss_params {
+    uint32_t struct_size;       /* = sizeof(ss_params); checked by ss_config_create */
+    uint32_t sample_rate;       /* config.rs:141 */
+    uint32_t fft_points;        /* :142  (power of two, 32..4096) */
+    float    frame_length;      /* :143  seconds */
+    float    frame_stride;      /* :144  seconds */
+    uint32_t num_cepstral;      /* :145 */
+    uint32_t num_filters;       /* :146 */
+    float    low_frequency;     /* :147 */
+    float    high_frequency;    /* :148 */
+    int32_t  dc_elimination;    /* :149 */
+    /* ---- switches (reference mode = what ss_params_default sets) ---- */
+    int32_t  framing;           /* SS_FRAMING_CONTRACT: frames[t,:] = x[t*step : t*step+flen], the documented
+                                   contract (processing.rs:55-64).  SS_FRAMING_LITERAL: the exact_chunks copy as
+                                   written (processing.rs:110-120), which leaves every frame zero for > 2 frames. */
+    int32_t  spectrum_exponent; /* 1: |X|/N as written (processing.rs:168,180); 2: |X|^2/N (speechpy) */
+    int32_t  dct_norm;          /* SS_DCT_REFERENCE: scaling as written (feature.rs:126-131); SS_DCT_ORTHO */
+    float    dct2_gain;         /* SS_DCT2_GAIN */
+    int32_t  mfcc_window;       /* window on the MFCC frames; reference applies none (feature.rs:203-210) */
+    float    preemph_coef;      /* fused pre-emphasis y[n] = x[n] - c*x[(n-shift) mod L] (processing.rs:31-53);
+                                   0 = off (reference mfcc() applies none) */
+    int32_t  preemph_shift;     /* >= 1 */
+} ss_params;
+
+typedef struct ss_config ss_config; /* opaque; replaces speechsauce::config::SpeechConfig (config.rs:99-131) */
+
+/* ---- configuration ------------------------------------------------------------------------ */
+
+/* SpeechConfigBuilder::new(sample_rate) defaults, config.rs:35-47 (Default = 16 kHz, :133-137). */
+int ss_params_default(ss_params *p, uint32_t sample_rate);
+
+/* SpeechConfig::new, config.rs:140-185: derives sizes, builds the Vorbis window, the sparse mel
+ * bank (feature.rs:36-90), FFT twiddles and the DCT table, and uploads them to the current HIP
+ * device.  Fails with SS_ERR_HIP when no device is usable. */
+int ss_config_create(const ss_params *p, ss_config **out);
+void ss_config_destroy(ss_config *cfg);
+int ss_config_params(const ss_config *cfg, ss_params *out);
+
+/* Validation and table construction only (no device): what ss_config_create checks. */
+int ss_params_validate(const ss_params *p);
+
+/* ---- derived sizes (host only, no device needed) --------------------------------------------- */
+
+/* frame_sample_length / frame_step_size, processing.rs:77-78 */
+int ss_frame_sizes(const ss_params *p, size_t *frame_len, size_t *frame_step);
+/* numframes with zero_padding=false, processing.rs:101 (what mfe/mfcc use, feature.rs:203-210) */
+int ss_num_frames(const ss_params *p, size_t n_samples, size_t *n_frames);
+/* STFT geometry: hop = frame_size (config.rs:154), n_pad (functions.rs:96), wnorm (config.rs:178) */
+int ss_stft_sizes(const ss_params *p, size_t *hop, size_t *n_pad, float *wnorm);
+/* rows returned by stft1/stft2 = ceil(n/hop) (functions.rs:95-98,121); the last n_pad are zero */
+int ss_stft_rows(const ss_params *p, size_t n_samples, size_t *rows, size_t *real_rows);
+
+/* ---- tables (host only) ------------------------------------------------------------------- */
+
+/* dense bank [num_filters x (fft_points/2+1)], feature.rs:36-90; idx (may be NULL) gets the
+ * num_filters+2 bin indices of feature.rs:69-70 */
+int ss_filterbank(const ss_params *p, float *fb, int32_t *idx);
+/* SpeechConfig.window (Vorbis), config.rs:151-160; n = fft_points */
+int ss_vorbis_window(size_t n, float *w);
+
+/* ---- hot path, host pointers (synchronous) -------------------------------------------------- */
+
+/* speechsauce::feature::mfcc(ArrayView1<f32>, &SpeechConfig) -> Array2<f32>  (feature.rs:99-148)
+ * out: [n_frames x num_cepstral] */
+int ss_mfcc(const ss_config *cfg, const float *x, size_t n_samples, float *out);
+/* speechsauce::feature::mfe -> (Array2<f32>, Array1<f32>)  (feature.rs:200-233)
+ * feat: [n_frames x num_filters], energy: [n_frames] */
+int ss_mfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat, float *energy);
+/* mel_spectrogram1 (channels = 1) / mel_spectrogram2 (feature.rs:151-174); x: [channels x n_samples],
+ * out: [channels x num_filters x rows] */
+int ss_mel_spectrogram(const ss_config *cfg, const float *x, size_t channels, size_t n_samples, float *out);
+/* speechsauce::processing::preemphasis (processing.rs:31-53) */
+int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, float *y);
+
+/* batch of equal-length clips: x [batch x n_samples] with row stride ld >= n_samples.
+ * out: [batch x n_frames x num_cepstral] */
+int ss_mfcc_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *out);
+int ss_mfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld,
+                 float *feat, float *energy);
+
+/* ---- hot path, device pointers (asynchronous on `stream`) ----------------------------------- */
+
+int ss_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                         float *d_out, void *stream);
+int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                        float *d_feat, float *d_energy, void *stream);
+int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
+                              size_t ld, float *d_out, void *stream);
+int ss_preemphasis_device(const float *d_x, size_t n_samples, long shift, float cof, float *d_y, void *stream);
+
+/* stage outputs (parity triage; pub fns of the reference too):
+ * power_spectrum (processing.rs:179-181) over the frames of each clip: [batch x n_frames x (fft_points/2+1)] */
+int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,
+                                   size_t ld, float *d_P, void *stream);
+/* stft2 (functions.rs:86-123): interleaved re,im  [channels x rows x (fft_points/2+1) x 2] */
+int ss_stft_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples, size_t ld,
+                   float *d_out, void *stream);
+
+/* ---- device / diagnostics ------------------------------------------------------------------- */
+
+int ss_device_count(int *count);
+int ss_set_device(int device);
+/* name of the kernel the last *_device call on this thread launched (for rocprof cross-checks) */
+const char *ss_last_kernel_name(void);
+/* Times `iters` back-to-back launches of the MFCC batch kernel with HIP events recorded on `stream`
+ * (the stream the kernel runs on) and returns the average launch duration in milliseconds. */
+int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                              float *d_out, void *stream, int iters, float *avg_ms);
+int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
+                                   size_t ld, float *d_out, void *stream, int iters, float *avg_ms);
+
+const char *ss_status_string(int status);
+const char *ss_last_error_string(void); /* thread-local detail of the last failure */
+int ss_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECHSAUCE_AMD_H */

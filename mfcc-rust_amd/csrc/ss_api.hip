@@ -1,0 +1,444 @@
+// C ABI entry points that touch the device (include/speechsauce_amd.h).  Host-pointer variants
+// stage through device buffers; device-pointer variants only enqueue kernels on the caller's
+// stream.  There is no CPU compute path here: without a HIP device these return SS_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ss_device.h"
+#include "ss_internal.h"
+
+struct ss_config {
+    ss::HostTables host;
+    int device = -1;
+    int num_cus = 256;
+    // device tables
+    float *d_window_mfcc = nullptr;
+    float *d_window_stft = nullptr;
+    float2 *d_tw_c = nullptr;
+    float2 *d_tw_n = nullptr;
+    int32_t *d_f_start = nullptr, *d_f_len = nullptr, *d_f_off = nullptr;
+    float *d_f_w = nullptr;
+    float *d_dct = nullptr;
+};
+
+namespace {
+
+thread_local const char *g_last_kernel = "";
+
+int hip_fail(hipError_t e, const char *what)
+{
+    return ss::fail(SS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SS_HIP(call)                                  \
+    do {                                              \
+        hipError_t e_ = (call);                       \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+template <typename T>
+int upload(T **dst, const void *src, size_t bytes)
+{
+    *dst = nullptr;
+    if (bytes == 0) return SS_OK;
+    SS_HIP(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    SS_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return SS_OK;
+}
+
+struct DeviceBuf {
+    void *p = nullptr;
+    ~DeviceBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes)
+    {
+        SS_HIP(hipMalloc(&p, bytes ? bytes : 16));
+        return SS_OK;
+    }
+    template <typename T>
+    T *as() { return static_cast<T *>(p); }
+};
+
+void fill_common(const ss_config *cfg, ss::FrontArgs &a)
+{
+    const ss::HostTables &h = cfg->host;
+    a.tw_c = cfg->d_tw_c;
+    a.tw_n = cfg->d_tw_n;
+    a.f_start = cfg->d_f_start;
+    a.f_len = cfg->d_f_len;
+    a.f_off = cfg->d_f_off;
+    a.f_w = cfg->d_f_w;
+    a.n_filters = h.params.num_filters;
+    a.dct = cfg->d_dct;
+    a.n_ceps = h.params.num_cepstral;
+    a.dc_elimination = h.params.dc_elimination;
+    a.spectrum_exponent = h.params.spectrum_exponent;
+}
+
+// MFCC-path launch (OUT_MFCC / OUT_MFE / OUT_POWER).
+int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t batch, size_t n, size_t ld,
+                  float *out0, float *out1, hipStream_t stream)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (!d_x || !out0) return ss::fail(SS_ERR_ARG, "null buffer");
+    if (ld < n) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    if (batch == 0) return SS_OK;
+    if (n > 0x7fffffffull || batch > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "clip too long / batch too large");
+    const ss::HostTables &h = cfg->host;
+    size_t T = 0;
+    int rc = ss::num_frames(h.params, n, T);
+    if (rc) return rc;
+    ss::FrontArgs a{};
+    fill_common(cfg, a);
+    a.x = d_x;
+    a.ld = ld;
+    a.n_samples = static_cast<uint32_t>(n);
+    a.batch = static_cast<uint32_t>(batch);
+    a.flen = h.d.flen;
+    a.step = h.d.step;
+    a.n_frames = static_cast<uint32_t>(T);
+    // processing.rs:110-120 as written: nothing is copied for > 2 frames, x[0..flen] into every row otherwise
+    if (h.params.framing == SS_FRAMING_LITERAL) a.frame_mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
+    else a.frame_mode = ss::FRAME_NORMAL;
+    a.preemph = h.params.preemph_coef;
+    a.preemph_shift = static_cast<uint32_t>(h.params.preemph_shift > 0 ? h.params.preemph_shift : 1);
+    a.window = cfg->d_window_mfcc;
+    a.scale = 1.0f / static_cast<float>(h.params.fft_points);  // processing.rs:180
+    // feature.rs:126-131 (n = T * M as f32) or scipy ortho over the axis length
+    const float g = h.params.dct2_gain;
+    const float M = static_cast<float>(h.params.num_filters);
+    if (h.params.dct_norm == SS_DCT_ORTHO) {
+        a.dct_scale_k = g * (1.0f / sqrtf(2.0f * M));
+        a.dct_scale_0 = a.dct_scale_00 = g * (1.0f / sqrtf(4.0f * M));
+    } else {
+        const float nn = static_cast<float>(T * h.params.num_filters);
+        a.dct_scale_k = g * (1.0f / sqrtf(2.0f * nn));
+        a.dct_scale_0 = g;
+        a.dct_scale_00 = g * (1.0f / sqrtf(4.0f * nn));
+    }
+    a.out_kind = out_kind;
+    a.out0 = out0;
+    a.out1 = out1;
+    ss::LaunchInfo info{};
+    hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
+    if (e != hipSuccess) return hip_fail(e, "launch_front_generic");
+    g_last_kernel = info.kernel_name;
+    return SS_OK;
+}
+
+// STFT-path launch (OUT_MEL / OUT_STFT).
+int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t channels, size_t n, size_t ld,
+                float *out0, hipStream_t stream)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (!d_x || !out0) return ss::fail(SS_ERR_ARG, "null buffer");
+    if (ld < n) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    if (channels == 0) return SS_OK;
+    if (n == 0 || n > 0x7fffffffull || channels > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "bad clip length / channel count");
+    const ss::HostTables &h = cfg->host;
+    size_t R = 0, Rreal = 0;
+    int rc = ss::stft_rows(h.params, n, R, Rreal);
+    if (rc) return rc;
+    ss::FrontArgs a{};
+    fill_common(cfg, a);
+    a.x = d_x;
+    a.ld = ld;
+    a.n_samples = static_cast<uint32_t>(n);
+    a.batch = static_cast<uint32_t>(channels);
+    a.hop = h.d.hop;
+    a.n_pad = h.d.n_pad;
+    a.rows = static_cast<uint32_t>(R);
+    a.real_rows = static_cast<uint32_t>(Rreal);
+    a.window = cfg->d_window_stft;
+    a.scale = h.d.wnorm;
+    a.out_kind = out_kind;
+    a.out0 = out0;
+    ss::LaunchInfo info{};
+    hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
+    if (e != hipSuccess) return hip_fail(e, "launch_front_generic");
+    g_last_kernel = info.kernel_name;
+    return SS_OK;
+}
+
+int check_device(const ss_config *cfg)
+{
+    int dev = -1;
+    SS_HIP(hipGetDevice(&dev));
+    if (dev != cfg->device) return ss::fail(SS_ERR_ARG, "config was created on a different HIP device than the current one");
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_device_count(int *count)
+{
+    if (!count) return ss::fail(SS_ERR_ARG, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return SS_OK;
+}
+
+int ss_set_device(int device)
+{
+    SS_HIP(hipSetDevice(device));
+    return SS_OK;
+}
+
+int ss_config_create(const ss_params *p, ss_config **out)
+{
+    if (!p || !out) return ss::fail(SS_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::unique_ptr<ss_config> cfg(new ss_config());
+    int rc = ss::build_tables(*p, cfg->host);
+    if (rc) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return ss::fail(SS_ERR_HIP, "no usable HIP device: the speechsauce_amd hot path has no CPU fallback");
+    SS_HIP(hipGetDevice(&cfg->device));
+    hipDeviceProp_t prop;
+    SS_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    cfg->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const ss::HostTables &h = cfg->host;
+    ss_config *c = cfg.get();
+#define SS_UP(field, vec)                                                              \
+    do {                                                                               \
+        rc = upload(&c->field, (vec).data(), (vec).size() * sizeof((vec)[0]));         \
+        if (rc) { ss_config_destroy(cfg.release()); return rc; }                       \
+    } while (0)
+    SS_UP(d_window_mfcc, h.window_mfcc);
+    SS_UP(d_window_stft, h.window_stft);
+    SS_UP(d_tw_c, h.tw_c);
+    SS_UP(d_tw_n, h.tw_n);
+    SS_UP(d_f_start, h.bank.start);
+    SS_UP(d_f_len, h.bank.len);
+    SS_UP(d_f_off, h.bank.off);
+    SS_UP(d_f_w, h.bank.w);
+    SS_UP(d_dct, h.dct);
+#undef SS_UP
+    *out = cfg.release();
+    return SS_OK;
+}
+
+void ss_config_destroy(ss_config *cfg)
+{
+    if (!cfg) return;
+    void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
+                    cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete cfg;
+}
+
+int ss_config_params(const ss_config *cfg, ss_params *out)
+{
+    if (!cfg || !out) return ss::fail(SS_ERR_ARG, "null argument");
+    *out = cfg->host.params;
+    return SS_OK;
+}
+
+// ---- device-pointer variants ---------------------------------------------------------------
+
+int ss_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                         float *d_out, void *stream)
+{
+    return launch_frames(cfg, ss::OUT_MFCC, d_x, batch, n_samples, ld, d_out, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                        float *d_feat, float *d_energy, void *stream)
+{
+    if (!d_energy) return ss::fail(SS_ERR_ARG, "null buffer");
+    return launch_frames(cfg, ss::OUT_MFE, d_x, batch, n_samples, ld, d_feat, d_energy, static_cast<hipStream_t>(stream));
+}
+
+int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,
+                                   size_t ld, float *d_P, void *stream)
+{
+    return launch_frames(cfg, ss::OUT_POWER, d_x, batch, n_samples, ld, d_P, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
+                              size_t ld, float *d_out, void *stream)
+{
+    return launch_stft(cfg, ss::OUT_MEL, d_x, channels, n_samples, ld, d_out, static_cast<hipStream_t>(stream));
+}
+
+int ss_stft_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples, size_t ld,
+                   float *d_out, void *stream)
+{
+    return launch_stft(cfg, ss::OUT_STFT, d_x, channels, n_samples, ld, d_out, static_cast<hipStream_t>(stream));
+}
+
+int ss_preemphasis_device(const float *d_x, size_t n_samples, long shift, float cof, float *d_y, void *stream)
+{
+    if (!d_x || !d_y) return ss::fail(SS_ERR_ARG, "null buffer");
+    // slices s![..shift] / s![-shift..] panic for shift <= 0 or shift > len (processing.rs:43-50)
+    if (n_samples == 0 || shift <= 0 || static_cast<size_t>(shift) > n_samples) return ss::fail(SS_ERR_ARG, "shift must be in [1, n_samples]");
+    hipError_t e = ss::launch_preemphasis(d_x, d_y, n_samples, static_cast<size_t>(shift) % n_samples, cof,
+                                          static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch_preemphasis");
+    g_last_kernel = "ss_preemphasis_kernel";
+    return SS_OK;
+}
+
+// ---- host-pointer variants -------------------------------------------------------------------
+
+int ss_mfcc_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *out)
+{
+    if (!cfg || !x || !out) return ss::fail(SS_ERR_ARG, "null argument");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    size_t T = 0;
+    int rc = ss::num_frames(cfg->host.params, n_samples, T);
+    if (rc) return rc;
+    if (batch == 0) return SS_OK;
+    rc = check_device(cfg);
+    if (rc) return rc;
+    const size_t in_elems = (batch - 1) * ld + n_samples, out_elems = batch * T * cfg->host.params.num_cepstral;
+    DeviceBuf dx, dout;
+    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dout.alloc(out_elems * sizeof(float)))) return rc;
+    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
+    rc = ss_mfcc_batch_device(cfg, dx.as<float>(), batch, n_samples, ld, dout.as<float>(), nullptr);
+    if (rc) return rc;
+    SS_HIP(hipMemcpy(out, dout.p, out_elems * sizeof(float), hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+int ss_mfcc(const ss_config *cfg, const float *x, size_t n_samples, float *out)
+{
+    return ss_mfcc_batch(cfg, x, 1, n_samples, n_samples, out);
+}
+
+int ss_mfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *feat, float *energy)
+{
+    if (!cfg || !x || !feat || !energy) return ss::fail(SS_ERR_ARG, "null argument");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    size_t T = 0;
+    int rc = ss::num_frames(cfg->host.params, n_samples, T);
+    if (rc) return rc;
+    if (batch == 0) return SS_OK;
+    rc = check_device(cfg);
+    if (rc) return rc;
+    const size_t in_elems = (batch - 1) * ld + n_samples;
+    const size_t feat_elems = batch * T * cfg->host.params.num_filters, en_elems = batch * T;
+    DeviceBuf dx, dfeat, den;
+    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dfeat.alloc(feat_elems * sizeof(float))) ||
+        (rc = den.alloc(en_elems * sizeof(float))))
+        return rc;
+    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
+    rc = ss_mfe_batch_device(cfg, dx.as<float>(), batch, n_samples, ld, dfeat.as<float>(), den.as<float>(), nullptr);
+    if (rc) return rc;
+    SS_HIP(hipMemcpy(feat, dfeat.p, feat_elems * sizeof(float), hipMemcpyDeviceToHost));
+    SS_HIP(hipMemcpy(energy, den.p, en_elems * sizeof(float), hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+int ss_mfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat, float *energy)
+{
+    return ss_mfe_batch(cfg, x, 1, n_samples, n_samples, feat, energy);
+}
+
+int ss_mel_spectrogram(const ss_config *cfg, const float *x, size_t channels, size_t n_samples, float *out)
+{
+    if (!cfg || !x || !out) return ss::fail(SS_ERR_ARG, "null argument");
+    size_t R = 0, Rreal = 0;
+    int rc = ss::stft_rows(cfg->host.params, n_samples, R, Rreal);
+    if (rc) return rc;
+    if (channels == 0) return SS_OK;
+    if (n_samples == 0) return ss::fail(SS_ERR_ARG, "empty signal");
+    rc = check_device(cfg);
+    if (rc) return rc;
+    const size_t in_elems = channels * n_samples, out_elems = channels * cfg->host.params.num_filters * R;
+    DeviceBuf dx, dout;
+    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dout.alloc(out_elems * sizeof(float)))) return rc;
+    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
+    rc = ss_mel_spectrogram_device(cfg, dx.as<float>(), channels, n_samples, n_samples, dout.as<float>(), nullptr);
+    if (rc) return rc;
+    SS_HIP(hipMemcpy(out, dout.p, out_elems * sizeof(float), hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, float *y)
+{
+    if (!x || !y) return ss::fail(SS_ERR_ARG, "null argument");
+    if (n_samples == 0 || shift <= 0 || static_cast<size_t>(shift) > n_samples) return ss::fail(SS_ERR_ARG, "shift must be in [1, n_samples]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return ss::fail(SS_ERR_HIP, "no usable HIP device: the speechsauce_amd hot path has no CPU fallback");
+    DeviceBuf dx, dy;
+    int rc;
+    if ((rc = dx.alloc(n_samples * sizeof(float))) || (rc = dy.alloc(n_samples * sizeof(float)))) return rc;
+    SS_HIP(hipMemcpy(dx.p, x, n_samples * sizeof(float), hipMemcpyHostToDevice));
+    rc = ss_preemphasis_device(dx.as<float>(), n_samples, shift, cof, dy.as<float>(), nullptr);
+    if (rc) return rc;
+    SS_HIP(hipMemcpy(y, dy.p, n_samples * sizeof(float), hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------
+
+const char *ss_last_kernel_name(void) { return g_last_kernel; }
+
+int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                              float *d_out, void *stream, int iters, float *avg_ms)
+{
+    if (!avg_ms || iters <= 0) return ss::fail(SS_ERR_ARG, "bad timing request");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    SS_HIP(hipEventCreate(&e0));
+    SS_HIP(hipEventCreate(&e1));
+    int rc = ss_mfcc_batch_device(cfg, d_x, batch, n_samples, ld, d_out, stream);  // warm-up
+    if (rc == SS_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && rc == SS_OK; ++i) rc = ss_mfcc_batch_device(cfg, d_x, batch, n_samples, ld, d_out, stream);
+        (void)hipEventRecord(e1, s);
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = hip_fail(e, "event timing");
+        *avg_ms = ms / static_cast<float>(iters);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
+                                   size_t ld, float *d_out, void *stream, int iters, float *avg_ms)
+{
+    if (!avg_ms || iters <= 0) return ss::fail(SS_ERR_ARG, "bad timing request");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    SS_HIP(hipEventCreate(&e0));
+    SS_HIP(hipEventCreate(&e1));
+    int rc = ss_mel_spectrogram_device(cfg, d_x, channels, n_samples, ld, d_out, stream);
+    if (rc == SS_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && rc == SS_OK; ++i) rc = ss_mel_spectrogram_device(cfg, d_x, channels, n_samples, ld, d_out, stream);
+        (void)hipEventRecord(e1, s);
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = hip_fail(e, "event timing");
+        *avg_ms = ms / static_cast<float>(iters);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Kernel argument block and launcher declarations shared by ss_kernels.hip and ss_api.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ss {
+
+enum OutKind : int32_t {
+    OUT_MFCC = 0,   // [frames x num_cepstral]                    feature.rs:99-148
+    OUT_MFE = 1,    // feat [frames x M] + energy [frames]        feature.rs:200-233
+    OUT_POWER = 2,  // P [frames x F]                             processing.rs:179-181
+    OUT_MEL = 3,    // [clips x M x R]                            feature.rs:151-174
+    OUT_STFT = 4    // [clips x R x F x 2]                        functions.rs:86-123
+};
+
+enum FrameMode : int32_t { FRAME_NORMAL = 0, FRAME_ZERO = 1, FRAME_FIRST = 2 };
+
+struct FrontArgs {
+    // input: `batch` clips of `n_samples`, row stride `ld` elements
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples;
+    uint32_t batch;
+    // MFCC framing (processing.rs:65-129)
+    uint32_t flen, step, n_frames;
+    int32_t frame_mode;
+    float preemph;
+    uint32_t preemph_shift;
+    // STFT framing (functions.rs:86-170)
+    uint32_t hop, n_pad, rows, real_rows;
+    const float *window;  // MFCC: [flen] or null; STFT: [n_fft]
+    float scale;          // MFCC: 1/N (processing.rs:180); STFT: wnorm (config.rs:178)
+    int32_t spectrum_exponent;
+    // FFT tables
+    const float2 *tw_c;  // exp(-2 pi i t / C), t < C
+    const float2 *tw_n;  // exp(-2 pi i k / N), k <= C/2
+    // sparse mel bank
+    const int32_t *f_start, *f_len, *f_off;
+    const float *f_w;
+    uint32_t n_filters;
+    // DCT
+    const float *dct;  // [n_ceps x n_filters]
+    uint32_t n_ceps;
+    float dct_scale_k;   // multiplier of columns >= 1 (gain * norm)
+    float dct_scale_0;   // multiplier of column 0, row t > 0
+    float dct_scale_00;  // multiplier of element [0,0] of each clip
+    int32_t dc_elimination;
+    // outputs
+    int32_t out_kind;
+    float *out0;
+    float *out1;
+};
+
+struct LaunchInfo {
+    const char *kernel_name;
+    unsigned grid, block;
+    size_t lds_bytes;
+};
+
+// Generic front-end (any power-of-two fft_points in [32, 4096]).
+hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info);
+// Element-wise pre-emphasis (processing.rs:31-53).
+hipError_t launch_preemphasis(const float *x, float *y, size_t n, size_t shift, float cof, hipStream_t stream);
+
+}  // namespace ss

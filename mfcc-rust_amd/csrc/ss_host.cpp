@@ -1,0 +1,355 @@
+// Host side of the config handle: parameter validation, derived sizes and every table the HIP
+// kernels consume.  Pure C++ (no HIP): this is what SpeechConfig::new (config.rs:140-185) and
+// feature::filterbanks (feature.rs:36-90) do on the host in the reference.
+//
+// Build with -ffp-contract=off: the mel bank indices sit on integer boundaries after an f32
+// ln -> exp round trip, so the f32 operation order below is part of the contract.
+#include "ss_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace ss {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int status, const std::string &msg)
+{
+    g_last_error = msg;
+    return status;
+}
+const std::string &last_error() { return g_last_error; }
+
+static bool is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
+
+int derive(const ss_params &p, Derived &d)
+{
+    // processing.rs:77-78: (sample_rate as f32 * seconds).round() as usize
+    const float fl = roundf(static_cast<float>(p.sample_rate) * p.frame_length);
+    const float st = roundf(static_cast<float>(p.sample_rate) * p.frame_stride);
+    if (!(fl >= 1.0f) || !(st >= 1.0f) || fl > 16777216.0f || st > 16777216.0f)
+        return fail(SS_ERR_BAD_CONFIG, "frame_length/frame_stride give a zero or absurd sample count");
+    d.flen = static_cast<uint32_t>(fl);
+    d.step = static_cast<uint32_t>(st);
+    d.n_fft = p.fft_points;
+    d.n_bins = p.fft_points / 2 + 1;
+    d.log2c = 0;
+    while ((2u << d.log2c) < p.fft_points) ++d.log2c;
+    // config.rs:154: frame_size = (frame_length * sample_rate as f32) as usize  (truncation)
+    const float hs = p.frame_length * static_cast<float>(p.sample_rate);
+    const uint32_t hop = hs >= 1.0f ? static_cast<uint32_t>(hs) : 0u;
+    // config.rs:162 (N - frame_size) and functions.rs:136 ((N - frame_size) - frame_size) are usize:
+    // the STFT path only exists for N >= 2*frame_size.
+    d.stft_ok = hop >= 1 && static_cast<uint64_t>(p.fft_points) >= 2ull * hop;
+    d.hop = hop;
+    if (d.stft_ok) {
+        d.n_pad = p.fft_points / hop - 1;  // functions.rs:96
+        // config.rs:178: 1.0 / (fft_points.pow(2) as f32 / (2 * frame_size) as f32)
+        d.wnorm = 1.0f / (static_cast<float>(static_cast<uint64_t>(p.fft_points) * p.fft_points) /
+                          static_cast<float>(2u * hop));
+    }
+    return SS_OK;
+}
+
+int validate(const ss_params &p)
+{
+    if (p.struct_size != sizeof(ss_params)) return fail(SS_ERR_ARG, "ss_params.struct_size mismatch (ABI)");
+    if (p.sample_rate == 0) return fail(SS_ERR_BAD_CONFIG, "sample_rate must be > 0");
+    if (p.fft_points < 32 || p.fft_points > 4096 || !is_pow2(p.fft_points))
+        return fail(SS_ERR_UNSUPPORTED, "fft_points must be a power of two in [32, 4096]");
+    if (p.num_filters == 0 || p.num_filters > 1024) return fail(SS_ERR_BAD_CONFIG, "num_filters out of range");
+    // feature.rs:133 slice_move(s![.., ..num_cepstral]) panics for num_cepstral > num_filters
+    if (p.num_cepstral == 0 || p.num_cepstral > p.num_filters)
+        return fail(SS_ERR_BAD_CONFIG, "num_cepstral must be in [1, num_filters]");
+    const float sr = static_cast<float>(p.sample_rate);
+    if (!(p.high_frequency <= sr / 2.0f))  // feature.rs:47-50
+        return fail(SS_ERR_BAD_CONFIG, "High frequency cannot be greater than half of the sampling frequency!");
+    if (!(p.low_frequency >= 0.0f))  // feature.rs:51
+        return fail(SS_ERR_BAD_CONFIG, "low frequency cannot be less than zero!");
+    if (p.framing != SS_FRAMING_CONTRACT && p.framing != SS_FRAMING_LITERAL)
+        return fail(SS_ERR_BAD_CONFIG, "framing switch");
+    if (p.spectrum_exponent != 1 && p.spectrum_exponent != 2)
+        return fail(SS_ERR_BAD_CONFIG, "spectrum_exponent must be 1 or 2");
+    if (p.dct_norm != SS_DCT_REFERENCE && p.dct_norm != SS_DCT_ORTHO) return fail(SS_ERR_BAD_CONFIG, "dct_norm switch");
+    if (p.mfcc_window < SS_WINDOW_RECT || p.mfcc_window > SS_WINDOW_VORBIS)
+        return fail(SS_ERR_BAD_CONFIG, "mfcc_window switch");
+    if (p.preemph_coef != 0.0f && p.preemph_shift < 1) return fail(SS_ERR_BAD_CONFIG, "preemph_shift must be >= 1");
+    Derived d;
+    int rc = derive(p, d);
+    if (rc) return rc;
+    // ndfft_r2c asserts the lane length equals the handler size: frames longer than fft_points panic
+    // (processing.rs:146-164); shorter ones are zero-padded.
+    if (d.flen > p.fft_points) return fail(SS_ERR_BAD_CONFIG, "frame longer than fft_points");
+    std::vector<float> fb;
+    std::vector<int32_t> idx;
+    return build_filterbank(p, fb, idx);
+}
+
+int num_frames(const ss_params &p, size_t n, size_t &t)
+{
+    Derived d;
+    int rc = derive(p, d);
+    if (rc) return rc;
+    // processing.rs:101: ((len - flen) as f32 / step as f32).floor() as usize; len < flen underflows.
+    if (n < d.flen) return fail(SS_ERR_SHORT_SIGNAL, "signal shorter than one frame");
+    const float q = floorf(static_cast<float>(n - d.flen) / static_cast<float>(d.step));
+    t = static_cast<size_t>(q);
+    // processing.rs:105: (numframes - 1) underflows for numframes == 0.
+    if (t == 0) return fail(SS_ERR_SHORT_SIGNAL, "signal yields zero frames");
+    return SS_OK;
+}
+
+int stft_rows(const ss_params &p, size_t n, size_t &rows, size_t &real_rows)
+{
+    Derived d;
+    int rc = derive(p, d);
+    if (rc) return rc;
+    if (!d.stft_ok) return fail(SS_ERR_BAD_CONFIG, "STFT path needs fft_points >= 2 * frame_size (functions.rs:136)");
+    // functions.rs:97: (ttd as f32 / frame_size as f32).ceil()
+    rows = static_cast<size_t>(ceilf(static_cast<float>(n) / static_cast<float>(d.hop)));
+    real_rows = rows > d.n_pad ? rows - d.n_pad : 0;
+    return SS_OK;
+}
+
+void vorbis_window(size_t n, float *w)
+{
+    // config.rs:151-160, f64 then cast
+    const double pi = 3.14159265358979323846;
+    const double half = static_cast<double>(n / 2);
+    for (size_t i = 0; i < n; ++i) {
+        const double s = std::sin(0.5 * pi * (static_cast<double>(i) + 0.5) / half);
+        w[i] = static_cast<float>(std::sin(0.5 * pi * s * s));
+    }
+}
+
+void hann_window(size_t n, float *w)
+{
+    // functions.rs:349-357 (periodic Hann, commented out in the reference; optional here)
+    const double pi = 3.14159265358979323846;
+    for (size_t i = 0; i < n; ++i)
+        w[i] = static_cast<float>(0.5 * (1.0 - std::cos(2.0 * pi * static_cast<double>(i) / static_cast<double>(n))));
+}
+
+int build_filterbank(const ss_params &p, std::vector<float> &fb, std::vector<int32_t> &idx)
+{
+    const size_t M = p.num_filters, F = p.fft_points / 2 + 1;
+    const float sr = static_cast<float>(p.sample_rate);
+    auto mel = [](float f) { return 1127.0f * logf(1.0f + f / 700.0f); };     // functions.rs:19-21
+    auto hz = [](float m) { return 700.0f * (expf(m / 1127.0f) - 1.0f); };     // functions.rs:36-41
+    const float lo = mel(p.low_frequency), hi = mel(p.high_frequency);
+    const float dm = (hi - lo) / static_cast<float>(M + 1);                    // ndarray linspace, feature.rs:57-61
+    idx.assign(M + 2, 0);
+    for (size_t i = 0; i < M + 2; ++i) {
+        const float f = hz(lo + dm * static_cast<float>(i));
+        const float v = static_cast<float>(F + 1) * f / sr;                    // feature.rs:69-70
+        idx[i] = v > 0.0f ? static_cast<int32_t>(v) : 0;
+    }
+    fb.assign(M * F, 0.0f);
+    for (size_t i = 0; i < M; ++i) {
+        const int32_t l = idx[i], m = idx[i + 1], r = idx[i + 2];
+        if (r < l || static_cast<size_t>(r) + 1 > F)                           // slice_mut panic, feature.rs:84
+            return fail(SS_ERR_BAD_CONFIG, "mel filter edges fall outside the spectrum");
+        const float lf = static_cast<float>(l), mf = static_cast<float>(m), rf = static_cast<float>(r);
+        for (int32_t x = l; x <= r; ++x) {                                     // triangle, functions.rs:43-60
+            const float xf = static_cast<float>(x);
+            float v = 0.0f;
+            if (xf >= lf && xf < rf) {
+                if (xf <= mf) v = (xf - lf) / (mf - lf);
+                if (mf <= xf) v = (rf - xf) / (rf - mf);
+            }
+            fb[i * F + static_cast<size_t>(x)] = v;
+        }
+    }
+    return SS_OK;
+}
+
+void sparsify(const std::vector<float> &fb, size_t M, size_t F, SparseBank &out)
+{
+    out = SparseBank{};
+    out.start.resize(M);
+    out.len.resize(M);
+    out.off.resize(M);
+    for (size_t m = 0; m < M; ++m) {
+        size_t first = F, last = 0;
+        for (size_t k = 0; k < F; ++k)
+            if (fb[m * F + k] != 0.0f) {
+                if (first == F) first = k;
+                last = k + 1;
+            }
+        out.off[m] = static_cast<int32_t>(out.w.size());
+        if (first == F) {  // empty filter (cfg5 has 19): contributes exactly 0 -> zero_handling -> EPS
+            out.start[m] = 0;
+            out.len[m] = 0;
+            continue;
+        }
+        out.start[m] = static_cast<int32_t>(first);
+        out.len[m] = static_cast<int32_t>(last - first);
+        for (size_t k = first; k < last; ++k) out.w.push_back(fb[m * F + k]);
+        if (out.len[m] > out.max_len) out.max_len = out.len[m];
+        if (static_cast<int32_t>(last) > out.last_bin) out.last_bin = static_cast<int32_t>(last);
+    }
+    if (out.w.empty()) out.w.push_back(0.0f);
+}
+
+int build_tables(const ss_params &p, HostTables &t)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    t.params = p;
+    rc = derive(p, t.d);
+    if (rc) return rc;
+    rc = build_filterbank(p, t.fb_dense, t.fb_idx);
+    if (rc) return rc;
+    sparsify(t.fb_dense, p.num_filters, t.d.n_bins, t.bank);
+
+    t.window_mfcc.clear();
+    if (p.mfcc_window == SS_WINDOW_HANN) {
+        t.window_mfcc.resize(t.d.flen);
+        hann_window(t.d.flen, t.window_mfcc.data());
+    } else if (p.mfcc_window == SS_WINDOW_VORBIS) {
+        t.window_mfcc.resize(t.d.flen);
+        vorbis_window(t.d.flen, t.window_mfcc.data());
+    }
+    t.window_stft.resize(p.fft_points);
+    vorbis_window(p.fft_points, t.window_stft.data());
+
+    const double pi = 3.14159265358979323846;
+    const size_t C = p.fft_points / 2, N = p.fft_points;
+    t.tw_c.resize(2 * C);
+    for (size_t i = 0; i < C; ++i) {
+        const double a = -2.0 * pi * static_cast<double>(i) / static_cast<double>(C);
+        t.tw_c[2 * i] = static_cast<float>(std::cos(a));
+        t.tw_c[2 * i + 1] = static_cast<float>(std::sin(a));
+    }
+    t.tw_n.resize(2 * (C / 2 + 1));
+    for (size_t k = 0; k <= C / 2; ++k) {
+        const double a = -2.0 * pi * static_cast<double>(k) / static_cast<double>(N);
+        t.tw_n[2 * k] = static_cast<float>(std::cos(a));
+        t.tw_n[2 * k + 1] = static_cast<float>(std::sin(a));
+    }
+    const size_t M = p.num_filters, Cc = p.num_cepstral;
+    t.dct.resize(Cc * M);
+    for (size_t k = 0; k < Cc; ++k)
+        for (size_t m = 0; m < M; ++m)
+            t.dct[k * M + m] = static_cast<float>(
+                std::cos(pi * static_cast<double>(k) * (2.0 * static_cast<double>(m) + 1.0) / (2.0 * static_cast<double>(M))));
+    return SS_OK;
+}
+
+}  // namespace ss
+
+// ---- host-only C ABI entry points ------------------------------------------------------------
+
+namespace ss { const std::string &last_error(); }
+
+extern "C" {
+
+int ss_params_default(ss_params *p, uint32_t sample_rate)
+{
+    if (!p) return ss::fail(SS_ERR_ARG, "null params");
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = static_cast<uint32_t>(sizeof(ss_params));
+    p->sample_rate = sample_rate;  // config.rs:35-47
+    p->fft_points = 512;
+    p->frame_length = 0.02f;
+    p->frame_stride = 0.01f;
+    p->num_cepstral = 13;
+    p->num_filters = 40;
+    p->low_frequency = 0.0f;
+    p->high_frequency = static_cast<float>(sample_rate) / 2.0f;
+    p->dc_elimination = 1;
+    p->framing = SS_FRAMING_CONTRACT;
+    p->spectrum_exponent = 1;
+    p->dct_norm = SS_DCT_REFERENCE;
+    p->dct2_gain = SS_DCT2_GAIN;
+    p->mfcc_window = SS_WINDOW_RECT;
+    p->preemph_coef = 0.0f;
+    p->preemph_shift = 1;
+    return SS_OK;
+}
+
+int ss_params_validate(const ss_params *p)
+{
+    if (!p) return ss::fail(SS_ERR_ARG, "null params");
+    return ss::validate(*p);
+}
+
+int ss_frame_sizes(const ss_params *p, size_t *frame_len, size_t *frame_step)
+{
+    if (!p || !frame_len || !frame_step) return ss::fail(SS_ERR_ARG, "null argument");
+    ss::Derived d;
+    int rc = ss::derive(*p, d);
+    if (rc) return rc;
+    *frame_len = d.flen;
+    *frame_step = d.step;
+    return SS_OK;
+}
+
+int ss_num_frames(const ss_params *p, size_t n_samples, size_t *n_frames)
+{
+    if (!p || !n_frames) return ss::fail(SS_ERR_ARG, "null argument");
+    size_t t = 0;
+    int rc = ss::num_frames(*p, n_samples, t);
+    if (rc) return rc;
+    *n_frames = t;
+    return SS_OK;
+}
+
+int ss_stft_sizes(const ss_params *p, size_t *hop, size_t *n_pad, float *wnorm)
+{
+    if (!p || !hop || !n_pad || !wnorm) return ss::fail(SS_ERR_ARG, "null argument");
+    ss::Derived d;
+    int rc = ss::derive(*p, d);
+    if (rc) return rc;
+    if (!d.stft_ok) return ss::fail(SS_ERR_BAD_CONFIG, "STFT path needs fft_points >= 2 * frame_size (functions.rs:136)");
+    *hop = d.hop;
+    *n_pad = d.n_pad;
+    *wnorm = d.wnorm;
+    return SS_OK;
+}
+
+int ss_stft_rows(const ss_params *p, size_t n_samples, size_t *rows, size_t *real_rows)
+{
+    if (!p || !rows || !real_rows) return ss::fail(SS_ERR_ARG, "null argument");
+    return ss::stft_rows(*p, n_samples, *rows, *real_rows);
+}
+
+int ss_filterbank(const ss_params *p, float *fb, int32_t *idx)
+{
+    if (!p || !fb) return ss::fail(SS_ERR_ARG, "null argument");
+    int rc = ss::validate(*p);
+    if (rc) return rc;
+    std::vector<float> dense;
+    std::vector<int32_t> id;
+    rc = ss::build_filterbank(*p, dense, id);
+    if (rc) return rc;
+    std::memcpy(fb, dense.data(), dense.size() * sizeof(float));
+    if (idx) std::memcpy(idx, id.data(), id.size() * sizeof(int32_t));
+    return SS_OK;
+}
+
+int ss_vorbis_window(size_t n, float *w)
+{
+    if (!w || n < 2) return ss::fail(SS_ERR_ARG, "bad window request");
+    ss::vorbis_window(n, w);
+    return SS_OK;
+}
+
+const char *ss_status_string(int status)
+{
+    switch (status) {
+        case SS_OK: return "ok";
+        case SS_ERR_SHORT_SIGNAL: return "signal too short for one frame";
+        case SS_ERR_BAD_CONFIG: return "invalid configuration";
+        case SS_ERR_ARG: return "invalid argument";
+        case SS_ERR_HIP: return "HIP runtime error / no device";
+        case SS_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+const char *ss_last_error_string(void) { return ss::last_error().c_str(); }
+int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Internal declarations shared by the host-side table builder (ss_host.cpp) and the HIP side
+// (ss_kernels.hip, ss_api.hip).  Not part of the public ABI.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "speechsauce_amd.h"
+
+namespace ss {
+
+constexpr float kEpsF32 = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
+
+struct Derived {
+    // MFCC path (processing.rs:77-78)
+    uint32_t flen = 0, step = 0;
+    // STFT path (config.rs:154,178; functions.rs:96); stft_ok=false when fft_points < 2*hop
+    bool stft_ok = false;
+    uint32_t hop = 0, n_pad = 0;
+    float wnorm = 0.f;
+    uint32_t n_fft = 0, n_bins = 0, log2c = 0;  // c = n_fft/2 complex points
+};
+
+// Sparse triangular bank: filter m covers bins [start[m], start[m]+len[m]) with weights
+// w[off[m] .. off[m]+len[m]).  Built from the dense bank so the numbers are the reference's.
+struct SparseBank {
+    std::vector<int32_t> start, len, off;
+    std::vector<float> w;
+    int32_t max_len = 0;
+    int32_t last_bin = 0;  // one past the highest bin with a non-zero weight
+};
+
+struct HostTables {
+    ss_params params{};
+    Derived d{};
+    std::vector<float> fb_dense;      // [M x F]
+    std::vector<int32_t> fb_idx;      // [M+2]
+    SparseBank bank;
+    std::vector<float> window_mfcc;   // [flen] or empty (rect)
+    std::vector<float> window_stft;   // [n_fft] Vorbis
+    std::vector<float> tw_c;          // interleaved re,im: exp(-2*pi*i*t/C), t in [0,C)
+    std::vector<float> tw_n;          // interleaved re,im: exp(-2*pi*i*k/N), k in [0,C/2]
+    std::vector<float> dct;           // [num_cepstral x M] cos(pi*k*(2m+1)/(2M))
+};
+
+void set_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+
+int validate(const ss_params &p);
+int derive(const ss_params &p, Derived &d);
+int num_frames(const ss_params &p, size_t n, size_t &t);
+int stft_rows(const ss_params &p, size_t n, size_t &rows, size_t &real_rows);
+int build_filterbank(const ss_params &p, std::vector<float> &fb, std::vector<int32_t> &idx);
+void sparsify(const std::vector<float> &fb, size_t M, size_t F, SparseBank &out);
+void vorbis_window(size_t n, float *w);
+void hann_window(size_t n, float *w);
+int build_tables(const ss_params &p, HostTables &t);
+
+}  // namespace ss

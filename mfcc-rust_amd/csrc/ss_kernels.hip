@@ -1,0 +1,483 @@
+// HIP kernels for the speechsauce hot path on gfx950 (MI355X, wave64).
+//
+// ss_front_generic<LOG2C>: framing -> (pre-emphasis, window) -> R2C FFT -> magnitude/power ->
+// sparse mel -> log -> DCT-II, one launch, any power-of-two fft_points in [32, 4096].
+//
+//   * A real frame of N = 2C samples is packed as C complex points z[n] = x[2n] + i x[2n+1]
+//     and transformed by a Stockham autosort FFT whose butterflies live in registers: every
+//     thread owns 16 complex points, so C/16 threads cooperate on a frame and a 256-thread
+//     workgroup carries 4096/C frames per pass.  Radix plan: 16, then 16, then C/256 (or 16
+//     then C/16 for C < 256): at most three LDS exchanges per frame.
+//   * The LDS exchange buffer uses the padded index i + (i >> 4): the stride-16 scatter of the
+//     first pass then lands on distinct banks for the 16 lanes of a ds_write_b64 group.
+//   * X[k] is untangled from Z[k], Z[C-k] pairwise, magnitudes go to an LDS row, the mel bank is
+//     a banded reduction over that row (CSR-like start/len/weights; no MFMA - at most two
+//     filters touch a bin), and the DCT-II is a [n_ceps x n_filters] table product.
+//   * HBM traffic: the clip samples once (neighbouring frames re-read them through L1/L2) and
+//     the features once.
+//
+// Reference semantics (file:line relative to the reference checkout) are cited at each stage.
+#include "ss_device.h"
+
+namespace ss {
+
+namespace {
+
+constexpr float kEps = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -i
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+// Forward 4-point DFT (exp(-2 pi i nk/4)), natural order in and out.
+__device__ __forceinline__ void fft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
+{
+    const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2);
+    const float2 a2 = cadd(v1, v3), a3 = mul_mi(csub(v1, v3));
+    v0 = cadd(a0, a2);
+    v1 = cadd(a1, a3);
+    v2 = csub(a0, a2);
+    v3 = csub(a1, a3);
+}
+
+template <int R>
+__device__ __forceinline__ void fft_reg(float2 *v);
+
+template <>
+__device__ __forceinline__ void fft_reg<2>(float2 *v)
+{
+    const float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+
+template <>
+__device__ __forceinline__ void fft_reg<4>(float2 *v)
+{
+    fft4(v[0], v[1], v[2], v[3]);
+}
+
+// n = n1 + 2 n2, k = 4 k1 + k2: W8^(nk) = W2^(n1 k1) W8^(n1 k2) W4^(n2 k2)
+template <>
+__device__ __forceinline__ void fft_reg<8>(float2 *v)
+{
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4(e0, e1, e2, e3);
+    fft4(o0, o1, o2, o3);
+    constexpr float h = 0.70710678118654752440f;
+    o1 = make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));   // * (h - i h)
+    o2 = mul_mi(o2);                                           // * -i
+    o3 = make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));  // * (-h - i h)
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+// n = n1 + 4 n2, k = 4 k1 + k2: W16^(nk) = W4^(n1 k1) W16^(n1 k2) W4^(n2 k2)
+template <>
+__device__ __forceinline__ void fft_reg<16>(float2 *v)
+{
+    // step A: for each n1, 4-point DFT over n2 (elements n1, n1+4, n1+8, n1+12) -> Y[n1][k2] kept in place
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) fft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+    // step B: Y[n1][k2] *= W16^(n1 k2); Y[n1][k2] sits in v[n1 + 4 k2]
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    constexpr float h = 0.70710678118654752440f;
+    // n1 = 1: W16^k2, k2 = 1,2,3
+    v[5] = cmul(v[5], make_float2(c1, -s1));
+    v[9] = make_float2(h * (v[9].x + v[9].y), h * (v[9].y - v[9].x));
+    v[13] = cmul(v[13], make_float2(s1, -c1));
+    // n1 = 2: W16^(2 k2) = W8^k2
+    v[6] = make_float2(h * (v[6].x + v[6].y), h * (v[6].y - v[6].x));
+    v[10] = mul_mi(v[10]);
+    v[14] = make_float2(h * (v[14].y - v[14].x), -h * (v[14].x + v[14].y));
+    // n1 = 3: W16^(3 k2): k2=1 -> W16^3, k2=2 -> W16^6, k2=3 -> W16^9
+    v[7] = cmul(v[7], make_float2(s1, -c1));
+    v[11] = make_float2(h * (v[11].y - v[11].x), -h * (v[11].x + v[11].y));
+    v[15] = cmul(v[15], make_float2(-c1, s1));
+    // step C: for each k2, 4-point DFT over n1 (elements 4 k2 + n1) -> X[4 k1 + k2]
+    float2 y[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        float2 a = v[4 * k2], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
+        fft4(a, b, c, d);
+        y[k2] = a;
+        y[4 + k2] = b;
+        y[8 + k2] = c;
+        y[12 + k2] = d;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = y[i];
+}
+
+__device__ __forceinline__ int phys(int i) { return i + (i >> 4); }
+
+// One Stockham pass of radix R with sub-transform length NS already done, on a frame of C points
+// held 16 per thread.  `j` is the thread index within the frame (TPF = C/16 threads).
+// Loads happen before the barrier-separated stores, so the pass works in place.
+template <int LOG2C, int R, int NS, bool kLoad>
+__device__ __forceinline__ void stockham_pass(float2 *zbuf, int j, const float2 *__restrict__ tw_c, float2 (&v)[16])
+{
+    constexpr int C = 1 << LOG2C;
+    constexpr int TPF = C / 16 > 0 ? C / 16 : 1;
+    constexpr int NB = 16 / R;  // butterflies per thread
+    constexpr int STRIDE = C / R;
+    if (kLoad) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int b = j + TPF * q;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[q * R + r] = zbuf[phys(b + r * STRIDE)];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int b = j + TPF * q;
+        if (NS > 1) {
+            const int k = b & (NS - 1);
+            constexpr int TWS = C / (NS * R);  // exp(-2 pi i k r / (NS R)) = tw_c[k r TWS]
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw_c[k * r * TWS]);
+        }
+        fft_reg<R>(&v[q * R]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int b = j + TPF * q;
+        const int k = b & (NS - 1);
+        const int j0 = (b - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) zbuf[phys(j0 + r * NS)] = v[q * R + r];
+    }
+}
+
+// Full C-point complex FFT of the frame whose pass-1 inputs are already in v
+// (v[e] = z[j + e * TPF]).  Result: natural order Z[k] at zbuf[phys(k)] (after a barrier).
+template <int LOG2C>
+__device__ __forceinline__ void frame_fft(float2 *zbuf, int j, const float2 *__restrict__ tw_c, float2 (&v)[16])
+{
+    constexpr int C = 1 << LOG2C;
+    stockham_pass<LOG2C, 16, 1, false>(zbuf, j, tw_c, v);
+    if constexpr (LOG2C >= 8) {
+        stockham_pass<LOG2C, 16, 16, true>(zbuf, j, tw_c, v);
+        if constexpr (LOG2C > 8) stockham_pass<LOG2C, C / 256, 256, true>(zbuf, j, tw_c, v);
+    } else if constexpr (LOG2C > 4) {
+        stockham_pass<LOG2C, C / 16, 16, true>(zbuf, j, tw_c, v);
+    }
+    __syncthreads();
+}
+
+template <int LOG2C>
+struct Geo {
+    static constexpr int C = 1 << LOG2C;
+    static constexpr int N = 2 * C;
+    static constexpr int F = C + 1;
+    static constexpr int TPF = C / 16;           // threads per frame
+    static constexpr int FPB = kBlock / TPF;     // frames per workgroup pass
+    static constexpr int ZLEN = C + C / 16;      // padded complex buffer
+    static constexpr int PLEN = (F + 3) & ~3;    // magnitude row
+};
+
+// Untangle Z -> X (real-input FFT of length N from the packed C-point FFT), scale, take
+// magnitude / power, store the row to LDS and return this thread's partial row sum.
+//   X[k]   = 1/2 [ (Z[k] + conj Z[C-k]) - i w (Z[k] - conj Z[C-k]) ],  w = exp(-2 pi i k / N)
+//   X[C-k] = conj( 1/2 [ (Z[k] + conj Z[C-k]) + i w (Z[k] - conj Z[C-k]) ] )
+template <int LOG2C>
+__device__ __forceinline__ float untangle_row(const float2 *zbuf, float *prow, float2 *stft_row, int j,
+                                              const FrontArgs &a, bool mel_mode, bool active)
+{
+    using G = Geo<LOG2C>;
+    float esum = 0.0f;
+    for (int k = j; k <= G::C / 2; k += G::TPF) {
+        const float2 zk = zbuf[phys(k)];
+        const float2 zc = zbuf[phys((G::C - k) & (G::C - 1))];
+        const float2 w = a.tw_n[k];
+        const float2 s = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));  // E[k]
+        const float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+        // -i w d  with d = (Z[k] - conj Z[C-k])/2
+        const float2 wd = cmul(w, d);
+        const float2 t = make_float2(wd.y, -wd.x);
+        float2 xa = cadd(s, t);           // X[k]
+        float2 xb = csub(s, t);           // conj X[C-k]
+        xb.y = -xb.y;
+        float pa, pb;
+        if (mel_mode) {
+            // functions.rs:166-169 (* wnorm) then feature.rs:164 (abs().powi(2))
+            xa.x *= a.scale; xa.y *= a.scale;
+            xb.x *= a.scale; xb.y *= a.scale;
+            pa = xa.x * xa.x + xa.y * xa.y;
+            pb = xb.x * xb.x + xb.y * xb.y;
+            if (stft_row && active) {
+                stft_row[k] = xa;
+                if (k != G::C / 2) stft_row[G::C - k] = xb;
+            }
+        } else {
+            // processing.rs:168 sqrt(re^2 + im^2), :180 * (1/N)
+            const float ma = sqrtf(xa.x * xa.x + xa.y * xa.y);
+            const float mb = sqrtf(xb.x * xb.x + xb.y * xb.y);
+            pa = a.spectrum_exponent == 2 ? a.scale * (ma * ma) : a.scale * ma;
+            pb = a.spectrum_exponent == 2 ? a.scale * (mb * mb) : a.scale * mb;
+        }
+        prow[k] = pa;
+        esum += pa;
+        if (k != G::C / 2) {
+            prow[G::C - k] = pb;
+            esum += pb;
+        }
+    }
+    return esum;
+}
+
+// Banded mel reduction of one magnitude row (feature.rs:229 / :173 restricted to the non-zero taps).
+__device__ __forceinline__ float mel_dot(const float *prow, const FrontArgs &a, int m)
+{
+    const int st = a.f_start[m], ln = a.f_len[m];
+    const float *w = a.f_w + a.f_off[m];
+    float s = 0.0f;
+    for (int i = 0; i < ln; ++i) s = fmaf(w[i], prow[st + i], s);
+    return s;
+}
+
+template <int LOG2C>
+__global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
+{
+    using G = Geo<LOG2C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int slot = tid / G::TPF;  // frame slot within the workgroup pass
+    const int j = tid % G::TPF;     // thread within the frame
+
+    const int M = static_cast<int>(a.n_filters);
+    const int mpad = (M + 3) & ~3;
+    // per-slot LDS carve: zbuf | prow | frow | red
+    const size_t slot_bytes = sizeof(float2) * G::ZLEN + sizeof(float) * (G::PLEN + mpad + G::TPF + 4);
+    unsigned char *sbase = smem_raw + slot_bytes * slot;
+    float2 *zbuf = reinterpret_cast<float2 *>(sbase);
+    float *prow = reinterpret_cast<float *>(sbase + sizeof(float2) * G::ZLEN);
+    float *frow = prow + G::PLEN;
+    float *red = frow + mpad;
+    // MEL mode: transposed output tile [M][rows_tile + 1] after all slots
+    float *tile = reinterpret_cast<float *>(smem_raw + slot_bytes * G::FPB);
+
+    const bool mel_mode = a.out_kind == OUT_MEL || a.out_kind == OUT_STFT;
+
+    if (!mel_mode) {
+        // ---------------- MFCC / MFE / power-spectrum path: flat list of B*T frames ----------------
+        const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
+        const unsigned long long groups = (total + G::FPB - 1) / G::FPB;
+        for (unsigned long long g = blockIdx.x; g < groups; g += gridDim.x) {
+            const unsigned long long gf = g * G::FPB + slot;
+            const bool active = gf < total;
+            const unsigned clip = active ? static_cast<unsigned>(gf / a.n_frames) : 0u;
+            const unsigned t = active ? static_cast<unsigned>(gf - static_cast<unsigned long long>(clip) * a.n_frames) : 0u;
+            const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+            // stack_frames (processing.rs:65-129, contract framing) + zero pad to N (:147-156)
+            const unsigned base = a.frame_mode == FRAME_NORMAL ? t * a.step : 0u;
+            const unsigned lim = a.frame_mode == FRAME_ZERO ? 0u : (a.frame_mode == FRAME_FIRST ? (a.flen & ~1u) : a.flen);
+            float2 v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned n = static_cast<unsigned>(j + e * G::TPF);
+                float s[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned i = 2 * n + h;
+                    float val = 0.0f;
+                    if (active && i < lim) {
+                        const unsigned idx = base + i;
+                        val = xc[idx];
+                        if (a.preemph != 0.0f) {  // processing.rs:31-53 fused
+                            const unsigned sh = a.preemph_shift % a.n_samples;
+                            const unsigned jdx = idx >= sh ? idx - sh : idx + a.n_samples - sh;
+                            val -= a.preemph * xc[jdx];
+                        }
+                        if (a.window) val *= a.window[i];
+                    }
+                    s[h] = val;
+                }
+                v[e] = make_float2(s[0], s[1]);
+            }
+            frame_fft<LOG2C>(zbuf, j, a.tw_c, v);
+            const float part = untangle_row<LOG2C>(zbuf, prow, nullptr, j, a, false, active);
+            red[j] = part;
+            __syncthreads();
+
+            if (a.out_kind == OUT_POWER) {
+                if (active) {
+                    float *dst = a.out0 + gf * G::F;
+                    for (int k = j; k < G::F; k += G::TPF) dst[k] = prow[k];
+                }
+            } else {
+                // feature.rs:216-219: frame energy + zero handling (deterministic serial sum)
+                float energy = 0.0f;
+                for (int i = 0; i < G::TPF; ++i) energy += red[i];
+                energy = energy == 0.0f ? kEps : energy;
+                // feature.rs:229-230 banded; zero handling
+                for (int m = j; m < M; m += G::TPF) {
+                    float s = mel_dot(prow, a, m);
+                    s = s == 0.0f ? kEps : s;
+                    if (a.out_kind == OUT_MFE) {
+                        if (active) a.out0[gf * M + m] = s;
+                    } else {
+                        frow[m] = logf(s);  // feature.rs:105
+                    }
+                }
+                if (a.out_kind == OUT_MFE) {
+                    if (active && j == 0) a.out1[gf] = energy;
+                } else {
+                    __syncthreads();
+                    // feature.rs:120-146: DCT-II (first n_ceps outputs), scaling, column-0 replacement
+                    const int Cc = static_cast<int>(a.n_ceps);
+                    for (int c = j; c < Cc; c += G::TPF) {
+                        const float *row = a.dct + c * M;
+                        float s = 0.0f;
+                        for (int m = 0; m < M; ++m) s = fmaf(frow[m], row[m], s);
+                        float o;
+                        if (c == 0) o = a.dc_elimination ? logf(energy) : s * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                        else o = s * a.dct_scale_k;
+                        if (active) a.out0[gf * Cc + c] = o;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------- STFT / mel-spectrogram path: one clip (channel) per workgroup visit -------
+        const int R = static_cast<int>(a.rows);
+        const int Rreal = static_cast<int>(a.real_rows);
+        const int W = G::N;
+        constexpr int TILE = 32;  // rows buffered before a transposed, coalesced flush
+        for (unsigned clip = blockIdx.x; clip < a.batch; clip += gridDim.x) {
+            const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+            for (int r0 = 0; r0 < R; r0 += TILE) {
+                const int rt = min(TILE, R - r0);
+                for (int rp = 0; rp < rt; rp += G::FPB) {
+                    const int rl = rp + slot;       // row within the tile
+                    const int r = r0 + rl;          // output row
+                    const bool active = rl < rt && r < Rreal;
+                    // functions.rs:137-151: window over the last W samples ending at chunk r + n_pad
+                    const long long start = static_cast<long long>(r + a.n_pad + 1) * a.hop - W;
+                    float2 v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int n = j + e * G::TPF;
+                        float s[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int i = 2 * n + h;
+                            const long long idx = start + i;
+                            float val = 0.0f;
+                            if (active && idx >= 0 && idx < static_cast<long long>(a.n_samples)) val = xc[idx] * a.window[i];
+                            s[h] = val;
+                        }
+                        v[e] = make_float2(s[0], s[1]);
+                    }
+                    frame_fft<LOG2C>(zbuf, j, a.tw_c, v);
+                    float2 *stft_row = nullptr;
+                    if (a.out_kind == OUT_STFT)
+                        stft_row = reinterpret_cast<float2 *>(a.out0) + (static_cast<unsigned long long>(clip) * R + r) * G::F;
+                    untangle_row<LOG2C>(zbuf, prow, stft_row, j, a, true, active);
+                    __syncthreads();
+                    if (a.out_kind == OUT_MEL && rl < rt) {
+                        // feature.rs:173: out[n,m,t] = sum_f P[n,t,f] fb[m,f]; rows >= real_rows stay zero
+                        for (int m = j; m < M; m += G::TPF) tile[m * (TILE + 1) + rl] = active ? mel_dot(prow, a, m) : 0.0f;
+                    }
+                    if (a.out_kind == OUT_STFT && rl < rt && r >= Rreal) {
+                        for (int k = j; k < G::F; k += G::TPF) stft_row[k] = make_float2(0.0f, 0.0f);
+                    }
+                    __syncthreads();
+                }
+                if (a.out_kind == OUT_MEL) {
+                    float *dst = a.out0 + static_cast<unsigned long long>(clip) * M * R;
+                    for (int i = tid; i < M * rt; i += kBlock) {
+                        const int m = i / rt, rl = i - m * rt;
+                        dst[static_cast<unsigned long long>(m) * R + r0 + rl] = tile[m * (TILE + 1) + rl];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
+template <int LOG2C>
+size_t front_lds_bytes(const FrontArgs &a)
+{
+    using G = Geo<LOG2C>;
+    const size_t mpad = (a.n_filters + 3) & ~3u;
+    const size_t slot_bytes = sizeof(float2) * G::ZLEN + sizeof(float) * (G::PLEN + mpad + G::TPF + 4);
+    size_t total = slot_bytes * G::FPB;
+    if (a.out_kind == OUT_MEL) total += sizeof(float) * a.n_filters * 33;
+    return (total + 15) & ~static_cast<size_t>(15);
+}
+
+template <int LOG2C>
+hipError_t launch_one(const FrontArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info, const char *name)
+{
+    using G = Geo<LOG2C>;
+    const size_t lds = front_lds_bytes<LOG2C>(a);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ss_front_generic<LOG2C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    unsigned long long work;
+    if (a.out_kind == OUT_MEL || a.out_kind == OUT_STFT) work = a.batch;
+    else work = (static_cast<unsigned long long>(a.batch) * a.n_frames + G::FPB - 1) / G::FPB;
+    if (work == 0) return hipSuccess;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * 8;
+    const unsigned grid = static_cast<unsigned>(work < cap ? work : cap);
+    if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kBlock), lds};
+    hipLaunchKernelGGL(ss_front_generic<LOG2C>, dim3(grid), dim3(kBlock), lds, stream, a);
+    return hipGetLastError();
+}
+
+__global__ void ss_preemphasis_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n, size_t shift, float cof)
+{
+    // processing.rs:31-53: y[i] = x[i] - cof * x[(i - shift) mod n]
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t jx = i >= shift ? i - shift : i + n - shift;
+        y[i] = x[i] - cof * x[jx];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    switch (log2c) {
+        case 4: return launch_one<4>(a, stream, num_cus, info, "ss_front_generic<4>");
+        case 5: return launch_one<5>(a, stream, num_cus, info, "ss_front_generic<5>");
+        case 6: return launch_one<6>(a, stream, num_cus, info, "ss_front_generic<6>");
+        case 7: return launch_one<7>(a, stream, num_cus, info, "ss_front_generic<7>");
+        case 8: return launch_one<8>(a, stream, num_cus, info, "ss_front_generic<8>");
+        case 9: return launch_one<9>(a, stream, num_cus, info, "ss_front_generic<9>");
+        case 10: return launch_one<10>(a, stream, num_cus, info, "ss_front_generic<10>");
+        case 11: return launch_one<11>(a, stream, num_cus, info, "ss_front_generic<11>");
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_preemphasis(const float *x, float *y, size_t n, size_t shift, float cof, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned block = 256;
+    size_t blocks = (n + block - 1) / block;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ss_preemphasis_kernel, dim3(static_cast<unsigned>(blocks)), dim3(block), 0, stream, x, y, n, shift, cof);
+    return hipGetLastError();
+}
+
+}  // namespace ss

@@ -1,0 +1,257 @@
+"""speechsauce_amd -- Python front of the MI355X-native MFCC / mel-spectrogram hot path.
+
+Drop-in for the hot-path functions of the reference's ``speechsauce`` package
+(py-speechsauce/speechsauce/__init__.py:37-132): the same names, keyword arguments, defaults,
+dtype rule (float32 only) and output shapes, served by hand-written HIP kernels through the C ABI
+in ``include/speechsauce_amd.h``.  ``import speechsauce_amd as speechsauce`` is the intended use.
+
+Inputs may be numpy arrays (host path: H2D, kernels, D2H inside the library) or torch tensors on
+a ROCm device (zero-copy device path on torch's current stream; the result is a torch tensor).
+There is no CPU compute path: without the built library and a HIP device these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import lru_cache
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import SpeechSauceError, SsParams, make_params  # noqa: F401
+
+__all__ = ["mfcc", "mel_spectrogram", "preemphasis", "mfe", "mfcc_batch", "mfe_batch", "SpeechConfig",
+           "SpeechSauceError"]
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class SpeechConfig:
+    """Owns an ``ss_config`` handle: the counterpart of ``PySpeechSauce(SpeechConfig)``
+    (py-speechsauce/src/lib.rs:7-10; speechsauce/src/config.rs:99-185)."""
+
+    def __init__(self, params: SsParams):
+        self.params = params
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ss_config_create(C.byref(params), C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().ss_config_destroy(h)
+            except Exception:
+                pass
+
+    # ---- derived sizes -------------------------------------------------------------------
+    def num_frames(self, n_samples: int) -> int:
+        t = C.c_size_t()
+        _lib.check(_lib.lib().ss_num_frames(C.byref(self.params), n_samples, C.byref(t)))
+        return t.value
+
+    def stft_rows(self, n_samples: int) -> tuple[int, int]:
+        r, rr = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib().ss_stft_rows(C.byref(self.params), n_samples, C.byref(r), C.byref(rr)))
+        return r.value, rr.value
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+
+def _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                   low_frequency, dc_elimination, high_frequency=None, **switches) -> SpeechConfig:
+    """Same positional order as ``_internal._speech_config`` (py-speechsauce/src/lib.rs:226-254)."""
+    return SpeechConfig(make_params(
+        sample_rate=sampling_frequency, fft_points=fft_length, frame_length=frame_length,
+        frame_stride=frame_stride, num_cepstral=num_cepstral, num_filters=num_filters,
+        low_frequency=low_frequency, high_frequency=high_frequency, dc_elimination=dc_elimination, **switches))
+
+
+@lru_cache(maxsize=32)
+def _get_speech_config(sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13, num_filters=40,
+                       fft_length=512, low_frequency=0, high_frequency: Optional[float] = None,
+                       dc_elimination=True, switches: tuple = ()) -> SpeechConfig:
+    """Memoised config factory (py-speechsauce/speechsauce/__init__.py:8-34)."""
+    return _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                          low_frequency, dc_elimination, high_frequency, **dict(switches))
+
+
+def _require_f32(signal, ndims: tuple[int, ...], what: str):
+    """The binding takes PyReadonlyArray<f32> only (py-speechsauce/src/lib.rs:170,182): no silent casts."""
+    if _is_torch(signal):
+        import torch
+
+        if signal.dtype != torch.float32:
+            raise TypeError(f"{what}: signal must be float32, got {signal.dtype}")
+        if signal.dim() not in ndims:
+            raise ValueError(f"{what}: Input signal must be {' or '.join(str(d) + 'd' for d in ndims)}")
+        if not signal.is_cuda:
+            signal = signal.detach().numpy()
+        return signal
+    arr = np.asarray(signal)
+    if arr.dtype != np.float32:
+        raise TypeError(f"{what}: signal must be float32, got {arr.dtype}")
+    if arr.ndim not in ndims:
+        raise ValueError(f"{what}: Input signal must be {' or '.join(str(d) + 'd' for d in ndims)}")
+    return arr
+
+
+def _stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- internal entry points (the `_internal` pyfns, py-speechsauce/src/lib.rs:167-204) -------------
+
+def _internal_mfcc_batch(signal, config: SpeechConfig):
+    """signal [B, L] -> [B, T, num_cepstral]"""
+    lib = _lib.lib()
+    B, L = signal.shape
+    T = config.num_frames(L)
+    Cc = config.params.num_cepstral
+    if _is_torch(signal):
+        import torch
+
+        x = signal if signal.stride(1) == 1 else signal.contiguous()
+        out = torch.empty((B, T, Cc), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_mfcc_batch_device(config.handle, x.data_ptr(), B, L, x.stride(0) if B > 1 else L,
+                                                out.data_ptr(), _stream_ptr()))
+        return out
+    x = np.ascontiguousarray(signal)
+    out = np.empty((B, T, Cc), dtype=np.float32)
+    _lib.check(lib.ss_mfcc_batch(config.handle, x.ctypes.data, B, L, L, out.ctypes.data))
+    return out
+
+
+def _internal_mfe_batch(signal, config: SpeechConfig):
+    lib = _lib.lib()
+    B, L = signal.shape
+    T = config.num_frames(L)
+    M = config.params.num_filters
+    if _is_torch(signal):
+        import torch
+
+        x = signal if signal.stride(1) == 1 else signal.contiguous()
+        feat = torch.empty((B, T, M), dtype=torch.float32, device=x.device)
+        en = torch.empty((B, T), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_mfe_batch_device(config.handle, x.data_ptr(), B, L, x.stride(0) if B > 1 else L,
+                                               feat.data_ptr(), en.data_ptr(), _stream_ptr()))
+        return feat, en
+    x = np.ascontiguousarray(signal)
+    feat = np.empty((B, T, M), dtype=np.float32)
+    en = np.empty((B, T), dtype=np.float32)
+    _lib.check(lib.ss_mfe_batch(config.handle, x.ctypes.data, B, L, L, feat.ctypes.data, en.ctypes.data))
+    return feat, en
+
+
+def _internal_mel_spectrogram(signal, config: SpeechConfig):
+    """1-D -> [n_mels, rows]; 2-D [C, L] -> [C, n_mels, rows] (py-speechsauce/src/lib.rs:179-204)."""
+    lib = _lib.lib()
+    one_d = signal.ndim == 1
+    sig2 = signal[None, :] if one_d else signal
+    ch, L = sig2.shape
+    R, _ = config.stft_rows(L)
+    M = config.params.num_filters
+    if _is_torch(sig2):
+        import torch
+
+        x = sig2 if sig2.stride(1) == 1 else sig2.contiguous()
+        out = torch.empty((ch, M, R), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_mel_spectrogram_device(config.handle, x.data_ptr(), ch, L, x.stride(0) if ch > 1 else L,
+                                                     out.data_ptr(), _stream_ptr()))
+    else:
+        x = np.ascontiguousarray(sig2)
+        out = np.empty((ch, M, R), dtype=np.float32)
+        _lib.check(lib.ss_mel_spectrogram(config.handle, x.ctypes.data, ch, L, out.ctypes.data))
+    return out[0] if one_d else out
+
+
+# ---- public API (py-speechsauce/speechsauce/__init__.py:37-132) ------------------------------------
+
+def _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length, low_frequency,
+         high_frequency, dc_elimination, switches) -> SpeechConfig:
+    return _get_speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                              low_frequency, high_frequency, dc_elimination, tuple(sorted(switches.items())))
+
+
+def mfcc(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13, num_filters=40,
+         fft_length=512, low_frequency=0, high_frequency=None, dc_elimination=True, **switches):
+    """MFCC features of a 1-D float32 signal -> (num_frames, num_cepstral).
+
+    Mirrors ``speechsauce.mfcc`` (py-speechsauce/speechsauce/__init__.py:37-83 -> feature.rs:99-148).
+    ``switches`` are the SURVEY section-0 options (framing, spectrum_exponent, dct_norm, dct2_gain,
+    mfcc_window, preemph_coef, preemph_shift); none given == reference mode.
+    """
+    sig = _require_f32(signal, (1,), "mfcc")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                  low_frequency, high_frequency, dc_elimination, switches)
+    return _internal_mfcc_batch(sig[None, :], config)[0]
+
+
+def mfcc_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13, num_filters=40,
+               fft_length=512, low_frequency=0, high_frequency=None, dc_elimination=True, **switches):
+    """Batch form: [B, L] float32 -> [B, num_frames, num_cepstral] in one launch."""
+    sig = _require_f32(signals, (2,), "mfcc_batch")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                  low_frequency, high_frequency, dc_elimination, switches)
+    return _internal_mfcc_batch(sig, config)
+
+
+def mfe(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_filters=40, fft_length=512,
+        low_frequency=0, high_frequency=None, **switches):
+    """Mel filterbank energies and frame energies (feature.rs:200-233): ((T, num_filters), (T,))."""
+    sig = _require_f32(signal, (1,), "mfe")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
+                  low_frequency, high_frequency, True, switches)
+    feat, en = _internal_mfe_batch(sig[None, :], config)
+    return feat[0], en[0]
+
+
+def mfe_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_filters=40, fft_length=512,
+              low_frequency=0, high_frequency=None, **switches):
+    sig = _require_f32(signals, (2,), "mfe_batch")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
+                  low_frequency, high_frequency, True, switches)
+    return _internal_mfe_batch(sig, config)
+
+
+def mel_spectrogram(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13,
+                    num_filters=40, fft_length=512, low_frequency=0, high_frequency=None, dc_elimination=True,
+                    **switches):
+    """Mel spectrogram of a 1-D or 2-D float32 signal -> (..., n_mels, time).
+
+    Mirrors ``speechsauce.mel_spectrogram`` (py-speechsauce/speechsauce/__init__.py:85-132 ->
+    feature.rs:151-174).  The STFT hop is ``frame_length * sampling_frequency`` samples and the
+    window is ``fft_length`` samples (config.rs:154, functions.rs:96-101); the reference panics
+    unless ``fft_length >= 2 * hop`` -- that raises SpeechSauceError here.
+    """
+    sig = _require_f32(signal, (1, 2), "mel_spectrogram")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                  low_frequency, high_frequency, dc_elimination, switches)
+    return _internal_mel_spectrogram(sig, config)
+
+
+def preemphasis(signal, shift=1, cof=0.98):
+    """y[n] = x[n] - cof * x[(n - shift) mod N]  (processing.rs:31-53; py lib.rs:207-215)."""
+    sig = _require_f32(signal, (1,), "preemphasis")
+    lib = _lib.lib()
+    n = sig.shape[0]
+    if _is_torch(sig):
+        import torch
+
+        x = sig.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_preemphasis_device(x.data_ptr(), n, int(shift), float(cof), y.data_ptr(), _stream_ptr()))
+        return y
+    x = np.ascontiguousarray(sig)
+    y = np.empty_like(x)
+    _lib.check(lib.ss_preemphasis(x.ctypes.data, n, int(shift), float(cof), y.ctypes.data))
+    return y

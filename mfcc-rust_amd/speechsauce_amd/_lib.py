@@ -1,0 +1,151 @@
+"""ctypes binding of libspeechsauce_amd.so (the C ABI of include/speechsauce_amd.h).
+
+This plays the role of the reference's PyO3 module ``speechsauce._internal``
+(py-speechsauce/src/lib.rs:141-256).  There is no CPU fallback: if the shared library is missing
+or no HIP device is usable, every compute call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
+
+SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED = range(6)
+FRAMING = {"contract": 0, "literal": 1}
+DCT_NORM = {"reference": 0, "ortho": 1}
+WINDOW = {"rect": 0, "hann": 1, "vorbis": 2}
+DCT2_GAIN = 2.0
+
+
+class SsParams(C.Structure):
+    """ss_params (include/speechsauce_amd.h); field order is ABI."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("sample_rate", C.c_uint32),
+        ("fft_points", C.c_uint32),
+        ("frame_length", C.c_float),
+        ("frame_stride", C.c_float),
+        ("num_cepstral", C.c_uint32),
+        ("num_filters", C.c_uint32),
+        ("low_frequency", C.c_float),
+        ("high_frequency", C.c_float),
+        ("dc_elimination", C.c_int32),
+        ("framing", C.c_int32),
+        ("spectrum_exponent", C.c_int32),
+        ("dct_norm", C.c_int32),
+        ("dct2_gain", C.c_float),
+        ("mfcc_window", C.c_int32),
+        ("preemph_coef", C.c_float),
+        ("preemph_shift", C.c_int32),
+    ]
+
+
+class SpeechSauceError(RuntimeError):
+    """Raised where the reference would panic (or where HIP fails)."""
+
+    def __init__(self, status: int, detail: str):
+        super().__init__(f"speechsauce_amd status {status}: {detail}")
+        self.status = status
+        self.detail = detail
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/speechsauce_amd.h declares
+_P = C.POINTER
+_cfg = C.c_void_p
+_fp = C.c_void_p  # float* passed as an address (numpy .ctypes.data or a device pointer)
+PROTOTYPES = {
+    "ss_params_default": (C.c_int, [_P(SsParams), C.c_uint32]),
+    "ss_config_create": (C.c_int, [_P(SsParams), _P(_cfg)]),
+    "ss_config_destroy": (None, [_cfg]),
+    "ss_config_params": (C.c_int, [_cfg, _P(SsParams)]),
+    "ss_params_validate": (C.c_int, [_P(SsParams)]),
+    "ss_frame_sizes": (C.c_int, [_P(SsParams), _P(C.c_size_t), _P(C.c_size_t)]),
+    "ss_num_frames": (C.c_int, [_P(SsParams), C.c_size_t, _P(C.c_size_t)]),
+    "ss_stft_sizes": (C.c_int, [_P(SsParams), _P(C.c_size_t), _P(C.c_size_t), _P(C.c_float)]),
+    "ss_stft_rows": (C.c_int, [_P(SsParams), C.c_size_t, _P(C.c_size_t), _P(C.c_size_t)]),
+    "ss_filterbank": (C.c_int, [_P(SsParams), _fp, C.c_void_p]),
+    "ss_vorbis_window": (C.c_int, [C.c_size_t, _fp]),
+    "ss_mfcc": (C.c_int, [_cfg, _fp, C.c_size_t, _fp]),
+    "ss_mfe": (C.c_int, [_cfg, _fp, C.c_size_t, _fp, _fp]),
+    "ss_mel_spectrogram": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, _fp]),
+    "ss_preemphasis": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp]),
+    "ss_mfcc_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp]),
+    "ss_mfe_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
+    "ss_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_mfe_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp, C.c_void_p]),
+    "ss_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_preemphasis_device": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp, C.c_void_p]),
+    "ss_power_spectrum_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_stft_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_device_count": (C.c_int, [_P(C.c_int)]),
+    "ss_set_device": (C.c_int, [C.c_int]),
+    "ss_last_kernel_name": (C.c_char_p, []),
+    "ss_time_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
+    "ss_time_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
+    "ss_status_string": (C.c_char_p, [C.c_int]),
+    "ss_last_error_string": (C.c_char_p, []),
+    "ss_abi_version": (C.c_int, []),
+}
+
+
+def lib():
+    """Load the shared library once.  torch is imported first when present so that both share one
+    HIP runtime (same SONAME libamdhip64.so.7; the loader reuses the copy torch already mapped)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            "(or `make -C mfcc-rust_amd/csrc`). speechsauce_amd has no CPU fallback."
+        )
+    try:
+        import torch  # noqa: F401  (device memory / streams plumbing; also pins the HIP runtime)
+    except Exception:  # pragma: no cover - torch is optional for the numpy host path
+        pass
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.ss_abi_version() != 1:
+        raise ImportError("libspeechsauce_amd.so ABI version mismatch")
+    _lib = handle
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != SS_OK:
+        detail = lib().ss_last_error_string().decode() or lib().ss_status_string(status).decode()
+        raise SpeechSauceError(status, detail)
+
+
+def make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stride=0.01, num_cepstral=13,
+                num_filters=40, low_frequency=0.0, high_frequency=None, dc_elimination=True,
+                framing="contract", spectrum_exponent=1, dct_norm="reference", dct2_gain=DCT2_GAIN,
+                mfcc_window="rect", preemph_coef=0.0, preemph_shift=1) -> SsParams:
+    p = SsParams()
+    check(lib().ss_params_default(C.byref(p), int(sample_rate)))
+    p.fft_points = int(fft_points)
+    p.frame_length = float(frame_length)
+    p.frame_stride = float(frame_stride)
+    p.num_cepstral = int(num_cepstral)
+    p.num_filters = int(num_filters)
+    p.low_frequency = float(low_frequency)
+    # py-speechsauce/src/lib.rs:249: high_frequency.unwrap_or(sampling_frequency as f32 / 2.0)
+    p.high_frequency = float(sample_rate) / 2.0 if high_frequency is None else float(high_frequency)
+    p.dc_elimination = int(bool(dc_elimination))
+    p.framing = FRAMING[framing] if isinstance(framing, str) else int(framing)
+    p.spectrum_exponent = int(spectrum_exponent)
+    p.dct_norm = DCT_NORM[dct_norm] if isinstance(dct_norm, str) else int(dct_norm)
+    p.dct2_gain = float(dct2_gain)
+    p.mfcc_window = WINDOW[mfcc_window] if isinstance(mfcc_window, str) else int(mfcc_window)
+    p.preemph_coef = float(preemph_coef)
+    p.preemph_shift = int(preemph_shift)
+    return p

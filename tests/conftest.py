@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "mfcc-rust_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_c
+
+    oracle_c.build()
+    return oracle_c
+
+
+@pytest.fixture(scope="session")
+def sslib():
+    """The built C-ABI library (fails loudly if it is missing: there is no CPU fallback)."""
+    from speechsauce_amd import _lib
+
+    return _lib.lib()
