@@ -3,6 +3,7 @@
 // stream.  There is no CPU compute path here: without a HIP device these return SS_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -24,6 +25,10 @@ struct ss_config {
     int32_t *d_f_start = nullptr, *d_f_len = nullptr, *d_f_off = nullptr;
     float *d_f_w = nullptr;
     float *d_dct = nullptr;
+    // fft_points = 512 MFCC kernel tables (ss_mfcc512.hip)
+    ss::Fast512Tables fast;
+    int32_t *d_fast_start = nullptr, *d_fast_filter = nullptr;
+    float *d_fast_w = nullptr, *d_fast_dct16 = nullptr;
 };
 
 namespace {
@@ -127,6 +132,45 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     a.out0 = out0;
     a.out1 = out1;
     ss::LaunchInfo info{};
+    // fft_points = 512 MFCC: the specialised wave-private kernel when its layout assumptions hold
+    // (8-byte aligned frame starts, even frame length, rectangular window, no fused pre-emphasis).
+    static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
+    const bool fast_ok = !force_generic && cfg->fast.ok && out_kind == ss::OUT_MFCC && a.frame_mode == ss::FRAME_NORMAL &&
+                         a.preemph == 0.0f && a.window == nullptr && (a.flen % 2 == 0) && (a.step % 2 == 0) &&
+                         (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
+    if (fast_ok) {
+        ss::Fast512Args f{};
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tw_c = cfg->d_tw_c;
+        f.tw_n = cfg->d_tw_n;
+        f.mel_start = cfg->d_fast_start;
+        f.mel_filter = cfg->d_fast_filter;
+        f.mel_w = cfg->d_fast_w;
+        for (int s = 0; s < 3; ++s) f.mel_maxlen[s] = cfg->fast.maxlen[s];
+        f.mel_wrows = cfg->fast.maxlen[0] + cfg->fast.maxlen[1] + cfg->fast.maxlen[2];
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct16 = cfg->d_fast_dct16;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        const size_t tb = 132 * sizeof(float2) + sizeof(float) * 16 * (f.n_filters + static_cast<size_t>(f.mel_wrows)) + 96 * sizeof(int32_t);
+        f.table_bytes = static_cast<uint32_t>((tb + 255) & ~static_cast<size_t>(255));
+        f.out = out0;
+        hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
+        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256");
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
     hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
     if (e != hipSuccess) return hip_fail(e, "launch_front_generic");
     g_last_kernel = info.kernel_name;
@@ -229,6 +273,13 @@ int ss_config_create(const ss_params *p, ss_config **out)
     SS_UP(d_f_off, h.bank.off);
     SS_UP(d_f_w, h.bank.w);
     SS_UP(d_dct, h.dct);
+    ss::build_fast512(h, c->fast);
+    if (c->fast.ok) {
+        SS_UP(d_fast_start, c->fast.mel_start);
+        SS_UP(d_fast_filter, c->fast.mel_filter);
+        SS_UP(d_fast_w, c->fast.mel_w);
+        SS_UP(d_fast_dct16, c->fast.dct16);
+    }
 #undef SS_UP
     *out = cfg.release();
     return SS_OK;
@@ -238,7 +289,8 @@ void ss_config_destroy(ss_config *cfg)
 {
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
-                    cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct};
+                    cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
+                    cfg->d_fast_start,  cfg->d_fast_filter, cfg->d_fast_w, cfg->d_fast_dct16};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

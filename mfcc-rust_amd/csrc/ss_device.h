@@ -64,4 +64,30 @@ hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t 
 // Element-wise pre-emphasis (processing.rs:31-53).
 hipError_t launch_preemphasis(const float *x, float *y, size_t n, size_t shift, float cof, hipStream_t stream);
 
+// Arguments of the fft_points = 512 MFCC kernel (ss_mfcc512.hip).
+struct Fast512Args {
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples, batch, flen, step, n_frames;
+    float scale;
+    int32_t spectrum_exponent;
+    const float2 *tw_c;  // exp(-2 pi i t / 256)
+    const float2 *tw_n;  // exp(-2 pi i k / 512), k <= 128
+    // mel lane tables: slot s (0..2), lane j (0..15) owns filter mel_filter[s*16+j] (or -1);
+    // its taps are mel_w[(row0(s) + q) * 16 + j], q < mel_maxlen[s], applied to P[mel_start[s*16+j] + q]
+    const int32_t *mel_start;
+    const int32_t *mel_filter;
+    const float *mel_w;
+    int32_t mel_maxlen[3];
+    int32_t mel_wrows;
+    uint32_t n_filters, n_ceps;
+    const float *dct16;  // [n_filters][16], cos(pi c (2m+1) / 2M) at [m*16 + c], zero for c >= n_ceps
+    float dct_scale_k, dct_scale_0, dct_scale_00;
+    int32_t dc_elimination;
+    uint32_t table_bytes;  // LDS bytes of the table area in front of the frame regions
+    float *out;
+};
+
+hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 }  // namespace ss

@@ -1,0 +1,104 @@
+// Register-resident complex butterflies shared by the HIP kernels (device code only).
+// Forward transform convention: exp(-2 pi i n k / R), natural order in and out.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ss {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -i
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+// Forward 4-point DFT (exp(-2 pi i nk/4)), natural order in and out.
+__device__ __forceinline__ void fft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
+{
+    const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2);
+    const float2 a2 = cadd(v1, v3), a3 = mul_mi(csub(v1, v3));
+    v0 = cadd(a0, a2);
+    v1 = cadd(a1, a3);
+    v2 = csub(a0, a2);
+    v3 = csub(a1, a3);
+}
+
+template <int R>
+__device__ __forceinline__ void fft_reg(float2 *v);
+
+template <>
+__device__ __forceinline__ void fft_reg<2>(float2 *v)
+{
+    const float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+
+template <>
+__device__ __forceinline__ void fft_reg<4>(float2 *v)
+{
+    fft4(v[0], v[1], v[2], v[3]);
+}
+
+// n = n1 + 2 n2, k = 4 k1 + k2: W8^(nk) = W2^(n1 k1) W8^(n1 k2) W4^(n2 k2)
+template <>
+__device__ __forceinline__ void fft_reg<8>(float2 *v)
+{
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    fft4(e0, e1, e2, e3);
+    fft4(o0, o1, o2, o3);
+    constexpr float h = 0.70710678118654752440f;
+    o1 = make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));   // * (h - i h)
+    o2 = mul_mi(o2);                                           // * -i
+    o3 = make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));  // * (-h - i h)
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+// n = n1 + 4 n2, k = 4 k1 + k2: W16^(nk) = W4^(n1 k1) W16^(n1 k2) W4^(n2 k2)
+template <>
+__device__ __forceinline__ void fft_reg<16>(float2 *v)
+{
+    // step A: for each n1, 4-point DFT over n2 (elements n1, n1+4, n1+8, n1+12) -> Y[n1][k2] kept in place
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) fft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+    // step B: Y[n1][k2] *= W16^(n1 k2); Y[n1][k2] sits in v[n1 + 4 k2]
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    constexpr float h = 0.70710678118654752440f;
+    // n1 = 1: W16^k2, k2 = 1,2,3
+    v[5] = cmul(v[5], make_float2(c1, -s1));
+    v[9] = make_float2(h * (v[9].x + v[9].y), h * (v[9].y - v[9].x));
+    v[13] = cmul(v[13], make_float2(s1, -c1));
+    // n1 = 2: W16^(2 k2) = W8^k2
+    v[6] = make_float2(h * (v[6].x + v[6].y), h * (v[6].y - v[6].x));
+    v[10] = mul_mi(v[10]);
+    v[14] = make_float2(h * (v[14].y - v[14].x), -h * (v[14].x + v[14].y));
+    // n1 = 3: W16^(3 k2): k2=1 -> W16^3, k2=2 -> W16^6, k2=3 -> W16^9
+    v[7] = cmul(v[7], make_float2(s1, -c1));
+    v[11] = make_float2(h * (v[11].y - v[11].x), -h * (v[11].x + v[11].y));
+    v[15] = cmul(v[15], make_float2(-c1, s1));
+    // step C: for each k2, 4-point DFT over n1 (elements 4 k2 + n1) -> X[4 k1 + k2]
+    float2 y[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        float2 a = v[4 * k2], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
+        fft4(a, b, c, d);
+        y[k2] = a;
+        y[4 + k2] = b;
+        y[8 + k2] = c;
+        y[12 + k2] = d;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = y[i];
+}
+
+// 16-point DFT on a 16-element register array
+__device__ __forceinline__ void fft16_reg(float2 (&v)[16]) { fft_reg<16>(v); }
+
+}  // namespace ss

@@ -6,6 +6,7 @@
 // ln -> exp round trip, so the f32 operation order below is part of the contract.
 #include "ss_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -235,6 +236,51 @@ int build_tables(const ss_params &p, HostTables &t)
             t.dct[k * M + m] = static_cast<float>(
                 std::cos(pi * static_cast<double>(k) * (2.0 * static_cast<double>(m) + 1.0) / (2.0 * static_cast<double>(M))));
     return SS_OK;
+}
+
+
+void build_fast512(const HostTables &t, Fast512Tables &f)
+{
+    f = Fast512Tables{};
+    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral, F = t.d.n_bins;
+    if (t.d.n_fft != 512 || M > 48 || Cc > 16) return;
+    // order filters by tap count (longest first) and deal them 16 per slot
+    std::vector<int32_t> order(M);
+    for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
+    f.mel_start.assign(48, 0);
+    f.mel_filter.assign(48, -1);
+    for (int s = 0; s < 3; ++s)
+        for (int j = 0; j < 16; ++j) {
+            const size_t i = static_cast<size_t>(s) * 16 + j;
+            if (i < M && t.bank.len[order[i]] > f.maxlen[s]) f.maxlen[s] = t.bank.len[order[i]];
+        }
+    const int rows = f.maxlen[0] + f.maxlen[1] + f.maxlen[2];
+    if (rows > 128) return;
+    f.mel_w.assign(static_cast<size_t>(rows > 0 ? rows : 1) * 16, 0.0f);
+    int row0 = 0;
+    for (int s = 0; s < 3; ++s) {
+        for (int j = 0; j < 16; ++j) {
+            const size_t i = static_cast<size_t>(s) * 16 + j;
+            if (i >= M) continue;
+            const int32_t m = order[i];
+            f.mel_filter[i] = m;
+            int32_t start = t.bank.start[m];
+            const int32_t len = t.bank.len[m];
+            // the lock-step loop reads maxlen[s] taps: keep start + maxlen inside the F-bin row
+            int32_t shift = 0;
+            if (start + f.maxlen[s] > static_cast<int32_t>(F)) shift = start + f.maxlen[s] - static_cast<int32_t>(F);
+            start -= shift;
+            f.mel_start[i] = start;
+            for (int32_t q = 0; q < len; ++q)
+                f.mel_w[static_cast<size_t>(row0 + shift + q) * 16 + j] = t.bank.w[t.bank.off[m] + q];
+        }
+        row0 += f.maxlen[s];
+    }
+    f.dct16.assign(M * 16, 0.0f);
+    for (size_t m = 0; m < M; ++m)
+        for (size_t c = 0; c < Cc; ++c) f.dct16[m * 16 + c] = t.dct[c * M + m];
+    f.ok = true;
 }
 
 }  // namespace ss

@@ -58,4 +58,16 @@ void vorbis_window(size_t n, float *w);
 void hann_window(size_t n, float *w);
 int build_tables(const ss_params &p, HostTables &t);
 
+// Lane tables of the fft_points = 512 MFCC kernel: filters sorted by tap count and dealt to
+// 3 slots x 16 lanes so the lock-step tap loops are short.
+struct Fast512Tables {
+    bool ok = false;
+    std::vector<int32_t> mel_start;   // [48]
+    std::vector<int32_t> mel_filter;  // [48]
+    std::vector<float> mel_w;         // [(maxlen0+maxlen1+maxlen2) x 16]
+    int32_t maxlen[3] = {0, 0, 0};
+    std::vector<float> dct16;         // [M x 16]
+};
+void build_fast512(const HostTables &t, Fast512Tables &f);
+
 }  // namespace ss
