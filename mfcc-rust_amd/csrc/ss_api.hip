@@ -29,6 +29,8 @@ struct ss_config {
     ss::Fast512Tables fast;
     int32_t *d_fast_start = nullptr, *d_fast_filter = nullptr;
     float *d_fast_w = nullptr, *d_fast_dct16 = nullptr;
+    ss::Fast512MTables fastm;
+    float *d_fastm_wt = nullptr, *d_fastm_ct = nullptr;
 };
 
 namespace {
@@ -138,6 +140,41 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool fast_ok = !force_generic && cfg->fast.ok && out_kind == ss::OUT_MFCC && a.frame_mode == ss::FRAME_NORMAL &&
                          a.preemph == 0.0f && a.window == nullptr && (a.flen % 2 == 0) && (a.step % 2 == 0) &&
                          (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
+    // SS_MFCC512_VARIANT=valu selects the LDS/VALU mel+DCT variant (ss_mfcc512.hip) for A/B runs
+    static const char *variant = std::getenv("SS_MFCC512_VARIANT");
+    const bool want_valu = variant && std::strcmp(variant, "valu") == 0;
+    if (fast_ok && cfg->fastm.ok && !want_valu && static_cast<unsigned long long>(batch) * T < 0xffffffffull) {
+        ss::Fast512MArgs f{};
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tw_c = cfg->d_tw_c;
+        f.tw_n = cfg->d_tw_n;
+        f.wt = cfg->d_fastm_wt;
+        f.ct = cfg->d_fastm_ct;
+        for (int s = 0; s < 3; ++s) {
+            f.ks_lo[s] = cfg->fastm.ks_lo[s];
+            f.ks_hi[s] = cfg->fastm.ks_hi[s];
+        }
+        f.n_mm = cfg->fastm.n_mm;
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        f.out = out0;
+        hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
+        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_mx");
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
     if (fast_ok) {
         ss::Fast512Args f{};
         f.x = d_x;
@@ -280,6 +317,11 @@ int ss_config_create(const ss_params *p, ss_config **out)
         SS_UP(d_fast_w, c->fast.mel_w);
         SS_UP(d_fast_dct16, c->fast.dct16);
     }
+    ss::build_fast512m(h, c->fastm);
+    if (c->fastm.ok) {
+        SS_UP(d_fastm_wt, c->fastm.wt);
+        SS_UP(d_fastm_ct, c->fastm.ct);
+    }
 #undef SS_UP
     *out = cfg.release();
     return SS_OK;
@@ -290,7 +332,8 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_start,  cfg->d_fast_filter, cfg->d_fast_w, cfg->d_fast_dct16};
+                    cfg->d_fast_start,  cfg->d_fast_filter, cfg->d_fast_w, cfg->d_fast_dct16,
+                    cfg->d_fastm_wt,    cfg->d_fastm_ct};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

@@ -90,4 +90,28 @@ struct Fast512Args {
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
+// Arguments of the second-generation fft_points = 512 MFCC kernel (ss_mfcc512_mfma.hip).
+struct Fast512MArgs {
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples, batch, flen, step, n_frames;
+    float scale;
+    int32_t spectrum_exponent;
+    const float2 *tw_c;  // exp(-2 pi i t / 256)
+    const float2 *tw_n;  // exp(-2 pi i k / 512), k <= 128
+    // block-sparse mel product: for 16-filter tile tl, k-steps ks_lo[tl] <= s < ks_hi[tl] (4 bins each);
+    // wt[e][lane] = W[16 tl + (lane & 15)][4 s + (lane >> 4)] in tile-major order, e < n_mm
+    const float *wt;
+    int32_t ks_lo[3], ks_hi[3];
+    int32_t n_mm;
+    // DCT A operands: ct[(tl*4 + i)][lane] = cos(pi c (2m+1) / 2M), c = lane & 15, m = 16 tl + 4 (lane >> 4) + i
+    const float *ct;
+    uint32_t n_filters, n_ceps;
+    float dct_scale_k, dct_scale_0, dct_scale_00;
+    int32_t dc_elimination;
+    float *out;
+};
+
+hipError_t launch_mfcc_c256_mx(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 }  // namespace ss

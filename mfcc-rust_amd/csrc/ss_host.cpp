@@ -283,6 +283,45 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     f.ok = true;
 }
 
+
+void build_fast512m(const HostTables &t, Fast512MTables &f)
+{
+    f = Fast512MTables{};
+    const int M = static_cast<int>(t.params.num_filters), Cc = static_cast<int>(t.params.num_cepstral);
+    const int F = static_cast<int>(t.d.n_bins);
+    if (t.d.n_fft != 512 || M > 48 || Cc > 16) return;
+    if (t.bank.last_bin > 129) return;  // the P tile keeps bins 0..128 (bank ends at (F+1)/2 when high = sr/2)
+    for (int tl = 0; tl < 3; ++tl) {
+        int lo = 1 << 30, hi = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int m = 16 * tl + r;
+            if (m >= M || t.bank.len[m] == 0) continue;
+            lo = std::min(lo, t.bank.start[m] / 4);
+            hi = std::max(hi, (t.bank.start[m] + t.bank.len[m] + 3) / 4);
+        }
+        if (hi == 0) lo = 0;
+        f.ks_lo[tl] = lo;
+        f.ks_hi[tl] = hi;
+        for (int s = lo; s < hi; ++s) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = 16 * tl + (lane & 15), bin = 4 * s + (lane >> 4);
+                f.wt.push_back(m < M && bin < F ? t.fb_dense[static_cast<size_t>(m) * F + bin] : 0.0f);
+            }
+            ++f.n_mm;
+        }
+    }
+    if (f.n_mm > 56) return;  // LDS budget of the kernel
+    if (f.wt.empty()) f.wt.assign(64, 0.0f);
+    f.ct.assign(12 * 64, 0.0f);
+    for (int tl = 0; tl < 3; ++tl)
+        for (int i = 0; i < 4; ++i)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = lane & 15, m = 16 * tl + 4 * (lane >> 4) + i;
+                if (c < Cc && m < M) f.ct[static_cast<size_t>(tl * 4 + i) * 64 + lane] = t.dct[static_cast<size_t>(c) * M + m];
+            }
+    f.ok = true;
+}
+
 }  // namespace ss
 
 // ---- host-only C ABI entry points ------------------------------------------------------------

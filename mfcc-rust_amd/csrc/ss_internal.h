@@ -70,4 +70,15 @@ struct Fast512Tables {
 };
 void build_fast512(const HostTables &t, Fast512Tables &f);
 
+// Operand tables of the MFMA variant (ss_mfcc512_mfma.hip): the banded mel bank cut into
+// 16-filter x 4-bin blocks (only the non-zero ones are kept) and the DCT cosines in MFMA A layout.
+struct Fast512MTables {
+    bool ok = false;
+    std::vector<float> wt;  // [n_mm][64]
+    std::vector<float> ct;  // [12][64]
+    int32_t ks_lo[3] = {0, 0, 0}, ks_hi[3] = {0, 0, 0};
+    int32_t n_mm = 0;
+};
+void build_fast512m(const HostTables &t, Fast512MTables &f);
+
 }  // namespace ss

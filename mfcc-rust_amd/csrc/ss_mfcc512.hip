@@ -28,6 +28,7 @@ namespace {
 
 constexpr float kEpsF = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
 constexpr int kFrameSlots = 272;        // float2 per frame region (256 + 16 pad)
+constexpr int kTableOffset = 16 * kFrameSlots + 2;  // float2 units; +2: lane 0 of the last frame reads one slot past its region
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
@@ -55,15 +56,16 @@ __global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
     const int f = lane >> 4;  // frame within the wave
     const int j = lane & 15;  // lane within the frame
 
-    // ---- LDS carve: tables first, then one 2176-B region per frame ----
-    float2 *s_twn = reinterpret_cast<float2 *>(smem);                         // 129 (+3 pad) float2
-    float *s_dct = reinterpret_cast<float *>(smem + 132 * sizeof(float2));    // [M][16]
+    // ---- LDS carve: one 2176-B region per frame first (compile-time 8-byte alignment -> ds_read/write_b64),
+    //      then the read-only tables ----
+    float2 *zfr = reinterpret_cast<float2 *>(smem) + (wave * 4 + f) * kFrameSlots;
+    float *prow = reinterpret_cast<float *>(zfr);  // P[0..256] reuses the frame region after the untangle reads
+    float *frow = prow + 260;                      // log-mel row
+    float2 *s_twn = reinterpret_cast<float2 *>(smem) + kTableOffset;          // 129 (+3 pad) float2
+    float *s_dct = reinterpret_cast<float *>(s_twn + 132);                    // [M][16]
     float *s_melw = s_dct + a.n_filters * 16;                                 // [sum maxlen][16]
     int *s_melst = reinterpret_cast<int *>(s_melw + a.mel_wrows * 16);        // [3][16]
     int *s_melf = s_melst + 48;                                               // [3][16]
-    float2 *zfr = reinterpret_cast<float2 *>(smem + a.table_bytes) + (wave * 4 + f) * kFrameSlots;
-    float *prow = reinterpret_cast<float *>(zfr);  // P[0..256] reuses the frame region after the untangle reads
-    float *frow = prow + 260;                      // log-mel row
 
     for (int i = tid; i < 129; i += 256) s_twn[i] = a.tw_n[i];
     for (int i = tid; i < static_cast<int>(a.n_filters) * 16; i += 256) s_dct[i] = a.dct16[i];
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
             const float2 wd = cmul(w, d);
             const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // X[k]
             const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // conj X[256-k]
-            const float ma = sqrtf(xa_r * xa_r + xa_i * xa_i);
-            const float mb = sqrtf(xb_r * xb_r + xb_i * xb_i);
+            const float ma = __builtin_amdgcn_sqrtf(xa_r * xa_r + xa_i * xa_i);
+            const float mb = __builtin_amdgcn_sqrtf(xb_r * xb_r + xb_i * xb_i);
             pk[i] = a.spectrum_exponent == 2 ? a.scale * (ma * ma) : a.scale * ma;
             pc[i] = a.spectrum_exponent == 2 ? a.scale * (mb * mb) : a.scale * mb;
             esum += pk[i] + pc[i];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
         float p128 = 0.f;
         if (j == 0) {
             const float2 z = zfr[128 + 8];  // X[128] = conj Z[128]
-            const float m = sqrtf(z.x * z.x + z.y * z.y);
+            const float m = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
             p128 = a.spectrum_exponent == 2 ? a.scale * (m * m) : a.scale * m;
             esum += p128;
         }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
                 for (int q = 0; q < len; ++q) acc = fmaf(ww[q * 16], pp[q], acc);
                 const int m = s_melf[s * 16 + j];
                 acc = acc == 0.f ? kEpsF : acc;
-                if (m >= 0) frow[m] = logf(acc);
+                if (m >= 0) frow[m] = __logf(acc);
                 wrow += len;
             }
         }
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
             float acc = 0.f;
             for (int m = 0; m < M; ++m) acc = fmaf(frow[m], s_dct[m * 16 + j], acc);
             float o;
-            if (j == 0) o = a.dc_elimination ? logf(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (j == 0) o = a.dc_elimination ? __logf(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
             else o = acc * a.dct_scale_k;
             if (active) a.out[gf * Cc + j] = o;
         }
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
 
 size_t fast512_lds_bytes(const Fast512Args &a)
 {
-    return a.table_bytes + 16 * kFrameSlots * sizeof(float2) + 16;
+    return a.table_bytes + kTableOffset * sizeof(float2);
 }
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
