@@ -3,6 +3,7 @@
 // stream.  There is no CPU compute path here: without a HIP device these return SS_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -30,7 +31,7 @@ struct ss_config {
     int32_t *d_fast_start = nullptr, *d_fast_filter = nullptr;
     float *d_fast_w = nullptr, *d_fast_dct16 = nullptr;
     ss::Fast512MTables fastm;
-    float *d_fastm_wt = nullptr, *d_fastm_ct = nullptr;
+    float *d_fastm_tab = nullptr, *d_fastm_tab_pk = nullptr;
 };
 
 namespace {
@@ -143,6 +144,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // SS_MFCC512_VARIANT=valu selects the LDS/VALU mel+DCT variant (ss_mfcc512.hip) for A/B runs
     static const char *variant = std::getenv("SS_MFCC512_VARIANT");
     const bool want_valu = variant && std::strcmp(variant, "valu") == 0;
+    const bool want_mx = variant && std::strcmp(variant, "mx") == 0;
     if (fast_ok && cfg->fastm.ok && !want_valu && static_cast<unsigned long long>(batch) * T < 0xffffffffull) {
         ss::Fast512MArgs f{};
         f.x = d_x;
@@ -154,15 +156,21 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.n_frames = a.n_frames;
         f.scale = a.scale;
         f.spectrum_exponent = a.spectrum_exponent;
-        f.tw_c = cfg->d_tw_c;
-        f.tw_n = cfg->d_tw_n;
-        f.wt = cfg->d_fastm_wt;
-        f.ct = cfg->d_fastm_ct;
-        for (int s = 0; s < 3; ++s) {
-            f.ks_lo[s] = cfg->fastm.ks_lo[s];
-            f.ks_hi[s] = cfg->fastm.ks_hi[s];
+        if (want_mx) {
+            f.tab = cfg->d_fastm_tab;
+            for (int s = 0; s < 3; ++s) {
+                f.ks_lo[s] = cfg->fastm.ks_lo[s];
+                f.ks_hi[s] = cfg->fastm.ks_hi[s];
+            }
+            f.n_mm = cfg->fastm.n_mm;
+        } else {  // packed-pair kernel: k-steps in groups of four
+            f.tab = cfg->d_fastm_tab_pk;
+            for (int s = 0; s < 3; ++s) {
+                f.ks_lo[s] = cfg->fastm.kg_lo[s];
+                f.ks_hi[s] = cfg->fastm.kg_hi[s];
+            }
+            f.n_mm = 4 * cfg->fastm.n_grp;
         }
-        f.n_mm = cfg->fastm.n_mm;
         f.n_filters = a.n_filters;
         f.n_ceps = a.n_ceps;
         f.dct_scale_k = a.dct_scale_k;
@@ -170,8 +178,39 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.dct_scale_00 = a.dct_scale_00;
         f.dc_elimination = a.dc_elimination;
         f.out = out0;
-        hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_mx");
+        static const char *abl = std::getenv("SS_ABLATE");
+        f.ablate = abl ? std::atoi(abl) : 0;
+        // SS_DEBUG_TIMES=<file>: diagnostic only -- dump per-wave realtime stamps of ONE launch
+        static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");
+        static bool dbg_done = false;
+        if (dbg_path && !dbg_done) {
+            dbg_done = true;
+            const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
+            DeviceBuf db;
+            int rc2 = db.alloc(nwaves * 4 * sizeof(unsigned long long));
+            if (rc2) return rc2;
+            SS_HIP(hipMemset(db.p, 0, nwaves * 4 * sizeof(unsigned long long)));
+            for (int rep = 0; rep < 3; ++rep) {  // last repetition is the warm one
+                f.dbg = db.as<unsigned long long>();
+                hipError_t e2 = want_mx ? ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info)
+                                        : ss::launch_mfcc_c256_pk(f, stream, cfg->num_cus, &info);
+                if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c256_mx");
+                SS_HIP(hipStreamSynchronize(stream));
+            }
+            std::vector<unsigned long long> hb(nwaves * 4);
+            SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *fp = std::fopen(dbg_path, "w")) {
+                for (size_t w = 0; w < nwaves; ++w)
+                    if (hb[4 * w + 2])
+                        std::fprintf(fp, "%zu %llu %llu %llu %llu %llu\n", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2],
+                                     hb[4 * w + 3] >> 32, hb[4 * w + 3] & 0xffffffffull);
+                std::fclose(fp);
+            }
+            f.dbg = nullptr;
+        }
+        hipError_t e = want_mx ? ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info)
+                               : ss::launch_mfcc_c256_pk(f, stream, cfg->num_cus, &info);
+        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_pk/mx");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
@@ -319,8 +358,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     }
     ss::build_fast512m(h, c->fastm);
     if (c->fastm.ok) {
-        SS_UP(d_fastm_wt, c->fastm.wt);
-        SS_UP(d_fastm_ct, c->fastm.ct);
+        SS_UP(d_fastm_tab, c->fastm.tab);
+        SS_UP(d_fastm_tab_pk, c->fastm.tab_pk);
     }
 #undef SS_UP
     *out = cfg.release();
@@ -333,7 +372,7 @@ void ss_config_destroy(ss_config *cfg)
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
                     cfg->d_fast_start,  cfg->d_fast_filter, cfg->d_fast_w, cfg->d_fast_dct16,
-                    cfg->d_fastm_wt,    cfg->d_fastm_ct};
+                    cfg->d_fastm_tab,    cfg->d_fastm_tab_pk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

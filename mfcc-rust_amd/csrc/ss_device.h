@@ -97,21 +97,25 @@ struct Fast512MArgs {
     uint32_t n_samples, batch, flen, step, n_frames;
     float scale;
     int32_t spectrum_exponent;
-    const float2 *tw_c;  // exp(-2 pi i t / 256)
-    const float2 *tw_n;  // exp(-2 pi i k / 512), k <= 128
-    // block-sparse mel product: for 16-filter tile tl, k-steps ks_lo[tl] <= s < ks_hi[tl] (4 bins each);
-    // wt[e][lane] = W[16 tl + (lane & 15)][4 s + (lane >> 4)] in tile-major order, e < n_mm
-    const float *wt;
+    // one table block, copied verbatim into LDS (layout: ss::fast512m_layout in ss_internal.h):
+    //   tw2 [15][16] float2  exp(-2 pi i j r / 256), r = 1..15
+    //   twn [8][16]  float2  exp(-2 pi i (j + 16 r) / 512)
+    //   ct  [12][64]         DCT MFMA A operands: cos(pi c (2m+1) / 2M), c = lane & 15, m = 16 tl + 4 (lane >> 4) + i
+    //   wt  [n_mm][64]       mel MFMA A operands: W[16 tl + (lane & 15)][4 s + (lane >> 4)], tile-major over the
+    //                        k-steps ks_lo[tl] <= s < ks_hi[tl] (4 bins each) that hold a non-zero weight
+    const float *tab;
     int32_t ks_lo[3], ks_hi[3];
-    int32_t n_mm;
-    // DCT A operands: ct[(tl*4 + i)][lane] = cos(pi c (2m+1) / 2M), c = lane & 15, m = 16 tl + 4 (lane >> 4) + i
-    const float *ct;
+    int32_t n_mm;      // table floats after the fixed part: n_mm * 64 (mx) or n_grp * 256 (pk: n_mm = 4 * n_grp)
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
     float *out;
+    unsigned long long *dbg;  // diagnostic runs only: per-wave {start, after prologue, end} s_memrealtime stamps, or null
+    int32_t ablate;           // diagnostic runs only (SS_ABLATE): skip parts of the pipeline to price them; 0 in production
 };
 
 hipError_t launch_mfcc_c256_mx(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+// Same arguments; two frames per 16-lane group, all arithmetic packed (ss_mfcc512_pk.hip).
+hipError_t launch_mfcc_c256_pk(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
 }  // namespace ss

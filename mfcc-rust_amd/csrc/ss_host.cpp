@@ -286,11 +286,13 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
 
 void build_fast512m(const HostTables &t, Fast512MTables &f)
 {
+    namespace L = fast512m_layout;
     f = Fast512MTables{};
     const int M = static_cast<int>(t.params.num_filters), Cc = static_cast<int>(t.params.num_cepstral);
     const int F = static_cast<int>(t.d.n_bins);
     if (t.d.n_fft != 512 || M > 48 || Cc > 16) return;
-    if (t.bank.last_bin > 129) return;  // the P tile keeps bins 0..128 (bank ends at (F+1)/2 when high = sr/2)
+    if (t.bank.last_bin > 129) return;  // the P tile keeps bins 0..128 (the bank ends at (F+1)/2 when high = sr/2)
+    std::vector<float> wt;
     for (int tl = 0; tl < 3; ++tl) {
         int lo = 1 << 30, hi = 0;
         for (int r = 0; r < 16; ++r) {
@@ -305,20 +307,47 @@ void build_fast512m(const HostTables &t, Fast512MTables &f)
         for (int s = lo; s < hi; ++s) {
             for (int lane = 0; lane < 64; ++lane) {
                 const int m = 16 * tl + (lane & 15), bin = 4 * s + (lane >> 4);
-                f.wt.push_back(m < M && bin < F ? t.fb_dense[static_cast<size_t>(m) * F + bin] : 0.0f);
+                wt.push_back(m < M && bin < F ? t.fb_dense[static_cast<size_t>(m) * F + bin] : 0.0f);
             }
             ++f.n_mm;
         }
     }
     if (f.n_mm > 56) return;  // LDS budget of the kernel
-    if (f.wt.empty()) f.wt.assign(64, 0.0f);
-    f.ct.assign(12 * 64, 0.0f);
+    f.tab.assign(static_cast<size_t>(L::kWt) + wt.size(), 0.0f);
+    for (int r = 1; r < 16; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256) = tw_c[j r]
+            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2] = t.tw_c[2 * (j * r)];
+            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2 + 1] = t.tw_c[2 * (j * r) + 1];
+        }
+    for (int r = 0; r < 8; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i (j + 16 r) / 512) = tw_n[j + 16 r]
+            f.tab[L::kTwn + (r * 16 + j) * 2] = t.tw_n[2 * (j + 16 * r)];
+            f.tab[L::kTwn + (r * 16 + j) * 2 + 1] = t.tw_n[2 * (j + 16 * r) + 1];
+        }
     for (int tl = 0; tl < 3; ++tl)
         for (int i = 0; i < 4; ++i)
             for (int lane = 0; lane < 64; ++lane) {
                 const int c = lane & 15, m = 16 * tl + 4 * (lane >> 4) + i;
-                if (c < Cc && m < M) f.ct[static_cast<size_t>(tl * 4 + i) * 64 + lane] = t.dct[static_cast<size_t>(c) * M + m];
+                if (c < Cc && m < M) f.tab[L::kCt + (tl * 4 + i) * 64 + lane] = t.dct[static_cast<size_t>(c) * M + m];
             }
+    std::copy(wt.begin(), wt.end(), f.tab.begin() + L::kWt);
+    // grouped weights for the packed-pair kernel
+    std::vector<float> wg;
+    for (int tl = 0; tl < 3; ++tl) {
+        f.kg_lo[tl] = f.ks_lo[tl] / 4;
+        f.kg_hi[tl] = (f.ks_hi[tl] + 3) / 4;
+        for (int gq = f.kg_lo[tl]; gq < f.kg_hi[tl]; ++gq) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int m = 16 * tl + (lane & 15), bin = 4 * (4 * gq + i) + (lane >> 4);
+                    wg.push_back(m < M && bin < F ? t.fb_dense[static_cast<size_t>(m) * F + bin] : 0.0f);
+                }
+            ++f.n_grp;
+        }
+    }
+    f.tab_pk.assign(f.tab.begin(), f.tab.begin() + L::kWt);
+    f.tab_pk.insert(f.tab_pk.end(), wg.begin(), wg.end());
+    if (f.n_grp > 14 || f.kg_hi[0] > 9 || f.kg_hi[1] > 9 || f.kg_hi[2] > 9) return;  // LDS budget / 36-step P rows
     f.ok = true;
 }
 

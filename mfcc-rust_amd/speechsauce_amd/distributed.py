@@ -1,0 +1,67 @@
+"""Clip-batch sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+Clips are independent units of the hot path (no cross-clip state: the STFT carry-over is defined per
+clip from zero state), so the batch axis shards with NO data-path collective.  The only exchange the
+north-star names is the final gather of the [n_frames x n_mfcc] blocks; `all_gather_features` does
+it with one all-gather (RCCL over xGMI on GPUs: every peer pair has a direct link, so an all-gather
+moves each block concurrently instead of around a ring; gloo on CPU for the tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition: ranks [0, n % world) get one extra item."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError("bad world/rank")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(n_items: int, world: int):
+    return [shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0] for r in range(world)]
+
+
+def all_gather_features(local, n_total: int, group=None):
+    """local: [B_rank, ...] feature block of this rank's shard -> [n_total, ...] on every rank.
+
+    Uneven shards are padded to the largest shard for the collective and trimmed afterwards."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = shard_sizes(n_total, world)
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError("local block does not match this rank's shard")
+    bmax = max(sizes)
+    tail = tuple(local.shape[1:])
+    if local.shape[0] == bmax:
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((bmax,) + tail, dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    out = torch.empty((world * bmax,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    if all(s == bmax for s in sizes):
+        return out
+    return torch.cat([out[r * bmax: r * bmax + sizes[r]] for r in range(world)], dim=0)
+
+
+def mfcc_sharded(signals, sampling_frequency, gather: bool = True, group=None, **kwargs):
+    """signals: the FULL [B, L] batch (every rank sees the same view, e.g. a memory-mapped corpus);
+    each rank computes its contiguous shard on its own GPU and, if `gather`, all ranks receive [B, T, C]."""
+    import torch.distributed as dist
+
+    from . import mfcc_batch
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(signals.shape[0], world, rank)
+    local = mfcc_batch(signals[lo:hi], sampling_frequency, **kwargs)
+    if gather and world > 1:
+        return all_gather_features(local, signals.shape[0], group)
+    return local
