@@ -31,7 +31,7 @@ struct ss_config {
     int32_t *d_fast_start = nullptr, *d_fast_filter = nullptr;
     float *d_fast_w = nullptr, *d_fast_dct16 = nullptr;
     ss::Fast512MTables fastm;
-    float *d_fastm_tab = nullptr, *d_fastm_tab_pk = nullptr;
+    float *d_fastm_tab = nullptr;
 };
 
 namespace {
@@ -144,7 +144,6 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // SS_MFCC512_VARIANT=valu selects the LDS/VALU mel+DCT variant (ss_mfcc512.hip) for A/B runs
     static const char *variant = std::getenv("SS_MFCC512_VARIANT");
     const bool want_valu = variant && std::strcmp(variant, "valu") == 0;
-    const bool want_mx = variant && std::strcmp(variant, "mx") == 0;
     if (fast_ok && cfg->fastm.ok && !want_valu && static_cast<unsigned long long>(batch) * T < 0xffffffffull) {
         ss::Fast512MArgs f{};
         f.x = d_x;
@@ -156,21 +155,12 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.n_frames = a.n_frames;
         f.scale = a.scale;
         f.spectrum_exponent = a.spectrum_exponent;
-        if (want_mx) {
-            f.tab = cfg->d_fastm_tab;
-            for (int s = 0; s < 3; ++s) {
-                f.ks_lo[s] = cfg->fastm.ks_lo[s];
-                f.ks_hi[s] = cfg->fastm.ks_hi[s];
-            }
-            f.n_mm = cfg->fastm.n_mm;
-        } else {  // packed-pair kernel: k-steps in groups of four
-            f.tab = cfg->d_fastm_tab_pk;
-            for (int s = 0; s < 3; ++s) {
-                f.ks_lo[s] = cfg->fastm.kg_lo[s];
-                f.ks_hi[s] = cfg->fastm.kg_hi[s];
-            }
-            f.n_mm = 4 * cfg->fastm.n_grp;
+        f.tab = cfg->d_fastm_tab;
+        for (int s = 0; s < 3; ++s) {
+            f.ks_lo[s] = cfg->fastm.ks_lo[s];
+            f.ks_hi[s] = cfg->fastm.ks_hi[s];
         }
+        f.n_mm = cfg->fastm.n_mm;
         f.n_filters = a.n_filters;
         f.n_ceps = a.n_ceps;
         f.dct_scale_k = a.dct_scale_k;
@@ -187,30 +177,32 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             dbg_done = true;
             const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
             DeviceBuf db;
-            int rc2 = db.alloc(nwaves * 4 * sizeof(unsigned long long));
+            int rc2 = db.alloc(nwaves * 12 * sizeof(unsigned long long));
             if (rc2) return rc2;
-            SS_HIP(hipMemset(db.p, 0, nwaves * 4 * sizeof(unsigned long long)));
+            SS_HIP(hipMemset(db.p, 0, nwaves * 12 * sizeof(unsigned long long)));
             for (int rep = 0; rep < 3; ++rep) {  // last repetition is the warm one
                 f.dbg = db.as<unsigned long long>();
-                hipError_t e2 = want_mx ? ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info)
-                                        : ss::launch_mfcc_c256_pk(f, stream, cfg->num_cus, &info);
+                hipError_t e2 = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
                 if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c256_mx");
                 SS_HIP(hipStreamSynchronize(stream));
             }
-            std::vector<unsigned long long> hb(nwaves * 4);
+            std::vector<unsigned long long> hb(nwaves * 12);
             SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            const size_t launched = static_cast<size_t>(info.grid) * (info.block / 64);
             if (FILE *fp = std::fopen(dbg_path, "w")) {
-                for (size_t w = 0; w < nwaves; ++w)
-                    if (hb[4 * w + 2])
-                        std::fprintf(fp, "%zu %llu %llu %llu %llu %llu\n", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2],
-                                     hb[4 * w + 3] >> 32, hb[4 * w + 3] & 0xffffffffull);
+                for (size_t w = 0; w < launched; ++w) {
+                    if (!hb[4 * w + 2]) continue;
+                    std::fprintf(fp, "%zu %llu %llu %llu %llu %llu", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2],
+                                 hb[4 * w + 3] >> 32, hb[4 * w + 3] & 0xffffffffull);
+                    for (int i = 0; i < 8; ++i) std::fprintf(fp, " %llu", hb[4 * launched + 8 * w + i]);
+                    std::fprintf(fp, "\n");
+                }
                 std::fclose(fp);
             }
             f.dbg = nullptr;
         }
-        hipError_t e = want_mx ? ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info)
-                               : ss::launch_mfcc_c256_pk(f, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_pk/mx");
+        hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
+        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_mx");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
@@ -359,7 +351,6 @@ int ss_config_create(const ss_params *p, ss_config **out)
     ss::build_fast512m(h, c->fastm);
     if (c->fastm.ok) {
         SS_UP(d_fastm_tab, c->fastm.tab);
-        SS_UP(d_fastm_tab_pk, c->fastm.tab_pk);
     }
 #undef SS_UP
     *out = cfg.release();
@@ -372,7 +363,7 @@ void ss_config_destroy(ss_config *cfg)
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
                     cfg->d_fast_start,  cfg->d_fast_filter, cfg->d_fast_w, cfg->d_fast_dct16,
-                    cfg->d_fastm_tab,    cfg->d_fastm_tab_pk};
+                    cfg->d_fastm_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

@@ -105,7 +105,7 @@ struct Fast512MArgs {
     //                        k-steps ks_lo[tl] <= s < ks_hi[tl] (4 bins each) that hold a non-zero weight
     const float *tab;
     int32_t ks_lo[3], ks_hi[3];
-    int32_t n_mm;      // table floats after the fixed part: n_mm * 64 (mx) or n_grp * 256 (pk: n_mm = 4 * n_grp)
+    int32_t n_mm;
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
@@ -115,7 +115,5 @@ struct Fast512MArgs {
 };
 
 hipError_t launch_mfcc_c256_mx(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
-// Same arguments; two frames per 16-lane group, all arithmetic packed (ss_mfcc512_pk.hip).
-hipError_t launch_mfcc_c256_pk(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
 }  // namespace ss

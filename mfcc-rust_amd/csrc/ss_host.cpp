@@ -331,23 +331,6 @@ void build_fast512m(const HostTables &t, Fast512MTables &f)
                 if (c < Cc && m < M) f.tab[L::kCt + (tl * 4 + i) * 64 + lane] = t.dct[static_cast<size_t>(c) * M + m];
             }
     std::copy(wt.begin(), wt.end(), f.tab.begin() + L::kWt);
-    // grouped weights for the packed-pair kernel
-    std::vector<float> wg;
-    for (int tl = 0; tl < 3; ++tl) {
-        f.kg_lo[tl] = f.ks_lo[tl] / 4;
-        f.kg_hi[tl] = (f.ks_hi[tl] + 3) / 4;
-        for (int gq = f.kg_lo[tl]; gq < f.kg_hi[tl]; ++gq) {
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 4; ++i) {
-                    const int m = 16 * tl + (lane & 15), bin = 4 * (4 * gq + i) + (lane >> 4);
-                    wg.push_back(m < M && bin < F ? t.fb_dense[static_cast<size_t>(m) * F + bin] : 0.0f);
-                }
-            ++f.n_grp;
-        }
-    }
-    f.tab_pk.assign(f.tab.begin(), f.tab.begin() + L::kWt);
-    f.tab_pk.insert(f.tab_pk.end(), wg.begin(), wg.end());
-    if (f.n_grp > 14 || f.kg_hi[0] > 9 || f.kg_hi[1] > 9 || f.kg_hi[2] > 9) return;  // LDS budget / 36-step P rows
     f.ok = true;
 }
 

@@ -75,7 +75,7 @@ namespace fast512m_layout {
 constexpr int kTw2 = 0;                 // [15][16] float2
 constexpr int kTwn = kTw2 + 15 * 32;    // [8][16] float2
 constexpr int kCt = kTwn + 8 * 32;      // [12][64]
-constexpr int kWt = kCt + 12 * 64;      // [n_mm][64]; packed-pair kernel: [n_grp][64][4]
+constexpr int kWt = kCt + 12 * 64;      // [n_mm][64]
 }  // namespace fast512m_layout
 
 // The banded mel bank cut into 16-filter x 4-bin blocks (only the non-zero ones are kept), the DCT
@@ -85,11 +85,6 @@ struct Fast512MTables {
     std::vector<float> tab;
     int32_t ks_lo[3] = {0, 0, 0}, ks_hi[3] = {0, 0, 0};
     int32_t n_mm = 0;
-    // packed-pair kernel (ss_mfcc512_pk.hip): k-steps in aligned groups of 4 so that one ds_read_b128
-    // feeds four MFMAs: group range [kg_lo, kg_hi) per tile, weights at tab_pk[kWt + ((grp*64)+lane)*4 + i]
-    std::vector<float> tab_pk;
-    int32_t kg_lo[3] = {0, 0, 0}, kg_hi[3] = {0, 0, 0};
-    int32_t n_grp = 0;
 };
 void build_fast512m(const HostTables &t, Fast512MTables &f);
 

@@ -78,6 +78,60 @@ __device__ __forceinline__ float bperm(int addr, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
+// ln(x) from v_log_f32 (log2) with the denormal pre-scale the library form uses; ~1 ulp of log2.
+__device__ __forceinline__ float fast_ln(float x)
+{
+    const bool tiny = x < 1.17549435e-38f;
+    const float l = __builtin_amdgcn_logf(tiny ? x * 4294967296.f : x);
+    return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
+}
+
+// One 16-filter tile of the block-sparse mel product over k-steps [s, sh).  LDS latency under load is several
+// hundred cycles, so the operands of up to KB k-steps are fetched back to back (one wait) before the MFMAs
+// issue back to back.  `wt` walks the weight table (tile-major), `pbp` is the lane's P row.
+template <int KB>
+__device__ __forceinline__ f32x4 mel_tile(const float *&wt, const float *pbp, int s, int sh)
+{
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    while (s < sh) {
+        const int n = min(sh - s, KB);
+        float wa[KB], pb[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if (i < n) {
+                wa[i] = wt[64 * i];
+                pb[i] = pbp[4 * (s + i)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            if (i < n) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], pb[i], acc, 0, 0, 0);
+        }
+        wt += 64 * n;
+        s += n;
+    }
+    return acc;
+}
+
+// zero handling (feature.rs:230) + ln (:105) feeding one k-step of the DCT product (:120-123)
+__device__ __forceinline__ f32x4 dct_step(f32x4 o, float c, float x)
+{
+    x = x == 0.f ? kEpsM : x;
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(c, fast_ln(x), o, 0, 0, 0);
+}
+
+// Diagnostic stamp (SS_DEBUG_TIMES runs only): shader-clock time with the LDS queue drained, fenced against
+// the scheduler on both sides.  Accumulates segment lengths into seg[i].
+#define SS_STAMP(i)                                                                      \
+    if (a.dbg) {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long t_;                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        seg[i] += t_ - t_prev;                                                           \
+        t_prev = t_;                                                                     \
+    }
+
 template <int NE, bool EXACT>
 __device__ __forceinline__ void load_quad(const Fast512MArgs &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE])
 {
@@ -148,6 +202,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
     __syncthreads();
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    if (a.dbg) t_prev = __builtin_amdgcn_s_memtime();
 
     while (chunk < c_hi) {
         // claim the next chunk now so that its first quad can be prefetched during this one
@@ -161,13 +217,19 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
             float2 v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
-            if (qi + 1 < nq) load_quad<NE, EXACT>(a, q0 + 1, total, f, j, vin);
-            else if (next < c_hi) load_quad<NE, EXACT>(a, next * 2, total, f, j, vin);
+            if (!(a.ablate & 1)) {
+                if (qi + 1 < nq) load_quad<NE, EXACT>(a, q0 + 1, total, f, j, vin);
+                else if (next < c_hi) load_quad<NE, EXACT>(a, next * 2, total, f, j, vin);
+            }
 
+            SS_STAMP(0)  // loop overhead + input wait + unpack
             // ---- 256-point complex FFT: radix-16, transpose through LDS (two frames at a time), twiddle, radix-16 ----
             fft16_reg(v);
+            SS_STAMP(1)  // first radix-16
             float2 u[16];
-            if (lane < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = v[r];
+            if (lane < 32 && !(a.ablate & 2)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
                 wave_sync();
@@ -179,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
                 }
             }
             wave_sync();
-            if (lane >= 32) {
+            if (lane >= 32 && !(a.ablate & 2)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
                 wave_sync();
@@ -191,20 +253,29 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
                 }
             }
             wave_sync();
+            SS_STAMP(2)  // LDS exchange
 #pragma unroll
-            for (int r = 1; r < 16; ++r) u[r] = cmul(u[r], s_tw2[(r - 1) * 16 + j]);
+            for (int r = 1; r < 16; ++r) u[r] = cmul(u[r], (a.ablate & 32) ? make_float2(0.6f, 0.8f) : s_tw2[(r - 1) * 16 + j]);
             fft16_reg(u);  // u[r] = Z[j + 16 r]
+            SS_STAMP(3)  // twiddle + second radix-16
 
             // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
             float esum = 0.f;
             float *prow = ptile + (qi * 4 + f) * kPPitch;
+            // all 16 partner fetches (register 15 - r of lane 16 - j) and the 8 twiddles go out back to back: one LDS wait
+            float2 zcs[8], ws[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                zcs[r] = u[15 - r];
+                if (!(a.ablate & 4)) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
+                ws[r] = (a.ablate & 32) ? make_float2(0.6f, 0.8f) : s_twn[r * 16 + j];
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const float2 zk = u[r];
-                // partner register 15 - r; lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
-                float2 zc = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
-                if (j == 0) zc = u[(16 - r) & 15];
-                const float2 w = s_twn[r * 16 + j];
+                // lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
+                const float2 zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
+                const float2 w = ws[r];
                 const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
                 const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
                 const float2 wd = cmul(w, d);
@@ -213,7 +284,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
                 const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
                 const float pa = hscale * (POW2 ? na : __builtin_amdgcn_sqrtf(na));
                 const float pb = hscale * (POW2 ? nb : __builtin_amdgcn_sqrtf(nb));
-                prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70)
+                if (!(a.ablate & 64)) prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70)
                 esum += pa + pb;
             }
             if (j == 0) {
@@ -226,34 +297,27 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
             }
             float energy = row16_sum_m(esum);
             energy = energy == 0.f ? kEpsM : energy;  // zero_handling, feature.rs:219
-            if (j == 0) elog[qi * 4 + f] = __logf(energy);
+            if (j == 0) elog[qi * 4 + f] = fast_ln(energy);
+            SS_STAMP(4)  // untangle + magnitudes + energy
         }
         wave_sync();
 
         // ---- B1: block-sparse mel product on the matrix pipe (feature.rs:229) ----
-        f32x4 acc[3];
-#pragma unroll
-        for (int tl = 0; tl < 3; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float *pbp = ptile + (lane & 7) * kPPitch + (lane >> 4);
         const float *wt = s_wt + lane;
-#pragma unroll
-        for (int tl = 0; tl < 3; ++tl) {
-            for (int s = a.ks_lo[tl]; s < a.ks_hi[tl]; ++s) {
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(*wt, pbp[4 * s], acc[tl], 0, 0, 0);
-                wt += 64;
-            }
-        }
+        const int mlo = (a.ablate & 8) ? 100 : 0;
+        const f32x4 acc0 = mel_tile<18>(wt, pbp, a.ks_lo[0] + mlo, a.ks_hi[0]);
+        const f32x4 acc1 = mel_tile<18>(wt, pbp, a.ks_lo[1] + mlo, a.ks_hi[1]);
+        const f32x4 acc2 = mel_tile<18>(wt, pbp, a.ks_lo[2] + mlo, a.ks_hi[2]);
         // ---- B2: zero handling (feature.rs:230) + ln (:105);  B3: DCT-II (:120-123) ----
         f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tl = 0; tl < 3; ++tl) {
+        for (int i = 0; i < 4; ++i) o = dct_step(o, s_ct[i * 64 + lane], acc0[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = acc[tl][i];
-                x = x == 0.f ? kEpsM : x;
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(s_ct[(tl * 4 + i) * 64 + lane], __logf(x), o, 0, 0, 0);
-            }
-        }
+        for (int i = 0; i < 4; ++i) o = dct_step(o, s_ct[(4 + i) * 64 + lane], acc1[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o = dct_step(o, s_ct[(8 + i) * 64 + lane], acc2[i]);
+        SS_STAMP(5)  // mel + ln + DCT on the matrix pipe
         // ---- B4: scaling + column-0 replacement (feature.rs:126-146), staged coalesced store ----
         float *stage = wbase;  // the exchange region is idle during phase B
         {
@@ -282,9 +346,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
             const unsigned nfr = min(nq * 4, total - first);
             const int nout = static_cast<int>(nfr) * Cc;
             float *dst = a.out + static_cast<unsigned long long>(first) * Cc;
-            for (int i = lane; i < nout; i += 64) dst[i] = stage[i];
+            if (!(a.ablate & 16))
+                for (int i = lane; i < nout; i += 64) dst[i] = stage[i];
         }
         wave_sync();
+        SS_STAMP(6)  // staging + store
         chunk = next;
     }
     if (a.dbg && lane == 0) {
@@ -293,6 +359,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256_mx(const Fast512MArgs
         d[1] = t_pro;
         d[2] = __builtin_amdgcn_s_memrealtime();
         d[3] = (static_cast<unsigned long long>(n_done) << 32) | __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // XCC_ID
+        unsigned long long *sg = a.dbg + 4ull * gridDim.x * WAVES + 8ull * (blockIdx.x * WAVES + wave);
+        for (int i = 0; i < 8; ++i) sg[i] = seg[i];
     }
 }
 
@@ -340,6 +408,7 @@ hipError_t launch_mfcc_c256_mx(const Fast512MArgs &a, hipStream_t stream, int nu
 {
     static const char *w = std::getenv("SS_MX_WAVES");  // A/B knob for occupancy experiments
     if (w && std::atoi(w) == 16) return launch_mx<16>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 8) return launch_mx<8>(a, stream, num_cus, info);
     return launch_mx<12>(a, stream, num_cus, info);
 }
 

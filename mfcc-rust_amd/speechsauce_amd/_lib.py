@@ -11,7 +11,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
+# SS_LIB_PATH overrides the in-tree build (A/B runs of two builds in one process tree)
+LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
 
 SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED = range(6)
 FRAMING = {"contract": 0, "literal": 1}

@@ -35,14 +35,14 @@ namespace ss {
 namespace {
 
 constexpr float kEpsP = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
-constexpr int kWavesP = 8;
 constexpr int kGroupSlots = 272;                  // 16-byte slots per frame-pair exchange region (17 x 16)
-constexpr int kWaveBytesP = 4 * kGroupSlots * 16;  // 17408 B: exchange | later P tile, stage, ln(energy)
+// Per-wave LDS: the exchange region (4 frame pairs at once, or 2 at a time when HALF) | later P tile, stage, ln(energy)
+template <bool HALF> constexpr int kWaveBytesP = (HALF ? 2 : 4) * kGroupSlots * 16;  // 17408 B or 8704 B
 // P tile (reuses the exchange region): [pair 4][half 2][k-sub 4][36 k-steps] floats; bin = 4 s + k-sub.
 // One ds_read_b128 then feeds four consecutive k-steps of a lane's MFMA B operand.
 constexpr int kPPair = 288, kPHalf = 144, kPSub = 36;
-constexpr int kStageOff = 2048;                   // float offsets inside the wave region (beyond the P tile)
-constexpr int kElogOff = 2304;
+constexpr int kStageOff = 1280;                   // float offsets inside the wave region (beyond the 1152-float P tile)
+constexpr int kElogOff = 1536;
 constexpr int kTabTw2 = fast512m_layout::kTw2;
 constexpr int kTabTwn = fast512m_layout::kTwn;
 constexpr int kTabCt = fast512m_layout::kCt;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void load_octet(const Fast512MArgs &a, unsigned octet
     }
 }
 
-template <int NE, bool EXACT, bool POW2>
+template <int NE, bool EXACT, bool POW2, int kWavesP, bool HALF, bool PREFETCH>
 __global__ __launch_bounds__(kWavesP * 64) void ss_mfcc_c256_pk(const Fast512MArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -156,12 +156,12 @@ __global__ __launch_bounds__(kWavesP * 64) void ss_mfcc_c256_pk(const Fast512MAr
     const int j = lane & 15;  // lane within the pair's DPP row
 
     // ---- LDS carve: per-wave regions, then the shared table block, then the octet counter ----
-    float *wbase = reinterpret_cast<float *>(smem + wave * kWaveBytesP);
-    float4 *ex = reinterpret_cast<float4 *>(wbase) + g * kGroupSlots;  // this pair's exchange region
+    float *wbase = reinterpret_cast<float *>(smem + wave * kWaveBytesP<HALF>);
+    float4 *ex = reinterpret_cast<float4 *>(wbase) + (HALF ? (g & 1) : g) * kGroupSlots;  // this pair's exchange region
     float *ptile = wbase;                                              // [4 pairs][132 bins][A,B] after the exchange
     float *stage = wbase + kStageOff;
     float *elog = wbase + kElogOff;
-    float *s_tab = reinterpret_cast<float *>(smem + kWavesP * kWaveBytesP);
+    float *s_tab = reinterpret_cast<float *>(smem + kWavesP * kWaveBytesP<HALF>);
     const float2 *s_tw2 = reinterpret_cast<const float2 *>(s_tab + kTabTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + kTabTwn);
     const float *s_ct = s_tab + kTabCt;
@@ -201,24 +201,51 @@ __global__ __launch_bounds__(kWavesP * 64) void ss_mfcc_c256_pk(const Fast512MAr
         next = __builtin_amdgcn_readfirstlane(next);
         ++n_done;
 
+        if (!PREFETCH && n_done > 1) load_octet<NE, EXACT>(a, oct, total, g, j, va, vb);
         cx2 v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {  // zero padding to fft_points, processing.rs:147-156
             if (e < NE) v[e] = cx2{v2f{va[e].x, vb[e].x}, v2f{va[e].y, vb[e].y}};
             else v[e] = cx2{v2f{0.f, 0.f}, v2f{0.f, 0.f}};
         }
-        if (next < c_hi && !(a.ablate & 1)) load_octet<NE, EXACT>(a, next, total, g, j, va, vb);  // prefetch
+        if (PREFETCH && next < c_hi && !(a.ablate & 1)) load_octet<NE, EXACT>(a, next, total, g, j, va, vb);
 
         // ---- 256-point complex FFT of both frames: radix-16, transpose through LDS, twiddle, radix-16 ----
         fft16_pk(v);
         if (!(a.ablate & 2)) {
+            if (HALF) {
+                // two frame pairs at a time through the same 8704-B region; a lane's registers are free once it
+                // has written them, so the reads land in place
+                if (lane < 32) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ex[17 * j + r] = make_float4(v[r].x.x, v[r].x.y, v[r].y.x, v[r].y.y);
-            wave_order();
+                    for (int r = 0; r < 16; ++r) ex[17 * j + r] = make_float4(v[r].x.x, v[r].x.y, v[r].y.x, v[r].y.y);
+                    wave_order();
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const float4 t4 = ex[17 * n1 + j];
-                v[n1] = cx2{v2f{t4.x, t4.y}, v2f{t4.z, t4.w}};
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const float4 t4 = ex[17 * n1 + j];
+                        v[n1] = cx2{v2f{t4.x, t4.y}, v2f{t4.z, t4.w}};
+                    }
+                }
+                wave_order();
+                if (lane >= 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[17 * j + r] = make_float4(v[r].x.x, v[r].x.y, v[r].y.x, v[r].y.y);
+                    wave_order();
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const float4 t4 = ex[17 * n1 + j];
+                        v[n1] = cx2{v2f{t4.x, t4.y}, v2f{t4.z, t4.w}};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ex[17 * j + r] = make_float4(v[r].x.x, v[r].x.y, v[r].y.x, v[r].y.y);
+                wave_order();
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const float4 t4 = ex[17 * n1 + j];
+                    v[n1] = cx2{v2f{t4.x, t4.y}, v2f{t4.z, t4.w}};
+                }
             }
         }
         wave_order();
@@ -343,16 +370,15 @@ __global__ __launch_bounds__(kWavesP * 64) void ss_mfcc_c256_pk(const Fast512MAr
     }
 }
 
-}  // namespace
-
-hipError_t launch_mfcc_c256_pk(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+template <int kWavesP, bool HALF, bool PREFETCH>
+hipError_t launch_pk(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = static_cast<size_t>(kWavesP) * kWaveBytesP + static_cast<size_t>(kTabWt + a.n_mm * 64) * sizeof(float) + 16;  // n_mm = 4 * n_grp
+    const size_t lds = static_cast<size_t>(kWavesP) * kWaveBytesP<HALF> + static_cast<size_t>(kTabWt + a.n_mm * 64) * sizeof(float) + 16;  // n_mm = 4 * n_grp
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
     if (total == 0) return hipSuccess;
     const unsigned long long octets = (total + 7) / 8;
-    // one 8-wave workgroup per CU; fewer when there is not at least one octet per wave
+    // one workgroup per CU; fewer when there is not at least one octet per wave
     unsigned long long blocks = (octets + kWavesP - 1) / kWavesP;
     const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
     if (blocks > cap) blocks = cap;
@@ -367,19 +393,31 @@ hipError_t launch_mfcc_c256_pk(const Fast512MArgs &a, hipStream_t stream, int nu
     };
     const bool pow2 = a.spectrum_exponent == 2;
     if (a.flen == 320) {
-        return pow2 ? go(ss_mfcc_c256_pk<10, true, true>, "ss_mfcc_c256_pk<10,true,pow2>")
-                    : go(ss_mfcc_c256_pk<10, true, false>, "ss_mfcc_c256_pk<10,true>");
+        return pow2 ? go(ss_mfcc_c256_pk<10, true, true, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<10,true,pow2>")
+                    : go(ss_mfcc_c256_pk<10, true, false, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<10,true>");
     }
     if (a.flen == 512) {
-        return pow2 ? go(ss_mfcc_c256_pk<16, true, true>, "ss_mfcc_c256_pk<16,true,pow2>")
-                    : go(ss_mfcc_c256_pk<16, true, false>, "ss_mfcc_c256_pk<16,true>");
+        return pow2 ? go(ss_mfcc_c256_pk<16, true, true, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<16,true,pow2>")
+                    : go(ss_mfcc_c256_pk<16, true, false, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<16,true>");
     }
     if (a.flen <= 320) {
-        return pow2 ? go(ss_mfcc_c256_pk<10, false, true>, "ss_mfcc_c256_pk<10,false,pow2>")
-                    : go(ss_mfcc_c256_pk<10, false, false>, "ss_mfcc_c256_pk<10,false>");
+        return pow2 ? go(ss_mfcc_c256_pk<10, false, true, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<10,false,pow2>")
+                    : go(ss_mfcc_c256_pk<10, false, false, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<10,false>");
     }
-    return pow2 ? go(ss_mfcc_c256_pk<16, false, true>, "ss_mfcc_c256_pk<16,false,pow2>")
-                : go(ss_mfcc_c256_pk<16, false, false>, "ss_mfcc_c256_pk<16,false>");
+    return pow2 ? go(ss_mfcc_c256_pk<16, false, true, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<16,false,pow2>")
+                : go(ss_mfcc_c256_pk<16, false, false, kWavesP, HALF, PREFETCH>, "ss_mfcc_c256_pk<16,false>");
+}
+
+}  // namespace
+
+hipError_t launch_mfcc_c256_pk(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    static const char *w = std::getenv("SS_PK_WAVES");  // A/B knob for occupancy experiments
+    const int nw = w ? std::atoi(w) : 8;
+    if (nw == 16) return launch_pk<16, true, false>(a, stream, num_cus, info);
+    if (nw == 12) return launch_pk<12, true, false>(a, stream, num_cus, info);
+    if (nw == 13) return launch_pk<12, true, true>(a, stream, num_cus, info);
+    return launch_pk<8, false, true>(a, stream, num_cus, info);
 }
 
 }  // namespace ss

@@ -14,3 +14,12 @@ for q in np.unique(nq):
 for x in np.unique(xcc):
     m = xcc == x
     print(f"xcc {x}: {m.sum()} waves, start p50 {np.median(st[m]):.2f} end p50 {np.median(en[m]):.2f} max {en[m].max():.2f}")
+
+if d.shape[1] >= 14:
+    names = ["loop+input wait", "radix-16 #1", "LDS exchange", "twiddle+radix-16 #2", "untangle+|X|+energy", "mel+ln+DCT (MFMA)", "stage+store", "-"]
+    seg = d[:, 6:14].astype(np.float64)
+    tot = seg.sum(axis=1)
+    print("segment shares (shader-clock ticks, mean over waves; stamps fence overlaps, read SHARES not lengths):")
+    for i, nme in enumerate(names[:7]):
+        print(f"  {nme:24s} {seg[:, i].mean():12.0f}  {100 * seg[:, i].sum() / tot.sum():5.1f} %")
+    print(f"  total per wave {tot.mean():.0f} ticks over {nq.mean():.2f} chunks -> {tot.mean() / nq.mean():.0f} ticks per chunk")
