@@ -28,8 +28,7 @@ struct ss_config {
     float *d_dct = nullptr;
     // fft_points = 512 MFCC kernel tables (ss_mfcc512.hip)
     ss::Fast512Tables fast;
-    int32_t *d_fast_start = nullptr, *d_fast_filter = nullptr;
-    float *d_fast_w = nullptr, *d_fast_dct16 = nullptr;
+    float *d_fast_tab = nullptr;
     ss::Fast512MTables fastm;
     float *d_fastm_tab = nullptr;
 };
@@ -141,10 +140,13 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool fast_ok = !force_generic && cfg->fast.ok && out_kind == ss::OUT_MFCC && a.frame_mode == ss::FRAME_NORMAL &&
                          a.preemph == 0.0f && a.window == nullptr && (a.flen % 2 == 0) && (a.step % 2 == 0) &&
                          (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
-    // SS_MFCC512_VARIANT=valu selects the LDS/VALU mel+DCT variant (ss_mfcc512.hip) for A/B runs
+    // SS_MFCC512_VARIANT=mfma selects the block-sparse f32-MFMA mel+DCT build (ss_mfcc512_mfma.hip) for A/B runs
     static const char *variant = std::getenv("SS_MFCC512_VARIANT");
-    const bool want_valu = variant && std::strcmp(variant, "valu") == 0;
-    if (fast_ok && cfg->fastm.ok && !want_valu && static_cast<unsigned long long>(batch) * T < 0xffffffffull) {
+    const bool want_mfma = variant && std::strcmp(variant, "mfma") == 0;
+    const bool fits32 = static_cast<unsigned long long>(batch) * T < 0xffffffffull;
+    static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only: per-wave realtime stamps of ONE launch
+    static bool dbg_done = false;
+    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma) {
         ss::Fast512MArgs f{};
         f.x = d_x;
         f.ld = ld;
@@ -168,45 +170,12 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.dct_scale_00 = a.dct_scale_00;
         f.dc_elimination = a.dc_elimination;
         f.out = out0;
-        static const char *abl = std::getenv("SS_ABLATE");
-        f.ablate = abl ? std::atoi(abl) : 0;
-        // SS_DEBUG_TIMES=<file>: diagnostic only -- dump per-wave realtime stamps of ONE launch
-        static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");
-        static bool dbg_done = false;
-        if (dbg_path && !dbg_done) {
-            dbg_done = true;
-            const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
-            DeviceBuf db;
-            int rc2 = db.alloc(nwaves * 12 * sizeof(unsigned long long));
-            if (rc2) return rc2;
-            SS_HIP(hipMemset(db.p, 0, nwaves * 12 * sizeof(unsigned long long)));
-            for (int rep = 0; rep < 3; ++rep) {  // last repetition is the warm one
-                f.dbg = db.as<unsigned long long>();
-                hipError_t e2 = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
-                if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c256_mx");
-                SS_HIP(hipStreamSynchronize(stream));
-            }
-            std::vector<unsigned long long> hb(nwaves * 12);
-            SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            const size_t launched = static_cast<size_t>(info.grid) * (info.block / 64);
-            if (FILE *fp = std::fopen(dbg_path, "w")) {
-                for (size_t w = 0; w < launched; ++w) {
-                    if (!hb[4 * w + 2]) continue;
-                    std::fprintf(fp, "%zu %llu %llu %llu %llu %llu", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2],
-                                 hb[4 * w + 3] >> 32, hb[4 * w + 3] & 0xffffffffull);
-                    for (int i = 0; i < 8; ++i) std::fprintf(fp, " %llu", hb[4 * launched + 8 * w + i]);
-                    std::fprintf(fp, "\n");
-                }
-                std::fclose(fp);
-            }
-            f.dbg = nullptr;
-        }
         hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_mx");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    if (fast_ok) {
+    if (fast_ok && fits32) {
         ss::Fast512Args f{};
         f.x = d_x;
         f.ld = ld;
@@ -217,23 +186,40 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.n_frames = a.n_frames;
         f.scale = a.scale;
         f.spectrum_exponent = a.spectrum_exponent;
-        f.tw_c = cfg->d_tw_c;
-        f.tw_n = cfg->d_tw_n;
-        f.mel_start = cfg->d_fast_start;
-        f.mel_filter = cfg->d_fast_filter;
-        f.mel_w = cfg->d_fast_w;
-        for (int s = 0; s < 3; ++s) f.mel_maxlen[s] = cfg->fast.maxlen[s];
-        f.mel_wrows = cfg->fast.maxlen[0] + cfg->fast.maxlen[1] + cfg->fast.maxlen[2];
+        f.tab = cfg->d_fast_tab;
+        f.mel_wpitch = cfg->fast.wpitch;
+        for (int s = 0; s < 3; ++s) f.mel_q4[s] = cfg->fast.q4[s];
         f.n_filters = a.n_filters;
         f.n_ceps = a.n_ceps;
-        f.dct16 = cfg->d_fast_dct16;
         f.dct_scale_k = a.dct_scale_k;
         f.dct_scale_0 = a.dct_scale_0;
         f.dct_scale_00 = a.dct_scale_00;
         f.dc_elimination = a.dc_elimination;
-        const size_t tb = 132 * sizeof(float2) + sizeof(float) * 16 * (f.n_filters + static_cast<size_t>(f.mel_wrows)) + 96 * sizeof(int32_t);
-        f.table_bytes = static_cast<uint32_t>((tb + 255) & ~static_cast<size_t>(255));
         f.out = out0;
+        if (dbg_path && !dbg_done) {
+            dbg_done = true;
+            const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
+            DeviceBuf db;
+            int rc2 = db.alloc(nwaves * 4 * sizeof(unsigned long long));
+            if (rc2) return rc2;
+            for (int rep = 0; rep < 3; ++rep) {  // the last repetition is the warm one
+                SS_HIP(hipMemsetAsync(db.p, 0, nwaves * 4 * sizeof(unsigned long long), stream));
+                f.dbg = db.as<unsigned long long>();
+                hipError_t e2 = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
+                if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c256");
+                SS_HIP(hipStreamSynchronize(stream));
+            }
+            std::vector<unsigned long long> hb(nwaves * 4);
+            SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *fp = std::fopen(dbg_path, "w")) {
+                for (size_t w = 0; w < nwaves; ++w)
+                    if (hb[4 * w + 2])
+                        std::fprintf(fp, "%zu %llu %llu %llu %llu %llu\n", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2],
+                                     hb[4 * w + 3] >> 32, hb[4 * w + 3] & 0xffffffffull);
+                std::fclose(fp);
+            }
+            f.dbg = nullptr;
+        }
         hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256");
         g_last_kernel = info.kernel_name;
@@ -343,10 +329,7 @@ int ss_config_create(const ss_params *p, ss_config **out)
     SS_UP(d_dct, h.dct);
     ss::build_fast512(h, c->fast);
     if (c->fast.ok) {
-        SS_UP(d_fast_start, c->fast.mel_start);
-        SS_UP(d_fast_filter, c->fast.mel_filter);
-        SS_UP(d_fast_w, c->fast.mel_w);
-        SS_UP(d_fast_dct16, c->fast.dct16);
+        SS_UP(d_fast_tab, c->fast.tab);
     }
     ss::build_fast512m(h, c->fastm);
     if (c->fastm.ok) {
@@ -362,8 +345,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_start,  cfg->d_fast_filter, cfg->d_fast_w, cfg->d_fast_dct16,
-                    cfg->d_fastm_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

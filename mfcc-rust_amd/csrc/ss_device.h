@@ -71,21 +71,20 @@ struct Fast512Args {
     uint32_t n_samples, batch, flen, step, n_frames;
     float scale;
     int32_t spectrum_exponent;
-    const float2 *tw_c;  // exp(-2 pi i t / 256)
-    const float2 *tw_n;  // exp(-2 pi i k / 512), k <= 128
-    // mel lane tables: slot s (0..2), lane j (0..15) owns filter mel_filter[s*16+j] (or -1);
-    // its taps are mel_w[(row0(s) + q) * 16 + j], q < mel_maxlen[s], applied to P[mel_start[s*16+j] + q]
-    const int32_t *mel_start;
-    const int32_t *mel_filter;
-    const float *mel_w;
-    int32_t mel_maxlen[3];
-    int32_t mel_wrows;
+    // one table block, copied verbatim into LDS (layout: ss::fast512_layout in ss_internal.h):
+    //   tw2   [15][16] float2  exp(-2 pi i j r / 256), r = 1..15
+    //   twn   [8][16]  float2  exp(-2 pi i (j + 16 r) / 512)
+    //   cos   [16][52]         row c: cos(pi c (2 m_q + 1) / 2M) for q = slot*16 + lane < 48 (0 for unused q / c >= n_ceps)
+    //   start [3][16]  int32   first P bin of the filter owned by (slot, lane)
+    //   melw  [16][mel_wpitch] lane row: taps of slot 0, 1, 2, each zero-padded to a multiple of 4
+    const float *tab;
+    int32_t mel_wpitch;  // floats per lane row = 4 * (mel_q4[0] + mel_q4[1] + mel_q4[2])
+    int32_t mel_q4[3];   // taps / 4 per slot (lock-step loop lengths)
     uint32_t n_filters, n_ceps;
-    const float *dct16;  // [n_filters][16], cos(pi c (2m+1) / 2M) at [m*16 + c], zero for c >= n_ceps
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
-    uint32_t table_bytes;  // LDS bytes of the table area in front of the frame regions
     float *out;
+    unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
 };
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

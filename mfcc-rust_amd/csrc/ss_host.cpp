@@ -241,48 +241,57 @@ int build_tables(const ss_params &p, HostTables &t)
 
 void build_fast512(const HostTables &t, Fast512Tables &f)
 {
+    namespace L = fast512_layout;
     f = Fast512Tables{};
-    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral, F = t.d.n_bins;
+    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
     if (t.d.n_fft != 512 || M > 48 || Cc > 16) return;
+    if (t.bank.last_bin > 129) return;  // the kernel keeps P bins 0..128 (the bank ends at (F+1)/2 when high = sr/2)
+    constexpr int32_t kRow = 132;       // P bins a tap may touch: 0..128 plus three zero pad bins
     // order filters by tap count (longest first) and deal them 16 per slot
     std::vector<int32_t> order(M);
     for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
-    f.mel_start.assign(48, 0);
-    f.mel_filter.assign(48, -1);
-    for (int s = 0; s < 3; ++s)
-        for (int j = 0; j < 16; ++j) {
-            const size_t i = static_cast<size_t>(s) * 16 + j;
-            if (i < M && t.bank.len[order[i]] > f.maxlen[s]) f.maxlen[s] = t.bank.len[order[i]];
+    int32_t maxlen[3] = {0, 0, 0};
+    for (size_t q = 0; q < M; ++q) maxlen[q / 16] = std::max(maxlen[q / 16], t.bank.len[order[q]]);
+    for (int s = 0; s < 3; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2]);
+    if (f.wpitch == 0) f.wpitch = 4;
+    if (f.wpitch > 160) return;
+    f.tab.assign(static_cast<size_t>(L::kMelW) + 16 * f.wpitch, 0.0f);
+    for (int r = 1; r < 16; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256) = tw_c[j r]
+            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2] = t.tw_c[2 * (j * r)];
+            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2 + 1] = t.tw_c[2 * (j * r) + 1];
         }
-    const int rows = f.maxlen[0] + f.maxlen[1] + f.maxlen[2];
-    if (rows > 128) return;
-    f.mel_w.assign(static_cast<size_t>(rows > 0 ? rows : 1) * 16, 0.0f);
-    int row0 = 0;
+    for (int r = 0; r < 8; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i (j + 16 r) / 512) = tw_n[j + 16 r]
+            f.tab[L::kTwn + (r * 16 + j) * 2] = t.tw_n[2 * (j + 16 * r)];
+            f.tab[L::kTwn + (r * 16 + j) * 2 + 1] = t.tw_n[2 * (j + 16 * r) + 1];
+        }
+    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t off = 0;
     for (int s = 0; s < 3; ++s) {
+        const int32_t span = 4 * f.q4[s];
         for (int j = 0; j < 16; ++j) {
-            const size_t i = static_cast<size_t>(s) * 16 + j;
-            if (i >= M) continue;
-            const int32_t m = order[i];
-            f.mel_filter[i] = m;
-            int32_t start = t.bank.start[m];
+            const size_t q = static_cast<size_t>(s) * 16 + j;
+            start[q] = 0;
+            if (q >= M) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
+            const int32_t m = order[q];
+            int32_t st = t.bank.start[m];
             const int32_t len = t.bank.len[m];
-            // the lock-step loop reads maxlen[s] taps: keep start + maxlen inside the F-bin row
+            // the lock-step loop reads `span` taps: keep st + span inside the 132-bin row
             int32_t shift = 0;
-            if (start + f.maxlen[s] > static_cast<int32_t>(F)) shift = start + f.maxlen[s] - static_cast<int32_t>(F);
-            start -= shift;
-            f.mel_start[i] = start;
-            for (int32_t q = 0; q < len; ++q)
-                f.mel_w[static_cast<size_t>(row0 + shift + q) * 16 + j] = t.bank.w[t.bank.off[m] + q];
+            if (st + span > kRow) shift = st + span - kRow;
+            st -= shift;
+            start[q] = st;
+            for (int32_t i = 0; i < len; ++i)
+                f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
+            for (size_t c = 0; c < Cc; ++c) f.tab[L::kCos + c * 52 + q] = t.dct[c * M + m];
         }
-        row0 += f.maxlen[s];
+        off += span;
     }
-    f.dct16.assign(M * 16, 0.0f);
-    for (size_t m = 0; m < M; ++m)
-        for (size_t c = 0; c < Cc; ++c) f.dct16[m * 16 + c] = t.dct[c * M + m];
     f.ok = true;
 }
-
 
 void build_fast512m(const HostTables &t, Fast512MTables &f)
 {

@@ -58,15 +58,22 @@ void vorbis_window(size_t n, float *w);
 void hann_window(size_t n, float *w);
 int build_tables(const ss_params &p, HostTables &t);
 
-// Lane tables of the fft_points = 512 MFCC kernel: filters sorted by tap count and dealt to
-// 3 slots x 16 lanes so the lock-step tap loops are short.
+// Table block of the fft_points = 512 MFCC kernel (ss_mfcc512.hip), float offsets; global layout == LDS layout.
+namespace fast512_layout {
+constexpr int kTw2 = 0;                  // [15][16] float2
+constexpr int kTwn = kTw2 + 15 * 32;     // [8][16] float2
+constexpr int kCos = kTwn + 8 * 32;      // [16][52]
+constexpr int kStart = kCos + 16 * 52;   // [3][16] int32
+constexpr int kMelW = kStart + 48;       // [16][pitch]
+}  // namespace fast512_layout
+
+// Filters sorted by tap count and dealt to 3 slots x 16 lanes so the lock-step tap loops are short;
+// the log-mel row and the cosine table use the same (slot, lane) order.
 struct Fast512Tables {
     bool ok = false;
-    std::vector<int32_t> mel_start;   // [48]
-    std::vector<int32_t> mel_filter;  // [48]
-    std::vector<float> mel_w;         // [(maxlen0+maxlen1+maxlen2) x 16]
-    int32_t maxlen[3] = {0, 0, 0};
-    std::vector<float> dct16;         // [M x 16]
+    std::vector<float> tab;
+    int32_t q4[3] = {0, 0, 0};  // taps / 4 per slot
+    int32_t wpitch = 0;
 };
 void build_fast512(const HostTables &t, Fast512Tables &f);
 

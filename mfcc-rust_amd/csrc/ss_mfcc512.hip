@@ -1,34 +1,51 @@
-// ss_mfcc_c256: the headline kernel -- fused MFCC for fft_points = 512 (C = 256 packed complex
-// points) on gfx950, wave64.
+// ss_mfcc_c256: the headline kernel -- fused MFCC for fft_points = 512 (C = 256 packed complex points)
+// on gfx950 (MI355X), wave64.  Everything between the clip samples in HBM and the [frames x n_ceps]
+// block in HBM happens in registers and wave-private LDS.
 //
-// Mapping (why it looks like this on CDNA4):
-//   * 16 lanes (one DPP row) own one frame, 16 complex points per lane; a wave carries 4 frames,
-//     a 256-thread workgroup 16.  The 256-point FFT is two radix-16 register butterflies with ONE
-//     transposing exchange between them.  Every exchange is private to a wave, so the main loop
-//     has no workgroup barrier at all: LDS operations of one wave execute in order.
-//   * exchange buffer index i + (i >> 4) (one pad slot per 16): the stride-16 scatter of the
-//     first pass hits 16 distinct bank pairs per ds_write_b64 lane group, and a frame's slice is
-//     2176 B = 34 bank rows + 32 banks, so the two frames of a 32-lane ds_read_b64 group sit on
-//     complementary halves of the 64 banks.
-//   * zero padding is compile-time: a 320-sample frame fills only 10 of the 16 inputs of each
-//     first-pass butterfly (template NE), the rest fold away.
-//   * the frame energy is reduced across the 16 lanes with DPP row operations (no LDS).
-//   * mel: each lane owns up to three filters (host-sorted by length so the lock-step loop
-//     count is small); weights come from a [tap][lane] LDS table (conflict-free).
-//   * DCT-II: lane c < n_ceps accumulates its coefficient from the log-mel row (LDS broadcast).
-//   * HBM traffic: samples once (the 50 % frame overlap is served by L1/L2), 13 floats out.
+// Mapping
+//   * Work unit: a QUAD of 4 consecutive frames; 16 lanes (one DPP row) own one frame, 16 complex points
+//     per lane.  One persistent workgroup per CU; its waves pull quads from an LDS counter (dynamic
+//     balance inside the CU, no global atomics), and the next quad's samples are prefetched.
+//   * 256-point FFT = two radix-16 register butterflies with ONE transposing exchange through LDS.  The
+//     exchange is private to a wave (LDS operations of one wave execute in order), so the main loop has
+//     NO workgroup barrier.  It runs two frames at a time through a 2 x 2304-B region: ds_write_b64
+//     scatter to (n1,k1) -> 34*(n1>>1) + 2*k1 + (n1&1), read back with 8 ds_read_b128 per lane;
+//     conflict-free on both sides.  Zero padding is compile-time (template NE: a 320-sample frame fills
+//     10 of the 16 first-pass inputs).
+//   * The real-FFT untangle needs Z[256-k], which sits in lane 16-j, register 15-r: fetched with
+//     ds_bpermute_b32 (LDS crossbar, no memory round trip).
+//   * |X|/N for bins 0..128 goes to a P row in LDS (the mel bank ends at bin (F+1)/2, feature.rs:69-70);
+//     all 257 bins feed the frame energy, reduced over the DPP row.
+//   * mel: banded reduction -- each lane owns up to three filters (host-sorted by tap count so the
+//     lock-step loops are short: 16/6/1 taps at the defaults); weights are per-lane rows in LDS read as
+//     ds_read_b128, all fetches of a stage issue back to back before the FMAs (LDS latency under load
+//     is several hundred cycles).  Not MFMA: on gfx950 v_mfma_f32_* shares the FP32 datapath with
+//     the VALU (measured: a VALU wave and an f32-MFMA wave on one SIMD take the SUM of their times),
+//     so a block-dense product costs 8x the sparse one (tools/ubench/mfma_valu_overlap.hip; the
+//     MFMA build of this kernel is kept as ss_mfcc512_mfma.hip for the A/B).
+//   * DCT-II: lane c < n_ceps accumulates its coefficient from the 48-entry log-mel row (ds_read_b128
+//     broadcasts) against its own cosine row (ds_read_b128, pitch 52 floats: conflict-free).
+//   * HBM traffic: samples once (the 50 % frame overlap is served by L1/L2), n_ceps floats per frame out.
+// Compiled with -fno-slp-vectorize: v_pk_*_f32 issues at half the rate of the scalar forms on gfx950
+// (tools/ubench/valu_rate.hip), so packing buys nothing and costs registers.
 //
 // Reference semantics: feature.rs:99-148 (mfcc), :200-233 (mfe), processing.rs:65-181.
 #include "ss_device.h"
 #include "ss_fft_reg.h"
+#include "ss_internal.h"
+
+#include <cstdlib>
 
 namespace ss {
 
 namespace {
 
 constexpr float kEpsF = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
-constexpr int kFrameSlots = 272;        // float2 per frame region (256 + 16 pad)
-constexpr int kTableOffset = 16 * kFrameSlots + 2;  // float2 units; +2: lane 0 of the last frame reads one slot past its region
+constexpr int kZStride = 288;           // float2 per frame exchange slot (2304 B = 9 bank rows)
+constexpr int kPRow = 144;              // floats per P row: bins 0..128, 3 zero pad bins, padding
+constexpr int kFRowOff = 4 * kPRow;     // log-mel rows [4][48] behind the P rows
+constexpr int kWaveFloats = 2 * kZStride * 2;  // 1152 floats = 4608 B; P rows (576) + log-mel rows (192) reuse it
+namespace L = fast512_layout;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
@@ -46,184 +63,321 @@ __device__ __forceinline__ float row16_sum(float v)
     return v;
 }
 
+// Wave-private LDS hand-off: the hardware keeps one wave's LDS operations in order; this only stops the
+// compiler from reordering the accesses around the point.
+__device__ __forceinline__ void wave_order()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float bperm(int addr, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// ln(x) from v_log_f32 (log2) with the denormal pre-scale the library form uses; ~1 ulp of log2.
+__device__ __forceinline__ float fast_ln(float x)
+{
+    const bool tiny = x < 1.17549435e-38f;
+    const float l = __builtin_amdgcn_logf(tiny ? x * 4294967296.f : x);
+    return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
+}
+
 template <int NE, bool EXACT>
-__global__ __launch_bounds__(256) void ss_mfcc_c256(const Fast512Args a)
+__device__ __forceinline__ void load_quad(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE])
+{
+    unsigned gf = quad * 4 + f;
+    gf = gf < total ? gf : total - 1;
+    const unsigned clip = gf / a.n_frames;
+    const unsigned t = gf - clip * a.n_frames;
+    // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
+    const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int n = j + 16 * e;
+        if (EXACT) vin[e] = src[n];
+        else vin[e] = 2 * n < static_cast<int>(a.flen) ? src[n] : make_float2(0.f, 0.f);
+    }
+}
+
+// One mel slot with a compile-time tap count (multiple of 4): weights and P taps are all requested before
+// the first FMA.  `w4` = this lane's weight row at the slot's offset, `p` = P row at the slot's start bin.
+template <int Q4>
+__device__ __forceinline__ float mel_slot_fixed(const float4 *w4, const float *p)
+{
+    float4 w[Q4];
+    float t[4 * Q4];
+#pragma unroll
+    for (int i = 0; i < Q4; ++i) w[i] = w4[i];
+#pragma unroll
+    for (int i = 0; i < 4 * Q4; ++i) t[i] = p[i];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < Q4; ++i) {
+        acc = fmaf(w[i].x, t[4 * i], acc);
+        acc = fmaf(w[i].y, t[4 * i + 1], acc);
+        acc = fmaf(w[i].z, t[4 * i + 2], acc);
+        acc = fmaf(w[i].w, t[4 * i + 3], acc);
+    }
+    return acc;
+}
+
+// Same with a run-time tap count (configurations other than the default bank shape).
+__device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p, int q4)
+{
+    float acc = 0.f;
+    for (int i = 0; i < q4; ++i) {
+        const float4 w = w4[i];
+        acc = fmaf(w.x, p[4 * i], acc);
+        acc = fmaf(w.y, p[4 * i + 1], acc);
+        acc = fmaf(w.z, p[4 * i + 2], acc);
+        acc = fmaf(w.w, p[4 * i + 3], acc);
+    }
+    return acc;
+}
+
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421>
+__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
-    const int f = lane >> 4;  // frame within the wave
-    const int j = lane & 15;  // lane within the frame
+    const unsigned long long t_start = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int f = lane >> 4;  // frame within the quad
+    const int j = lane & 15;  // lane within the frame (DPP row)
 
-    // ---- LDS carve: one 2176-B region per frame first (compile-time 8-byte alignment -> ds_read/write_b64),
-    //      then the read-only tables ----
-    float2 *zfr = reinterpret_cast<float2 *>(smem) + (wave * 4 + f) * kFrameSlots;
-    float *prow = reinterpret_cast<float *>(zfr);  // P[0..256] reuses the frame region after the untangle reads
-    float *frow = prow + 260;                      // log-mel row
-    float2 *s_twn = reinterpret_cast<float2 *>(smem) + kTableOffset;          // 129 (+3 pad) float2
-    float *s_dct = reinterpret_cast<float *>(s_twn + 132);                    // [M][16]
-    float *s_melw = s_dct + a.n_filters * 16;                                 // [sum maxlen][16]
-    int *s_melst = reinterpret_cast<int *>(s_melw + a.mel_wrows * 16);        // [3][16]
-    int *s_melf = s_melst + 48;                                               // [3][16]
+    // ---- LDS carve: per-wave regions, then the shared read-only table block, then the quad counter ----
+    float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloats;
+    float2 *zh = reinterpret_cast<float2 *>(wbase) + (f & 1) * kZStride;  // this frame's slot of the 2-frame exchange
+    float *prow = wbase + f * kPRow;                                      // P[0..131] after the exchange
+    float *frow = wbase + kFRowOff + f * 48;                              // ln(mel) in (slot, lane) order
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloats;
+    const float2 *s_tw2 = reinterpret_cast<const float2 *>(s_tab + L::kTw2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const float *s_cos = s_tab + L::kCos;
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const float *s_melw = s_tab + L::kMelW;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 16 * a.mel_wpitch);
 
-    for (int i = tid; i < 129; i += 256) s_twn[i] = a.tw_n[i];
-    for (int i = tid; i < static_cast<int>(a.n_filters) * 16; i += 256) s_dct[i] = a.dct16[i];
-    for (int i = tid; i < a.mel_wrows * 16; i += 256) s_melw[i] = a.mel_w[i];
-    if (tid < 48) {
-        s_melst[tid] = a.mel_start[tid];
-        s_melf[tid] = a.mel_filter[tid];
+    // quad range of this workgroup (contiguous, balanced to within one quad)
+    const unsigned total = a.batch * a.n_frames;
+    const unsigned quads = (total + 3) / 4;
+    const unsigned q_lo = static_cast<unsigned>(static_cast<unsigned long long>(quads) * blockIdx.x / gridDim.x);
+    const unsigned q_hi = static_cast<unsigned>(static_cast<unsigned long long>(quads) * (blockIdx.x + 1) / gridDim.x);
+
+    // the table block arrives as float4s, global layout == LDS layout
+    {
+        const int n4 = (L::kMelW + 16 * a.mel_wpitch) / 4;
+        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = q_lo + WAVES;
     }
-    // second-pass twiddles exp(-2 pi i j r / 256), r = 1..15, live in registers for the whole kernel
-    float2 tw2[15];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tw2[r - 1] = a.tw_c[j * r];
-    __syncthreads();
+    // first quad of this wave; its loads are in flight across the barrier
+    unsigned quad = q_lo + wave;
+    float2 vin[NE];
+    if (quad < q_hi) load_quad<NE, EXACT>(a, quad, total, f, j, vin);
 
-    const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
-    const unsigned long long groups = (total + 15) / 16;
-    const int M = static_cast<int>(a.n_filters);
+    const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
+    const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
     const int Cc = static_cast<int>(a.n_ceps);
-    // partner index base for Z[256-k]: lanes j >= 1 read phys(256-k) = (271 - j) - 17 i, lane 0 reads 272 - 17 i
-    const int cbase = j == 0 ? 272 : 271 - j;
+    // |X| = (1/2)|...|: the 1/2 of the untangle is folded into the scale (1/4 for the squared form)
+    const float hscale = POW2 ? 0.25f * a.scale : 0.5f * a.scale;
+    __syncthreads();
+    const int st0 = s_start[j], st1 = s_start[16 + j], st2 = s_start[32 + j];  // first bin of this lane's three filters
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
+    const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
+    const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned n_done = 0;
 
-    for (unsigned long long g = blockIdx.x; g < groups; g += gridDim.x) {
-        const unsigned long long gf = g * 16 + wave * 4 + f;
-        const bool active = gf < total;
-        const unsigned long long gfc = active ? gf : total - 1;
-        const unsigned clip = static_cast<unsigned>(gfc / a.n_frames);
-        const unsigned t = static_cast<unsigned>(gfc - static_cast<unsigned long long>(clip) * a.n_frames);
-        // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
-        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
+    while (quad < q_hi) {
+        // claim the next quad now so that its samples can be prefetched during this one
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+        ++n_done;
 
         float2 v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (e < NE) {
-                const int n = j + 16 * e;
-                if (EXACT) v[e] = src[n];
-                else v[e] = 2 * n < static_cast<int>(a.flen) ? src[n] : make_float2(0.f, 0.f);
-            } else {
-                v[e] = make_float2(0.f, 0.f);  // zero padding to fft_points (processing.rs:147-156)
+        for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
+        if (next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
+
+        // ---- 256-point complex FFT: radix-16, transpose through LDS (two frames at a time), twiddle, radix-16 ----
+        fft16_reg(v);
+        float2 u[16];
+        if (lane < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
+            wave_order();
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&zh[34 * p + 2 * j]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
-        fft16_reg(v);
+        wave_order();
+        if (lane >= 32) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zfr[17 * j + r] = v[r];
-        __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
+            wave_order();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = zfr[j + 17 * r];
+            for (int p = 0; p < 8; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&zh[34 * p + 2 * j]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order();
 #pragma unroll
-        for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw2[r - 1]);
-        fft16_reg(v);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zfr[j + 17 * r] = v[r];  // natural order: Z[k] at k + (k >> 4)
-        __builtin_amdgcn_wave_barrier();
+        for (int r = 1; r < 16; ++r) u[r] = cmul(u[r], s_tw2[(r - 1) * 16 + j]);
+        fft16_reg(u);  // u[r] = Z[j + 16 r]
 
-        // ---- untangle Z -> X, magnitude (processing.rs:168), * 1/N (:180), row sum (feature.rs:216) ----
-        float pk[8], pc[8];
+        // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
+        // all 16 partner fetches (register 15 - r of lane 16 - j) and the 8 twiddles go out back to back: one LDS wait
+        float2 zcs[8], ws[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
+            ws[r] = s_twn[r * 16 + j];
+        }
+        if (j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float esum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = j + 16 * i;
-            const float2 zk = zfr[j + 17 * i];
-            float2 zc = zfr[cbase - 17 * i];
-            if (i == 0 && j == 0) zc = zk;  // Z[256] == Z[0]
-            const float2 w = s_twn[k];
-            const float2 s = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-            const float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));
+        for (int r = 0; r < 8; ++r) {
+            const float2 zk = u[r];
+            // lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
+            const float2 zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
+            const float2 w = ws[r];
+            const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+            const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
             const float2 wd = cmul(w, d);
-            const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // X[k]
-            const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // conj X[256-k]
-            const float ma = __builtin_amdgcn_sqrtf(xa_r * xa_r + xa_i * xa_i);
-            const float mb = __builtin_amdgcn_sqrtf(xb_r * xb_r + xb_i * xb_i);
-            pk[i] = a.spectrum_exponent == 2 ? a.scale * (ma * ma) : a.scale * ma;
-            pc[i] = a.spectrum_exponent == 2 ? a.scale * (mb * mb) : a.scale * mb;
-            esum += pk[i] + pc[i];
+            const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // 2 X[k]
+            const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // 2 conj X[256-k]
+            const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
+            const float pa = hscale * (POW2 ? na : __builtin_amdgcn_sqrtf(na));
+            const float pb = hscale * (POW2 ? nb : __builtin_amdgcn_sqrtf(nb));
+            prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70)
+            esum += pa + pb;
         }
-        float p128 = 0.f;
         if (j == 0) {
-            const float2 z = zfr[128 + 8];  // X[128] = conj Z[128]
-            const float m = __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
-            p128 = a.spectrum_exponent == 2 ? a.scale * (m * m) : a.scale * m;
+            // lane 0's pair k = 0 produced X[0] and X[256]; X[128] = conj Z[128] is the one extra bin
+            const float2 z = u[8];
+            const float n = 4.f * (z.x * z.x + z.y * z.y);
+            const float p128 = hscale * (POW2 ? n : __builtin_amdgcn_sqrtf(n));
+            prow[128] = p128;
             esum += p128;
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            prow[j + 16 * i] = pk[i];
-            prow[256 - (j + 16 * i)] = pc[i];
-        }
-        if (j == 0) prow[128] = p128;
-        __builtin_amdgcn_wave_barrier();
         float energy = row16_sum(esum);
         energy = energy == 0.f ? kEpsF : energy;  // zero_handling, feature.rs:219
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
-        int wrow = 0;
+        float m0, m1, m2;
+        if (BANK421) {
+            m0 = mel_slot_fixed<4>(w4, prow + st0);
+            m1 = mel_slot_fixed<2>(w4 + 4, prow + st1);
+            m2 = mel_slot_fixed<1>(w4 + 6, prow + st2);
+        } else {
+            m0 = mel_slot_loop(w4, prow + st0, a.mel_q4[0]);
+            m1 = mel_slot_loop(w4 + a.mel_q4[0], prow + st1, a.mel_q4[1]);
+            m2 = mel_slot_loop(w4 + a.mel_q4[0] + a.mel_q4[1], prow + st2, a.mel_q4[2]);
+        }
+        frow[j] = fast_ln(m0 == 0.f ? kEpsF : m0);
+        frow[16 + j] = fast_ln(m1 == 0.f ? kEpsF : m1);
+        frow[32 + j] = fast_ln(m2 == 0.f ? kEpsF : m2);
+        wave_order();
+
+        // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 48-entry row ----
+        float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int len = a.mel_maxlen[s];
-            if (len > 0) {
-                const float *pp = prow + s_melst[s * 16 + j];
-                const float *ww = s_melw + wrow * 16 + j;
-                float acc = 0.f;
-                for (int q = 0; q < len; ++q) acc = fmaf(ww[q * 16], pp[q], acc);
-                const int m = s_melf[s * 16 + j];
-                acc = acc == 0.f ? kEpsF : acc;
-                if (m >= 0) frow[m] = __logf(acc);
-                wrow += len;
+        for (int h = 0; h < 2; ++h) {
+            float4 lq[6], cq[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (6 * h + i)]);
+                cq[i] = c4[6 * h + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                acc = fmaf(lq[i].x, cq[i].x, acc);
+                acc = fmaf(lq[i].y, cq[i].y, acc);
+                acc = fmaf(lq[i].z, cq[i].z, acc);
+                acc = fmaf(lq[i].w, cq[i].w, acc);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- DCT-II, first n_ceps coefficients, scaling + column-0 replacement (feature.rs:120-146) ----
-        if (j < Cc) {
-            float acc = 0.f;
-            for (int m = 0; m < M; ++m) acc = fmaf(frow[m], s_dct[m * 16 + j], acc);
-            float o;
-            if (j == 0) o = a.dc_elimination ? __logf(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-            else o = acc * a.dct_scale_k;
-            if (active) a.out[gf * Cc + j] = o;
+        // ---- scaling + column-0 replacement (feature.rs:126-146) and the store ----
+        {
+            const unsigned gf = quad * 4 + f;
+            float o = acc * a.dct_scale_k;
+            if (j == 0) {
+                if (a.dc_elimination) {
+                    o = fast_ln(energy);
+                } else {
+                    const unsigned gfc = min(gf, total - 1);
+                    o = acc * (gfc % a.n_frames == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                }
+            }
+            if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_order();
+        quad = next;
+    }
+    if (a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + 4ull * (blockIdx.x * WAVES + wave);
+        d[0] = t_start;
+        d[1] = t_pro;
+        d[2] = __builtin_amdgcn_s_memrealtime();
+        d[3] = (static_cast<unsigned long long>(n_done) << 32) | __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // XCC_ID
     }
 }
 
-}  // namespace
-
-size_t fast512_lds_bytes(const Fast512Args &a)
+template <int WAVES>
+hipError_t launch_w(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    return a.table_bytes + kTableOffset * sizeof(float2);
-}
-
-hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
-{
-    const size_t lds = fast512_lds_bytes(a);
+    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloats + L::kMelW + 16 * a.mel_wpitch) * sizeof(float) + 16;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
-    const unsigned long long groups = (total + 15) / 16;
-    if (groups == 0) return hipSuccess;
-    // persistent grid: at most 4 workgroups per CU, sized so that every workgroup gets the same number of groups
-    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * 4;
-    const unsigned long long per = (groups + cap - 1) / cap;
-    const unsigned grid = static_cast<unsigned>((groups + per - 1) / per);
-    const bool exact10 = a.flen == 320, full = a.flen == 512;
+    if (total == 0) return hipSuccess;
+    const unsigned long long quads = (total + 3) / 4;
+    // one workgroup per CU; fewer when there is not at least one quad per wave
+    unsigned long long blocks = (quads + WAVES - 1) / WAVES;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    if (blocks > cap) blocks = cap;
+    const unsigned grid = static_cast<unsigned>(blocks);
     auto go = [&](auto kern, const char *name) {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                static_cast<int>(lds));
             if (e != hipSuccess) return e;
         }
-        if (info) *info = LaunchInfo{name, grid, 256u, lds};
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
         return hipGetLastError();
     };
-    if (exact10) return go(ss_mfcc_c256<10, true>, "ss_mfcc_c256<10,true>");
-    if (full) return go(ss_mfcc_c256<16, true>, "ss_mfcc_c256<16,true>");
-    if (a.flen <= 320) return go(ss_mfcc_c256<10, false>, "ss_mfcc_c256<10,false>");
-    return go(ss_mfcc_c256<16, false>, "ss_mfcc_c256<16,false>");
+    const bool pow2 = a.spectrum_exponent == 2;
+    const bool b421 = a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1;
+    if (a.flen == 320 && !pow2 && b421) return go(ss_mfcc_c256<10, true, false, WAVES, true>, "ss_mfcc_c256<10,exact,bank421>");
+    if (a.flen == 320) {
+        return pow2 ? go(ss_mfcc_c256<10, true, true, WAVES, false>, "ss_mfcc_c256<10,exact,pow2>")
+                    : go(ss_mfcc_c256<10, true, false, WAVES, false>, "ss_mfcc_c256<10,exact>");
+    }
+    if (a.flen <= 320) {
+        return pow2 ? go(ss_mfcc_c256<10, false, true, WAVES, false>, "ss_mfcc_c256<10,pow2>")
+                    : go(ss_mfcc_c256<10, false, false, WAVES, false>, "ss_mfcc_c256<10>");
+    }
+    return pow2 ? go(ss_mfcc_c256<16, false, true, WAVES, false>, "ss_mfcc_c256<16,pow2>")
+                : go(ss_mfcc_c256<16, false, false, WAVES, false>, "ss_mfcc_c256<16>");
+}
+
+}  // namespace
+
+hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
+    if (w && std::atoi(w) == 16) return launch_w<16>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 8) return launch_w<8>(a, stream, num_cus, info);
+    return launch_w<12>(a, stream, num_cus, info);
 }
 
 }  // namespace ss
