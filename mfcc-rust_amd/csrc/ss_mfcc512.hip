@@ -8,9 +8,9 @@
 //     balance inside the CU, no global atomics), and the next quad's samples are prefetched.
 //   * 256-point FFT = two radix-16 register butterflies with ONE transposing exchange through LDS.  The
 //     exchange is private to a wave (LDS operations of one wave execute in order), so the main loop has
-//     NO workgroup barrier.  It runs two frames at a time through a 2 x 2304-B region: ds_write_b64
-//     scatter to (n1,k1) -> 34*(n1>>1) + 2*k1 + (n1&1), read back with 8 ds_read_b128 per lane;
-//     conflict-free on both sides.  Zero padding is compile-time (template NE: a 320-sample frame fills
+//     NO workgroup barrier.  Each frame has a 2304-B slot: ds_write_b64 scatter to
+//     (n1,k1) -> 34*(n1>>1) + 2*k1 + (n1&1), read back with 8 ds_read_b128 per lane; conflict-free on
+//     both sides (2304 B = 9 bank rows keeps the b128 lane groups of neighbouring frames apart).  Zero padding is compile-time (template NE: a 320-sample frame fills
 //     10 of the 16 first-pass inputs).
 //   * The real-FFT untangle needs Z[256-k], which sits in lane 16-j, register 15-r: fetched with
 //     ds_bpermute_b32 (LDS crossbar, no memory round trip).
@@ -44,7 +44,7 @@ constexpr float kEpsF = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
 constexpr int kZStride = 288;           // float2 per frame exchange slot (2304 B = 9 bank rows)
 constexpr int kPRow = 144;              // floats per P row: bins 0..128, 3 zero pad bins, padding
 constexpr int kFRowOff = 4 * kPRow;     // log-mel rows [4][48] behind the P rows
-constexpr int kWaveFloats = 2 * kZStride * 2;  // 1152 floats = 4608 B; P rows (576) + log-mel rows (192) reuse it
+constexpr int kWaveFloats = 4 * kZStride * 2;  // 2304 floats = 9216 B: four exchange slots; P rows (576) + log-mel rows (192) reuse them
 namespace L = fast512_layout;
 
 template <int CTRL>
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 
     // ---- LDS carve: per-wave regions, then the shared read-only table block, then the quad counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloats;
-    float2 *zh = reinterpret_cast<float2 *>(wbase) + (f & 1) * kZStride;  // this frame's slot of the 2-frame exchange
+    float2 *zh = reinterpret_cast<float2 *>(wbase) + f * kZStride;        // this frame's exchange slot
     float *prow = wbase + f * kPRow;                                      // P[0..131] after the exchange
     float *frow = wbase + kFRowOff + f * 48;                              // ln(mel) in (slot, lane) order
     float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloats;
@@ -187,6 +187,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const int st0 = s_start[j], st1 = s_start[16 + j], st2 = s_start[32 + j];  // first bin of this lane's three filters
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
+    float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512), resident
+#pragma unroll
+    for (int r = 0; r < 8; ++r) twn[r] = s_twn[r * 16 + j];
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
 
@@ -202,31 +205,17 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
         if (next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
 
-        // ---- 256-point complex FFT: radix-16, transpose through LDS (two frames at a time), twiddle, radix-16 ----
+        // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
         fft16_reg(v);
-        float2 u[16];
-        if (lane < 32) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
-            wave_order();
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(&zh[34 * p + 2 * j]);
-                u[2 * p] = make_float2(t4.x, t4.y);
-                u[2 * p + 1] = make_float2(t4.z, t4.w);
-            }
-        }
+        for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         wave_order();
-        if (lane >= 32) {
+        float2 u[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
-            wave_order();
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(&zh[34 * p + 2 * j]);
-                u[2 * p] = make_float2(t4.x, t4.y);
-                u[2 * p + 1] = make_float2(t4.z, t4.w);
-            }
+        for (int p = 0; p < 8; ++p) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(&zh[34 * p + 2 * j]);
+            u[2 * p] = make_float2(t4.x, t4.y);
+            u[2 * p + 1] = make_float2(t4.z, t4.w);
         }
         wave_order();
 #pragma unroll
@@ -234,13 +223,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         fft16_reg(u);  // u[r] = Z[j + 16 r]
 
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
-        // all 16 partner fetches (register 15 - r of lane 16 - j) and the 8 twiddles go out back to back: one LDS wait
-        float2 zcs[8], ws[8];
+        // all 16 partner fetches (register 15 - r of lane 16 - j) go out back to back: one LDS wait
+        float2 zcs[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
-            ws[r] = s_twn[r * 16 + j];
-        }
+        for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         if (j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float esum = 0.f;
 #pragma unroll
@@ -248,7 +234,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             const float2 zk = u[r];
             // lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
             const float2 zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
-            const float2 w = ws[r];
+            const float2 w = twn[r];
             const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
             const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
             const float2 wd = cmul(w, d);
