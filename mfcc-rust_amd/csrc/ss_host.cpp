@@ -259,9 +259,10 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     if (f.wpitch > 160) return;
     f.tab.assign(static_cast<size_t>(L::kMelW) + 16 * f.wpitch, 0.0f);
     for (int r = 1; r < 16; ++r)
-        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256) = tw_c[j r]
-            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2] = t.tw_c[2 * (j * r)];
-            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2 + 1] = t.tw_c[2 * (j * r) + 1];
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256) = tw_c[j r]; two twiddles per 16-byte slot
+            const int p = (r - 1) / 2, half = (r - 1) % 2;
+            f.tab[L::kTw2 + (p * 16 + j) * 4 + 2 * half] = t.tw_c[2 * (j * r)];
+            f.tab[L::kTw2 + (p * 16 + j) * 4 + 2 * half + 1] = t.tw_c[2 * (j * r) + 1];
         }
     for (int r = 0; r < 8; ++r)
         for (int j = 0; j < 16; ++j) {  // exp(-2 pi i (j + 16 r) / 512) = tw_n[j + 16 r]

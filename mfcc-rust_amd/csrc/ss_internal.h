@@ -60,8 +60,8 @@ int build_tables(const ss_params &p, HostTables &t);
 
 // Table block of the fft_points = 512 MFCC kernel (ss_mfcc512.hip), float offsets; global layout == LDS layout.
 namespace fast512_layout {
-constexpr int kTw2 = 0;                  // [15][16] float2
-constexpr int kTwn = kTw2 + 15 * 32;     // [8][16] float2
+constexpr int kTw2 = 0;                  // [8][16] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 256); last .zw unused
+constexpr int kTwn = kTw2 + 8 * 64;      // [8][16] float2
 constexpr int kCos = kTwn + 8 * 32;      // [16][52]
 constexpr int kStart = kCos + 16 * 52;   // [3][16] int32
 constexpr int kMelW = kStart + 48;       // [16][pitch]

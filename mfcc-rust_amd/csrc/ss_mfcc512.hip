@@ -43,8 +43,8 @@ namespace {
 constexpr float kEpsF = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
 constexpr int kZStride = 288;           // float2 per frame exchange slot (2304 B = 9 bank rows)
 constexpr int kPRow = 144;              // floats per P row: bins 0..128, 3 zero pad bins, padding
-constexpr int kFRowOff = 4 * kPRow;     // log-mel rows [4][48] behind the P rows
-constexpr int kWaveFloats = 4 * kZStride * 2;  // 2304 floats = 9216 B: four exchange slots; P rows (576) + log-mel rows (192) reuse them
+constexpr int kPOff = 4 * kZStride * 2;  // P rows sit behind the exchange slots: their zero pad bins persist
+constexpr int kWaveFloats = 4 * kZStride * 2 + 4 * kPRow;  // four exchange slots (log-mel rows reuse them) + four P rows
 namespace L = fast512_layout;
 
 template <int CTRL>
@@ -137,9 +137,10 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421>
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
+    constexpr bool PREFETCH = WAVES <= 12;  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -151,10 +152,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     // ---- LDS carve: per-wave regions, then the shared read-only table block, then the quad counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloats;
     float2 *zh = reinterpret_cast<float2 *>(wbase) + f * kZStride;        // this frame's exchange slot
-    float *prow = wbase + f * kPRow;                                      // P[0..131] after the exchange
-    float *frow = wbase + kFRowOff + f * 48;                              // ln(mel) in (slot, lane) order
+    float *prow = wbase + kPOff + f * kPRow;                              // P[0..128] + zero pad bins 129..131
+    float *frow = wbase + f * 48;                                         // ln(mel) in (slot, lane) order (after the exchange)
     float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloats;
-    const float2 *s_tw2 = reinterpret_cast<const float2 *>(s_tab + L::kTw2);
+    const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
     const float *s_cos = s_tab + L::kCos;
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         const int n4 = (L::kMelW + 16 * a.mel_wpitch) / 4;
         for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) *s_next = q_lo + WAVES;
+        if (j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
     }
     // first quad of this wave; its loads are in flight across the barrier
     unsigned quad = q_lo + wave;
@@ -187,9 +189,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const int st0 = s_start[j], st1 = s_start[16 + j], st2 = s_start[32 + j];  // first bin of this lane's three filters
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
-    float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512), resident
+    float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512): resident when the register budget allows (<= 3 waves per SIMD)
+    if (PREFETCH) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) twn[r] = s_twn[r * 16 + j];
+        for (int r = 0; r < 8; ++r) twn[r] = s_twn[r * 16 + j];
+    }
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
 
@@ -200,10 +204,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         next = __builtin_amdgcn_readfirstlane(next);
         ++n_done;
 
+        if (!PREFETCH && n_done > 1) load_quad<NE, EXACT>(a, quad, total, f, j, vin);
         float2 v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
-        if (next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
+        if (PREFETCH && next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
 
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
         fft16_reg(v);
@@ -219,7 +224,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         }
         wave_order();
 #pragma unroll
-        for (int r = 1; r < 16; ++r) u[r] = cmul(u[r], s_tw2[(r - 1) * 16 + j]);
+        for (int p = 0; p < 8; ++p) {  // two twiddles per ds_read_b128
+            const float4 w2 = s_tw2[p * 16 + j];
+            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+            if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        }
         fft16_reg(u);  // u[r] = Z[j + 16 r]
 
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
@@ -227,22 +236,21 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         float2 zcs[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
-        if (j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float esum = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float2 zk = u[r];
             // lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
             const float2 zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
-            const float2 w = twn[r];
+            const float2 w = PREFETCH ? twn[r] : s_twn[r * 16 + j];
             const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
             const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
             const float2 wd = cmul(w, d);
             const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // 2 X[k]
             const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // 2 conj X[256-k]
             const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
-            const float pa = hscale * (POW2 ? na : __builtin_amdgcn_sqrtf(na));
-            const float pb = hscale * (POW2 ? nb : __builtin_amdgcn_sqrtf(nb));
+            const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);  // unscaled; hscale is applied to the sums below
+            const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
             prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70)
             esum += pa + pb;
         }
@@ -250,11 +258,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             // lane 0's pair k = 0 produced X[0] and X[256]; X[128] = conj Z[128] is the one extra bin
             const float2 z = u[8];
             const float n = 4.f * (z.x * z.x + z.y * z.y);
-            const float p128 = hscale * (POW2 ? n : __builtin_amdgcn_sqrtf(n));
+            const float p128 = POW2 ? n : __builtin_amdgcn_sqrtf(n);
             prow[128] = p128;
             esum += p128;
         }
-        float energy = row16_sum(esum);
+        float energy = hscale * row16_sum(esum);
         energy = energy == 0.f ? kEpsF : energy;  // zero_handling, feature.rs:219
         wave_order();
 
@@ -269,6 +277,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             m1 = mel_slot_loop(w4 + a.mel_q4[0], prow + st1, a.mel_q4[1]);
             m2 = mel_slot_loop(w4 + a.mel_q4[0] + a.mel_q4[1], prow + st2, a.mel_q4[2]);
         }
+        m0 *= hscale;
+        m1 *= hscale;
+        m2 *= hscale;
         frow[j] = fast_ln(m0 == 0.f ? kEpsF : m0);
         frow[16 + j] = fast_ln(m1 == 0.f ? kEpsF : m1);
         frow[32 + j] = fast_ln(m2 == 0.f ? kEpsF : m2);
@@ -277,15 +288,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 48-entry row ----
         float acc = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float4 lq[6], cq[6];
+        for (int h = 0; h < 2; ++h) {  // NQ float4s of the (slot, lane)-ordered row carry filters; two batches of fetches
+            constexpr int HB = NQ / 2;
+            float4 lq[HB], cq[HB];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (6 * h + i)]);
-                cq[i] = c4[6 * h + i];
+            for (int i = 0; i < HB; ++i) {
+                lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (HB * h + i)]);
+                cq[i] = c4[HB * h + i];
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < HB; ++i) {
                 acc = fmaf(lq[i].x, cq[i].x, acc);
                 acc = fmaf(lq[i].y, cq[i].y, acc);
                 acc = fmaf(lq[i].z, cq[i].z, acc);
@@ -343,25 +355,25 @@ hipError_t launch_w(const Fast512Args &a, hipStream_t stream, int num_cus, Launc
     };
     const bool pow2 = a.spectrum_exponent == 2;
     const bool b421 = a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1;
-    if (a.flen == 320 && !pow2 && b421) return go(ss_mfcc_c256<10, true, false, WAVES, true>, "ss_mfcc_c256<10,exact,bank421>");
+    if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10>, "ss_mfcc_c256<10,exact,bank421>");
     if (a.flen == 320) {
-        return pow2 ? go(ss_mfcc_c256<10, true, true, WAVES, false>, "ss_mfcc_c256<10,exact,pow2>")
-                    : go(ss_mfcc_c256<10, true, false, WAVES, false>, "ss_mfcc_c256<10,exact>");
+        return pow2 ? go(ss_mfcc_c256<10, true, true, WAVES, false, 12>, "ss_mfcc_c256<10,exact,pow2>")
+                    : go(ss_mfcc_c256<10, true, false, WAVES, false, 12>, "ss_mfcc_c256<10,exact>");
     }
     if (a.flen <= 320) {
-        return pow2 ? go(ss_mfcc_c256<10, false, true, WAVES, false>, "ss_mfcc_c256<10,pow2>")
-                    : go(ss_mfcc_c256<10, false, false, WAVES, false>, "ss_mfcc_c256<10>");
+        return pow2 ? go(ss_mfcc_c256<10, false, true, WAVES, false, 12>, "ss_mfcc_c256<10,pow2>")
+                    : go(ss_mfcc_c256<10, false, false, WAVES, false, 12>, "ss_mfcc_c256<10>");
     }
-    return pow2 ? go(ss_mfcc_c256<16, false, true, WAVES, false>, "ss_mfcc_c256<16,pow2>")
-                : go(ss_mfcc_c256<16, false, false, WAVES, false>, "ss_mfcc_c256<16>");
+    return pow2 ? go(ss_mfcc_c256<16, false, true, WAVES, false, 12>, "ss_mfcc_c256<16,pow2>")
+                : go(ss_mfcc_c256<16, false, false, WAVES, false, 12>, "ss_mfcc_c256<16>");
 }
 
 }  // namespace
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
+    // 12 waves per CU (3 per SIMD, <= 168 VGPRs, 138 KB of LDS): measured equal to 14 and 16 and 8 % faster than 8
     static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
-    if (w && std::atoi(w) == 16) return launch_w<16>(a, stream, num_cus, info);
     if (w && std::atoi(w) == 8) return launch_w<8>(a, stream, num_cus, info);
     return launch_w<12>(a, stream, num_cus, info);
 }
