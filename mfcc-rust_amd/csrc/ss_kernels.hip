@@ -29,6 +29,14 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ int phys(int i) { return i + (i >> 4); }
 
+// ln(x) from v_log_f32 (log2) with the denormal pre-scale the library form uses; ~1 ulp of log2.
+__device__ __forceinline__ float fast_ln(float x)
+{
+    const bool tiny = x < 1.17549435e-38f;
+    const float l = __builtin_amdgcn_logf(tiny ? x * 4294967296.f : x);
+    return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
+}
+
 // One Stockham pass of radix R with sub-transform length NS already done, on a frame of C points
 // held 16 per thread.  `j` is the thread index within the frame (TPF = C/16 threads).
 // Loads happen before the barrier-separated stores, so the pass works in place.
@@ -132,8 +140,8 @@ __device__ __forceinline__ float untangle_row(const float2 *zbuf, float *prow, f
             }
         } else {
             // processing.rs:168 sqrt(re^2 + im^2), :180 * (1/N)
-            const float ma = sqrtf(xa.x * xa.x + xa.y * xa.y);
-            const float mb = sqrtf(xb.x * xb.x + xb.y * xb.y);
+            const float ma = __builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y);
+            const float mb = __builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y);
             pa = a.spectrum_exponent == 2 ? a.scale * (ma * ma) : a.scale * ma;
             pb = a.spectrum_exponent == 2 ? a.scale * (mb * mb) : a.scale * mb;
         }
@@ -187,8 +195,9 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
         for (unsigned long long g = blockIdx.x; g < groups; g += gridDim.x) {
             const unsigned long long gf = g * G::FPB + slot;
             const bool active = gf < total;
-            const unsigned clip = active ? static_cast<unsigned>(gf / a.n_frames) : 0u;
-            const unsigned t = active ? static_cast<unsigned>(gf - static_cast<unsigned long long>(clip) * a.n_frames) : 0u;
+            const unsigned gf32 = static_cast<unsigned>(gf);  // launch_one rejects batches with >= 2^32 frames
+            const unsigned clip = active ? gf32 / a.n_frames : 0u;
+            const unsigned t = active ? gf32 - clip * a.n_frames : 0u;
             const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
             // stack_frames (processing.rs:65-129, contract framing) + zero pad to N (:147-156)
             const unsigned base = a.frame_mode == FRAME_NORMAL ? t * a.step : 0u;
@@ -229,8 +238,10 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
             } else {
                 // feature.rs:216-219: frame energy + zero handling (deterministic serial sum)
                 float energy = 0.0f;
-                for (int i = 0; i < G::TPF; ++i) energy += red[i];
-                energy = energy == 0.0f ? kEps : energy;
+                if (j == 0) {  // only the thread that owns coefficient 0 / the energy output needs it
+                    for (int i = 0; i < G::TPF; ++i) energy += red[i];
+                    energy = energy == 0.0f ? kEps : energy;
+                }
                 // feature.rs:229-230 banded; zero handling
                 for (int m = j; m < M; m += G::TPF) {
                     float s = mel_dot(prow, a, m);
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                     if (a.out_kind == OUT_MFE) {
                         if (active) a.out0[gf * M + m] = s;
                     } else {
-                        frow[m] = logf(s);  // feature.rs:105
+                        frow[m] = fast_ln(s);  // feature.rs:105
                     }
                 }
                 if (a.out_kind == OUT_MFE) {
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                         float s = 0.0f;
                         for (int m = 0; m < M; ++m) s = fmaf(frow[m], row[m], s);
                         float o;
-                        if (c == 0) o = a.dc_elimination ? logf(energy) : s * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                        if (c == 0) o = a.dc_elimination ? fast_ln(energy) : s * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
                         else o = s * a.dct_scale_k;
                         if (active) a.out0[gf * Cc + c] = o;
                     }
@@ -345,6 +356,7 @@ hipError_t launch_one(const FrontArgs &a, hipStream_t stream, int num_cus, Launc
     if (a.out_kind == OUT_MEL || a.out_kind == OUT_STFT) work = a.batch;
     else work = (static_cast<unsigned long long>(a.batch) * a.n_frames + G::FPB - 1) / G::FPB;
     if (work == 0) return hipSuccess;
+    if (static_cast<unsigned long long>(a.batch) * a.n_frames >= 0xffffffffull) return hipErrorInvalidValue;
     const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * 8;
     const unsigned grid = static_cast<unsigned>(work < cap ? work : cap);
     if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kBlock), lds};
