@@ -258,14 +258,38 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                     __syncthreads();
                     // feature.rs:120-146: DCT-II (first n_ceps outputs), scaling, column-0 replacement
                     const int Cc = static_cast<int>(a.n_ceps);
-                    for (int c = j; c < Cc; c += G::TPF) {
-                        const float *row = a.dct + c * M;
+                    const int parts = G::TPF / Cc;  // threads per coefficient (uniform)
+                    if (parts >= 2) {
+                        // wide frames (many threads, long filter rows): split every coefficient's sum over `parts`
+                        // threads, then combine the partials in fixed order (deterministic)
+                        const int c = j % Cc, part = j / Cc;
+                        const int ms = (M + parts - 1) / parts;
                         float s = 0.0f;
-                        for (int m = 0; m < M; ++m) s = fmaf(frow[m], row[m], s);
-                        float o;
-                        if (c == 0) o = a.dc_elimination ? fast_ln(energy) : s * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-                        else o = s * a.dct_scale_k;
-                        if (active) a.out0[gf * Cc + c] = o;
+                        if (part < parts) {
+                            const float *row = a.dct + c * M;
+                            const int m1 = min(M, (part + 1) * ms);
+                            for (int m = part * ms; m < m1; ++m) s = fmaf(frow[m], row[m], s);
+                            red[j] = s;
+                        }
+                        __syncthreads();
+                        if (j < Cc) {
+                            float tot = 0.0f;
+                            for (int p = 0; p < parts; ++p) tot += red[p * Cc + j];
+                            float o;
+                            if (j == 0) o = a.dc_elimination ? fast_ln(energy) : tot * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                            else o = tot * a.dct_scale_k;
+                            if (active) a.out0[gf * Cc + j] = o;
+                        }
+                    } else {
+                        for (int c = j; c < Cc; c += G::TPF) {
+                            const float *row = a.dct + c * M;
+                            float s = 0.0f;
+                            for (int m = 0; m < M; ++m) s = fmaf(frow[m], row[m], s);
+                            float o;
+                            if (c == 0) o = a.dc_elimination ? fast_ln(energy) : s * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                            else o = s * a.dct_scale_k;
+                            if (active) a.out0[gf * Cc + c] = o;
+                        }
                     }
                 }
             }
