@@ -91,7 +91,7 @@ def load_traffic(kernel_name, workload):
         with open(path) as f:
             d = json.load(f)
         e = d.get(workload)
-        if e and e.get("kernel") == kernel_name:
+        if e and kernel_name.split("<")[0] in e.get("kernel_full", ""):
             return e.get("hbm_bytes_per_launch")
     except Exception:
         pass

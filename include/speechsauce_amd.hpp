@@ -1,0 +1,156 @@
+// speechsauce_amd.hpp -- header-only C++ mirror of the reference crate's Rust API over the C ABI
+// (speechsauce_amd.h).  Same names, argument meaning and error behaviour as the reference:
+//   speechsauce::config::{SpeechConfigBuilder, SpeechConfig}   (speechsauce/src/config.rs:10-190)
+//   speechsauce::feature::{mfcc, mfe, mel_spectrogram1, mel_spectrogram2}  (feature.rs:99-233)
+//   speechsauce::processing::preemphasis                        (processing.rs:31-53)
+// Where the reference panics, these throw speechsauce::Error carrying the ss_status.
+// Arrays are plain row-major std::vector<float> plus shapes (the reference returns ndarray::ArrayN<f32>).
+#pragma once
+
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "speechsauce_amd.h"
+
+namespace speechsauce {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(int status)
+{
+    if (status != SS_OK) {
+        const char *d = ss_last_error_string();
+        throw Error(status, (d && *d) ? d : ss_status_string(status));
+    }
+}
+
+// 2-D / 3-D owning arrays, row-major
+struct Array2 {
+    std::size_t rows = 0, cols = 0;
+    std::vector<float> data;
+    float &operator()(std::size_t r, std::size_t c) { return data[r * cols + c]; }
+    float operator()(std::size_t r, std::size_t c) const { return data[r * cols + c]; }
+};
+struct Array3 {
+    std::size_t d0 = 0, d1 = 0, d2 = 0;
+    std::vector<float> data;
+};
+
+class SpeechConfig;
+
+// config.rs:10-97
+class SpeechConfigBuilder {
+public:
+    explicit SpeechConfigBuilder(std::size_t sample_rate) { check(ss_params_default(&p_, static_cast<uint32_t>(sample_rate))); }
+    SpeechConfigBuilder &high_freq(float v) { p_.high_frequency = v; return *this; }
+    SpeechConfigBuilder &low_freq(float v) { p_.low_frequency = v; return *this; }
+    SpeechConfigBuilder &dc_elimination(bool v) { p_.dc_elimination = v; return *this; }
+    SpeechConfigBuilder &num_cepstral(std::size_t v) { p_.num_cepstral = static_cast<uint32_t>(v); return *this; }
+    SpeechConfigBuilder &frame_stride(float v) { p_.frame_stride = v; return *this; }
+    SpeechConfigBuilder &frame_length(float v) { p_.frame_length = v; return *this; }
+    SpeechConfigBuilder &fft_points(std::size_t v) { p_.fft_points = static_cast<uint32_t>(v); return *this; }
+    // not settable in the reference builder (config.rs:49-82 has no num_filters setter); offered here
+    SpeechConfigBuilder &num_filters(std::size_t v) { p_.num_filters = static_cast<uint32_t>(v); return *this; }
+    // switches of include/speechsauce_amd.h (reference mode when untouched)
+    ss_params &params() { return p_; }
+    inline SpeechConfig build() const;
+
+private:
+    ss_params p_{};
+};
+
+// config.rs:99-190.  Immutable after creation: unlike the reference there is no STFT carry-over state.
+class SpeechConfig {
+public:
+    // SpeechConfig::new, config.rs:140-150
+    SpeechConfig(std::size_t sample_rate, std::size_t fft_points, float frame_length, float frame_stride, std::size_t num_cepstral,
+                 std::size_t num_filters, float low_frequency, float high_frequency, bool dc_elimination)
+    {
+        check(ss_params_default(&p_, static_cast<uint32_t>(sample_rate)));
+        p_.fft_points = static_cast<uint32_t>(fft_points);
+        p_.frame_length = frame_length;
+        p_.frame_stride = frame_stride;
+        p_.num_cepstral = static_cast<uint32_t>(num_cepstral);
+        p_.num_filters = static_cast<uint32_t>(num_filters);
+        p_.low_frequency = low_frequency;
+        p_.high_frequency = high_frequency;
+        p_.dc_elimination = dc_elimination;
+        check(ss_config_create(&p_, &h_));
+    }
+    explicit SpeechConfig(const ss_params &p) : p_(p) { check(ss_config_create(&p_, &h_)); }
+    SpeechConfig() : SpeechConfig(SpeechConfigBuilder(16000).build()) {}  // Default, config.rs:133-137
+    SpeechConfig(SpeechConfig &&o) noexcept : p_(o.p_), h_(o.h_) { o.h_ = nullptr; }
+    SpeechConfig &operator=(SpeechConfig &&o) noexcept { std::swap(p_, o.p_); std::swap(h_, o.h_); return *this; }
+    SpeechConfig(const SpeechConfig &) = delete;
+    SpeechConfig &operator=(const SpeechConfig &) = delete;
+    ~SpeechConfig() { ss_config_destroy(h_); }
+
+    const ss_params &params() const { return p_; }
+    const ss_config *handle() const { return h_; }
+    std::size_t sample_rate() const { return p_.sample_rate; }
+    std::size_t window_size() const { return p_.fft_points; }
+    std::size_t freq_size() const { return p_.fft_points / 2 + 1; }
+    std::size_t num_cepstral() const { return p_.num_cepstral; }
+    std::size_t num_filters() const { return p_.num_filters; }
+
+private:
+    ss_params p_{};
+    ss_config *h_ = nullptr;
+};
+
+inline SpeechConfig SpeechConfigBuilder::build() const { return SpeechConfig(p_); }
+
+// feature.rs:99-148
+inline Array2 mfcc(const float *signal, std::size_t n, const SpeechConfig &cfg)
+{
+    std::size_t t = 0;
+    check(ss_num_frames(&cfg.params(), n, &t));
+    Array2 out{t, cfg.num_cepstral(), std::vector<float>(t * cfg.num_cepstral())};
+    check(ss_mfcc(cfg.handle(), signal, n, out.data.data()));
+    return out;
+}
+inline Array2 mfcc(const std::vector<float> &signal, const SpeechConfig &cfg) { return mfcc(signal.data(), signal.size(), cfg); }
+
+// feature.rs:200-233: (features [T x M], frame energies [T])
+inline std::pair<Array2, std::vector<float>> mfe(const float *signal, std::size_t n, const SpeechConfig &cfg)
+{
+    std::size_t t = 0;
+    check(ss_num_frames(&cfg.params(), n, &t));
+    Array2 feat{t, cfg.num_filters(), std::vector<float>(t * cfg.num_filters())};
+    std::vector<float> energy(t);
+    check(ss_mfe(cfg.handle(), signal, n, feat.data.data(), energy.data()));
+    return {std::move(feat), std::move(energy)};
+}
+
+// feature.rs:163-174: signal [channels x n] -> [channels x num_filters x rows]
+inline Array3 mel_spectrogram2(const float *signal, std::size_t channels, std::size_t n, const SpeechConfig &cfg)
+{
+    std::size_t rows = 0, real_rows = 0;
+    check(ss_stft_rows(&cfg.params(), n, &rows, &real_rows));
+    Array3 out{channels, cfg.num_filters(), rows, std::vector<float>(channels * cfg.num_filters() * rows)};
+    check(ss_mel_spectrogram(cfg.handle(), signal, channels, n, out.data.data()));
+    return out;
+}
+
+// feature.rs:151-162 (one channel; the reference's axis mix-up is not reproduced)
+inline Array2 mel_spectrogram1(const float *signal, std::size_t n, const SpeechConfig &cfg)
+{
+    Array3 a = mel_spectrogram2(signal, 1, n, cfg);
+    return Array2{a.d1, a.d2, std::move(a.data)};
+}
+
+// processing.rs:31-53
+inline std::vector<float> preemphasis(const std::vector<float> &signal, long shift = 1, float cof = 0.98f)
+{
+    std::vector<float> y(signal.size());
+    check(ss_preemphasis(signal.data(), signal.size(), shift, cof, y.data()));
+    return y;
+}
+
+}  // namespace speechsauce

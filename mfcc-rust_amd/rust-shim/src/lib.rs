@@ -1,0 +1,240 @@
+//! `speechsauce-amd`: the hot-path API of the `speechsauce` crate on an MI355X.
+//!
+//! Signatures follow the reference one for one so a caller switches by changing the `use` line:
+//!   speechsauce::feature::mfcc(ArrayView1<f32>, &SpeechConfig) -> Array2<f32>          (feature.rs:99)
+//!   speechsauce::feature::mfe(ArrayView1<f32>, &SpeechConfig) -> (Array2, Array1)       (feature.rs:200)
+//!   speechsauce::feature::mel_spectrogram1 / mel_spectrogram2                           (feature.rs:151,163)
+//!   speechsauce::processing::preemphasis(Array1<f32>, isize, f32) -> Array1<f32>        (processing.rs:31)
+//!   speechsauce::config::{SpeechConfig, SpeechConfigBuilder}                            (config.rs:10-190)
+//! The host side here owns what the north-star assigns to Rust: ndarray I/O (contiguity, shapes,
+//! allocation of the outputs) and the framing parameters; every numeric step runs in the HIP kernels
+//! behind the `extern "C"` layer of include/speechsauce_amd.h.  Where the reference panics these
+//! functions panic too, with the library's error text (`expect`-style), so behaviour under bad input is
+//! unchanged for existing callers; `try_*` variants return `Result`.
+//!
+//! This file is shipped uncompiled (the build image has no Rust toolchain).
+
+use ndarray::{Array1, Array2, Array3, ArrayView1, ArrayView2};
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_long, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct SsParams {
+    pub struct_size: u32,
+    pub sample_rate: u32,
+    pub fft_points: u32,
+    pub frame_length: f32,
+    pub frame_stride: f32,
+    pub num_cepstral: u32,
+    pub num_filters: u32,
+    pub low_frequency: f32,
+    pub high_frequency: f32,
+    pub dc_elimination: i32,
+    pub framing: i32,
+    pub spectrum_exponent: i32,
+    pub dct_norm: i32,
+    pub dct2_gain: f32,
+    pub mfcc_window: i32,
+    pub preemph_coef: f32,
+    pub preemph_shift: i32,
+}
+
+#[repr(C)]
+pub struct SsConfig {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    fn ss_params_default(p: *mut SsParams, sample_rate: u32) -> c_int;
+    fn ss_config_create(p: *const SsParams, out: *mut *mut SsConfig) -> c_int;
+    fn ss_config_destroy(cfg: *mut SsConfig);
+    fn ss_num_frames(p: *const SsParams, n_samples: usize, n_frames: *mut usize) -> c_int;
+    fn ss_stft_rows(p: *const SsParams, n_samples: usize, rows: *mut usize, real_rows: *mut usize) -> c_int;
+    fn ss_mfcc(cfg: *const SsConfig, x: *const f32, n: usize, out: *mut f32) -> c_int;
+    fn ss_mfe(cfg: *const SsConfig, x: *const f32, n: usize, feat: *mut f32, energy: *mut f32) -> c_int;
+    fn ss_mel_spectrogram(cfg: *const SsConfig, x: *const f32, channels: usize, n: usize, out: *mut f32) -> c_int;
+    fn ss_mfcc_batch(cfg: *const SsConfig, x: *const f32, batch: usize, n: usize, ld: usize, out: *mut f32) -> c_int;
+    fn ss_mfcc_batch_device(cfg: *const SsConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
+                            stream: *mut c_void) -> c_int;
+    fn ss_preemphasis(x: *const f32, n: usize, shift: c_long, cof: f32, y: *mut f32) -> c_int;
+    fn ss_last_error_string() -> *const c_char;
+}
+
+#[derive(Debug)]
+pub struct Error {
+    pub status: i32,
+    pub detail: String,
+}
+
+fn check(status: c_int) -> Result<(), Error> {
+    if status == 0 {
+        return Ok(());
+    }
+    let detail = unsafe { CStr::from_ptr(ss_last_error_string()) }.to_string_lossy().into_owned();
+    Err(Error { status, detail })
+}
+
+/// config.rs:10-97
+pub struct SpeechConfigBuilder {
+    p: SsParams,
+}
+
+impl SpeechConfigBuilder {
+    pub fn new(sample_rate: usize) -> Self {
+        let mut p = std::mem::MaybeUninit::<SsParams>::uninit();
+        unsafe {
+            check(ss_params_default(p.as_mut_ptr(), sample_rate as u32)).expect("ss_params_default");
+            SpeechConfigBuilder { p: p.assume_init() }
+        }
+    }
+    pub fn high_freq(mut self, v: f32) -> Self { self.p.high_frequency = v; self }
+    pub fn low_freq(mut self, v: f32) -> Self { self.p.low_frequency = v; self }
+    pub fn dc_elimination(mut self, v: bool) -> Self { self.p.dc_elimination = v as i32; self }
+    pub fn num_cepstral(mut self, v: usize) -> Self { self.p.num_cepstral = v as u32; self }
+    pub fn frame_stride(mut self, v: f32) -> Self { self.p.frame_stride = v; self }
+    pub fn frame_length(mut self, v: f32) -> Self { self.p.frame_length = v; self }
+    pub fn fft_points(mut self, v: usize) -> Self { self.p.fft_points = v as u32; self }
+    pub fn build(self) -> SpeechConfig { SpeechConfig::from_params(self.p).expect("SpeechConfig::new") }
+}
+
+/// config.rs:99-190.  Immutable after creation (no STFT carry-over), hence Send + Sync.
+pub struct SpeechConfig {
+    pub sample_rate: usize,
+    pub window_size: usize,
+    pub frame_length: f32,
+    pub frame_stride: f32,
+    pub num_cepstral: usize,
+    pub num_filters: usize,
+    pub low_frequency: f32,
+    pub high_frequency: f32,
+    pub freq_size: usize,
+    pub dc_elimination: bool,
+    params: SsParams,
+    handle: *mut SsConfig,
+}
+unsafe impl Send for SpeechConfig {}
+unsafe impl Sync for SpeechConfig {}
+
+impl SpeechConfig {
+    /// config.rs:140-150
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(sample_rate: usize, fft_points: usize, frame_length: f32, frame_stride: f32, num_cepstral: usize,
+               num_filters: usize, low_frequency: f32, high_frequency: f32, dc_elimination: bool) -> Self {
+        let mut b = SpeechConfigBuilder::new(sample_rate).p;
+        b.fft_points = fft_points as u32;
+        b.frame_length = frame_length;
+        b.frame_stride = frame_stride;
+        b.num_cepstral = num_cepstral as u32;
+        b.num_filters = num_filters as u32;
+        b.low_frequency = low_frequency;
+        b.high_frequency = high_frequency;
+        b.dc_elimination = dc_elimination as i32;
+        Self::from_params(b).expect("SpeechConfig::new")
+    }
+    pub fn from_params(p: SsParams) -> Result<Self, Error> {
+        let mut h: *mut SsConfig = std::ptr::null_mut();
+        check(unsafe { ss_config_create(&p, &mut h) })?;
+        Ok(SpeechConfig {
+            sample_rate: p.sample_rate as usize,
+            window_size: p.fft_points as usize,
+            frame_length: p.frame_length,
+            frame_stride: p.frame_stride,
+            num_cepstral: p.num_cepstral as usize,
+            num_filters: p.num_filters as usize,
+            low_frequency: p.low_frequency,
+            high_frequency: p.high_frequency,
+            freq_size: p.fft_points as usize / 2 + 1,
+            dc_elimination: p.dc_elimination != 0,
+            params: p,
+            handle: h,
+        })
+    }
+    pub fn builder() -> SpeechConfigBuilder { SpeechConfigBuilder::new(16000) }
+}
+impl Default for SpeechConfig {
+    fn default() -> Self { SpeechConfigBuilder::new(16000).build() }
+}
+impl Drop for SpeechConfig {
+    fn drop(&mut self) { unsafe { ss_config_destroy(self.handle) } }
+}
+
+fn contiguous(signal: ArrayView1<f32>) -> std::borrow::Cow<[f32]> {
+    match signal.as_slice() {
+        Some(s) => std::borrow::Cow::Borrowed(s),
+        None => std::borrow::Cow::Owned(signal.to_vec()),  // the reference accepts any stride (as_array())
+    }
+}
+
+/// feature.rs:99-148
+pub fn try_mfcc(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+    let x = contiguous(signal);
+    let mut t = 0usize;
+    check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
+    let mut out = Array2::<f32>::zeros((t, cfg.num_cepstral));
+    check(unsafe { ss_mfcc(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
+    Ok(out)
+}
+pub fn mfcc(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_mfcc(signal, cfg).expect("mfcc") }
+
+/// feature.rs:200-233
+pub fn try_mfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<(Array2<f32>, Array1<f32>), Error> {
+    let x = contiguous(signal);
+    let mut t = 0usize;
+    check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
+    let mut feat = Array2::<f32>::zeros((t, cfg.num_filters));
+    let mut en = Array1::<f32>::zeros(t);
+    check(unsafe { ss_mfe(cfg.handle, x.as_ptr(), x.len(), feat.as_mut_ptr(), en.as_mut_ptr()) })?;
+    Ok((feat, en))
+}
+pub fn mfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> (Array2<f32>, Array1<f32>) { try_mfe(signal, cfg).expect("mfe") }
+
+/// feature.rs:163-174: [channels, samples] -> [channels, n_mels, rows]; rows need contiguous storage like
+/// the reference's `as_slice().expect(..)` (functions.rs:104)
+pub fn try_mel_spectrogram2(signal: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<f32>, Error> {
+    let owned = signal.as_standard_layout();
+    let (ch, n) = owned.dim();
+    let (mut rows, mut real) = (0usize, 0usize);
+    check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut real) })?;
+    let mut out = Array3::<f32>::zeros((ch, cfg.num_filters, rows));
+    check(unsafe { ss_mel_spectrogram(cfg.handle, owned.as_ptr(), ch, n, out.as_mut_ptr()) })?;
+    Ok(out)
+}
+pub fn mel_spectrogram2(signal: ArrayView2<f32>, cfg: &SpeechConfig) -> Array3<f32> {
+    try_mel_spectrogram2(signal, cfg).expect("mel_spectrogram2")
+}
+/// feature.rs:151-162 (one channel)
+pub fn mel_spectrogram1(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> {
+    let x = contiguous(signal);
+    let v = ArrayView2::from_shape((1, x.len()), &x).expect("shape");
+    let out = mel_spectrogram2(v, cfg);
+    let (_, m, r) = out.dim();
+    out.into_shape((m, r)).expect("shape")
+}
+
+/// Batch form with no counterpart in the reference: [batch, samples] -> [batch, frames, n_cepstral] in one launch.
+pub fn try_mfcc_batch(signals: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<f32>, Error> {
+    let owned = signals.as_standard_layout();
+    let (b, n) = owned.dim();
+    let mut t = 0usize;
+    check(unsafe { ss_num_frames(&cfg.params, n, &mut t) })?;
+    let mut out = Array3::<f32>::zeros((b, t, cfg.num_cepstral));
+    check(unsafe { ss_mfcc_batch(cfg.handle, owned.as_ptr(), b, n, n, out.as_mut_ptr()) })?;
+    Ok(out)
+}
+
+/// Device-resident batch: raw device pointers + a hipStream_t, asynchronous.
+/// # Safety
+/// `d_x` / `d_out` must be device allocations of the right size on the device the config was created on.
+pub unsafe fn mfcc_batch_device(cfg: &SpeechConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
+                                stream: *mut c_void) -> Result<(), Error> {
+    check(ss_mfcc_batch_device(cfg.handle, d_x, batch, n, ld, d_out, stream))
+}
+
+/// processing.rs:31-53
+pub fn preemphasis(signal: Array1<f32>, shift: isize, cof: f32) -> Array1<f32> {
+    let x = signal.as_standard_layout();
+    let mut y = Array1::<f32>::zeros(x.len());
+    check(unsafe { ss_preemphasis(x.as_ptr(), x.len(), shift as c_long, cof, y.as_mut_ptr()) }).expect("preemphasis");
+    y
+}

@@ -167,3 +167,27 @@ def test_python_front_argument_rules():
     d = {k: v.default for k, v in sig.parameters.items()}
     assert (d["frame_length"], d["frame_stride"], d["num_cepstral"], d["num_filters"], d["fft_length"],
             d["low_frequency"], d["high_frequency"], d["dc_elimination"]) == (0.020, 0.01, 13, 40, 512, 0, None, True)
+
+
+def test_cpp_mirror_header_compiles_and_fails_loudly(tmp_path, sslib):
+    """include/speechsauce_amd.hpp (C++ mirror of the Rust API) builds against the library with plain g++;
+    without a device it throws speechsauce::Error(SS_ERR_HIP) instead of computing anything on the CPU."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src = tmp_path / "t.cpp"
+    src.write_text(
+        '#include "speechsauce_amd.hpp"\n'
+        "int main() {\n"
+        "  try { speechsauce::SpeechConfig cfg; std::vector<float> x(16000, 0.f);\n"
+        "        auto m = speechsauce::mfcc(x, cfg); return m.rows == 98 && m.cols == 13 ? 0 : 3; }\n"
+        "  catch (const speechsauce::Error &e) { return e.status == SS_ERR_HIP ? 10 : 4; }\n"
+        "}\n")
+    libdir = os.path.join(ROOT, "mfcc-rust_amd", "lib")
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lspeechsauce_amd",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    rc = subprocess.run([str(exe)]).returncode
+    assert rc == (0 if _has_gpu() else 10)

@@ -238,3 +238,136 @@ def test_strided_batch_ld(ss, oracle, sslib):
     p = oracle.make_params(**CFG1)
     for b in range(5):
         assert _rel(out[b].cpu().numpy(), oracle.mfcc(p, x[b, :16000])) <= RTOL
+
+
+# ---------------------------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/golden_v1.npz, generated by the numpy restatement)
+# ---------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg5"])
+def test_golden_fixtures_mfcc(ss, name):
+    from common import CONFIGS, N_SAMPLES, golden_signals, load_golden
+
+    g = load_golden()
+    kw = dict(CONFIGS[name])
+    sr = kw.pop("sample_rate")
+    pykw = dict(frame_length=kw.get("frame_length", 0.02), frame_stride=kw.get("frame_stride", 0.01),
+                num_cepstral=kw.get("num_cepstral", 13), num_filters=kw.get("num_filters", 40),
+                fft_length=kw.get("fft_points", 512), high_frequency=kw.get("high_frequency"))
+    for sname, x in golden_signals(N_SAMPLES[name], sr).items():
+        got = ss.mfcc(x, sr, **pykw)
+        assert _rel(got, g[f"{name}/{sname}/mfcc"]) <= RTOL, sname
+        feat, en = ss.mfe(x, sr, frame_length=pykw["frame_length"], frame_stride=pykw["frame_stride"],
+                          num_filters=pykw["num_filters"], fft_length=pykw["fft_length"], high_frequency=pykw["high_frequency"])
+        assert _rel(en, g[f"{name}/{sname}/energy"]) <= 1e-5
+        assert _rel(feat[[0, feat.shape[0] // 2, -1]], g[f"{name}/{sname}/feat_rows"]) <= 1e-5
+
+
+def test_golden_fixtures_mel(ss):
+    from common import golden_signals, load_golden
+
+    g = load_golden()
+    kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+    for sname, x in golden_signals(16000, 16000).items():
+        got = ss.mel_spectrogram(x, 16000, **kw)
+        assert _rel(got, g[f"cfg3/{sname}/mel"]) <= RTOL, sname
+
+
+def test_golden_switches(ss):
+    from common import golden_signals, load_golden
+
+    g = load_golden()
+    x = golden_signals(16000, 16000)["noise"]
+    for tag, sw in {"pow2": dict(spectrum_exponent=2), "ortho": dict(dct_norm="ortho"), "hann": dict(mfcc_window="hann"),
+                    "preemph": dict(preemph_coef=0.97), "nodc": dict(dc_elimination=False)}.items():
+        assert _rel(ss.mfcc(x, 16000, **sw), g[f"switch/{tag}"]) <= RTOL, tag
+    assert np.abs(ss.mfcc(x, 16000, framing="literal") - g["switch/literal"]).max() <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE.json's full batch sizes
+# ---------------------------------------------------------------------------------------------------------
+
+def test_cfg2_full_batch_properties(ss, sslib):
+    import torch
+    from speechsauce_amd import _lib
+
+    x = torch.from_numpy(_signal(21, (1024, 16000))).cuda()
+    a = ss.mfcc_batch(x, 16000)
+    b = ss.mfcc_batch(x, 16000)
+    assert torch.equal(a, b)                                   # deterministic: no atomics, fixed reduction orders
+    perm = torch.randperm(1024, device="cuda")
+    assert torch.equal(ss.mfcc_batch(x[perm].contiguous(), 16000), a[perm])   # clips are independent units
+    one = ss.mfcc_batch(x[517:518].contiguous(), 16000)
+    assert torch.equal(one[0], a[517])                         # batch == single clip, bit for bit
+    assert torch.isfinite(a).all()
+    # |X|/N and the mel energies are homogeneous of degree 1: mfe(4x) = 4 mfe(x) exactly (power of two)
+    f1, e1 = ss.mfe_batch(x[:64].contiguous(), 16000)
+    f4, e4 = ss.mfe_batch((4.0 * x[:64]).contiguous(), 16000)
+    assert torch.equal(f4, 4.0 * f1) and torch.equal(e4, 4.0 * e1)
+    # Parseval on the squared spectrum: sum_k w_k |X[k]|^2 / N = sum_n x_n^2 over each (zero-padded) frame
+    cfg = _cfg(ss, sample_rate=16000, spectrum_exponent=2)
+    T = cfg.num_frames(16000)
+    P = torch.empty((8, T, 257), dtype=torch.float32, device="cuda")
+    xs = x[:8].contiguous()
+    _lib.check(sslib.ss_power_spectrum_batch_device(cfg.handle, xs.data_ptr(), 8, 16000, 16000, P.data_ptr(), None))
+    w = torch.full((257,), 2.0, device="cuda")
+    w[0] = w[256] = 1.0
+    lhs = (P * w).sum(-1)
+    frames = xs.unfold(1, 320, 160)[:, :T]
+    rhs = (frames.double() ** 2).sum(-1)
+    assert ((lhs.double() - rhs).abs() / rhs).max().item() < 1e-5
+
+
+def test_cfg3_full_batch_properties(ss):
+    import torch
+
+    x = torch.from_numpy(_signal(22, (1024, 16000))).cuda()
+    kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+    a = ss.mel_spectrogram(x, 16000, **kw)
+    assert a.shape == (1024, 128, 32)
+    assert torch.equal(a, ss.mel_spectrogram(x, 16000, **kw))
+    assert torch.equal(ss.mel_spectrogram(x[300], 16000, **kw), a[300])
+    assert (a[:, :, 29:] == 0).all() and (a >= 0).all() and torch.isfinite(a).all()
+    # |X|^2 is homogeneous of degree 2
+    assert torch.equal(ss.mel_spectrogram((2.0 * x[:32]).contiguous(), 16000, **kw), 4.0 * a[:32])
+
+
+def test_cfg5_full_batch(ss, oracle):
+    import torch
+
+    x = _signal(23, (512, 44100))
+    kw = dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096)
+    a = ss.mfcc_batch(torch.from_numpy(x).cuda(), 44100, **kw)
+    assert a.shape == (512, 39, 40) and torch.isfinite(a).all()
+    assert torch.equal(a, ss.mfcc_batch(torch.from_numpy(x).cuda(), 44100, **kw))
+    p = oracle.make_params(**CFG5)
+    for b in (0, 255, 511):
+        assert _rel(a[b].cpu().numpy(), oracle.mfcc(p, x[b])) <= RTOL
+
+
+def test_kernel_variants_agree(ss):
+    """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
+    the variant is chosen once per process from the environment)."""
+    import subprocess
+    import sys
+
+    code = ("import sys, numpy as np; sys.path.insert(0, 'mfcc-rust_amd'); import speechsauce_amd as ss;"
+            "x=(np.random.default_rng(5).standard_normal((37,16000))*0.1).astype(np.float32);"
+            "import torch; o=ss.mfcc_batch(torch.from_numpy(x).cuda(),16000).cpu().numpy();"
+            "np.save(sys.argv[1], o); print(ss._lib.lib().ss_last_kernel_name().decode())")
+    import os
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs, names = [], []
+    with tempfile.TemporaryDirectory() as td:
+        for env in ({}, {"SS_MFCC512_VARIANT": "mfma"}, {"SS_FORCE_GENERIC": "1"}):
+            path = os.path.join(td, f"o{len(outs)}.npy")
+            r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env={**os.environ, **env},
+                               capture_output=True, text=True, check=True)
+            names.append(r.stdout.strip().splitlines()[-1])
+            outs.append(np.load(path))
+    assert names[0].startswith("ss_mfcc_c256<") and "mx" in names[1] and names[2].startswith("ss_front_generic")
+    for o in outs[1:]:
+        assert _rel(o, outs[0]) <= 2e-5
