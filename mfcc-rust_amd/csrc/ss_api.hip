@@ -31,6 +31,9 @@ struct ss_config {
     float *d_fast_tab = nullptr;
     ss::Fast512MTables fastm;
     float *d_fastm_tab = nullptr;
+    // fft_points = 2048 mel-spectrogram kernel tables (ss_mel2048.hip)
+    ss::Mel2048Tables mel2048;
+    float *d_mel2048_tab = nullptr;
 };
 
 namespace {
@@ -259,6 +262,30 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     a.out_kind = out_kind;
     a.out0 = out0;
     ss::LaunchInfo info{};
+    // fft_points = 2048 mel spectrogram: the wave-private kernel when its layout assumptions hold
+    static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
+    if (!force_generic && out_kind == ss::OUT_MEL && cfg->mel2048.ok && (a.hop % 2 == 0) && (ld % 2 == 0) &&
+        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        ss::Mel2048Args m{};
+        m.x = d_x;
+        m.ld = ld;
+        m.n_samples = a.n_samples;
+        m.batch = a.batch;
+        m.hop = a.hop;
+        m.n_pad = a.n_pad;
+        m.rows = a.rows;
+        m.real_rows = a.real_rows;
+        m.scale = a.scale;
+        m.tab = cfg->d_mel2048_tab;
+        m.mel_wpitch = cfg->mel2048.wpitch;
+        for (int s = 0; s < 4; ++s) m.mel_q4[s] = cfg->mel2048.q4[s];
+        m.n_filters = a.n_filters;
+        m.out = out0;
+        hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
+        if (e != hipSuccess) return hip_fail(e, "launch_mel_c1024");
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
     hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
     if (e != hipSuccess) return hip_fail(e, "launch_front_generic");
     g_last_kernel = info.kernel_name;
@@ -331,6 +358,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->fast.ok) {
         SS_UP(d_fast_tab, c->fast.tab);
     }
+    ss::build_mel2048(h, c->mel2048);
+    if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
     if (c->fastm.ok) {
         SS_UP(d_fastm_tab, c->fastm.tab);
@@ -345,7 +374,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

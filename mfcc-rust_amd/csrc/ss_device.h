@@ -115,4 +115,21 @@ struct Fast512MArgs {
 
 hipError_t launch_mfcc_c256_mx(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
+// Arguments of the fft_points = 2048 mel-spectrogram kernel (ss_mel2048.hip).
+struct Mel2048Args {
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples, batch;
+    uint32_t hop, n_pad, rows, real_rows;
+    float scale;  // wnorm (config.rs:178)
+    // one table block, copied verbatim into LDS (layout: ss::mel2048_layout in ss_internal.h)
+    const float *tab;
+    int32_t mel_wpitch;  // floats per lane weight row
+    int32_t mel_q4[4];   // taps / 4 per slot
+    uint32_t n_filters;
+    float *out;  // [batch][n_filters][rows]
+};
+
+hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 }  // namespace ss

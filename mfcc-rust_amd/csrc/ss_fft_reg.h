@@ -98,6 +98,52 @@ __device__ __forceinline__ void fft_reg<16>(float2 *v)
     for (int i = 0; i < 16; ++i) v[i] = y[i];
 }
 
+
+// 32-point DFT: n = n1 + 4 n2 (n1 < 4, n2 < 8), k = 8 k1 + k2: W32^(nk) = W4^(n1 k1) W32^(n1 k2) W8^(n2 k2)
+template <>
+__device__ __forceinline__ void fft_reg<32>(float2 *v)
+{
+    // step A: for each n1 an 8-point DFT over n2 (elements n1 + 4 n2) -> Y[n1][k2] written back to v[n1 + 4 k2]
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+        float2 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v[n1 + 4 * i];
+        fft_reg<8>(t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[n1 + 4 * i] = t[i];
+    }
+    // step B: Y[n1][k2] *= W32^(n1 k2)
+    constexpr float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                              0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+    for (int n1 = 1; n1 < 4; ++n1) {
+#pragma unroll
+        for (int k2 = 1; k2 < 8; ++k2) {
+            const int m = n1 * k2;  // 1..21: W32^m = cos(2 pi m / 32) - i sin(2 pi m / 32)
+            // cos(m) for m in 0..8 is c32[m]; use symmetries for m up to 21
+            float cr, sr;
+            if (m <= 8) { cr = m == 8 ? 0.0f : c32[m]; sr = m == 8 ? 1.0f : c32[8 - m]; }
+            else if (m <= 16) { cr = m == 16 ? -1.0f : -c32[16 - m]; sr = m == 16 ? 0.0f : c32[m - 8]; }
+            else { cr = -c32[m - 16]; sr = -c32[24 - m]; }
+            v[n1 + 4 * k2] = cmul(v[n1 + 4 * k2], make_float2(cr, -sr));
+        }
+    }
+    // step C: for each k2 a 4-point DFT over n1 (elements 4 k2 + n1) -> X[8 k1 + k2]
+    float2 y[32];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+        float2 a = v[4 * k2], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
+        fft4(a, b, c, d);
+        y[k2] = a;
+        y[8 + k2] = b;
+        y[16 + k2] = c;
+        y[24 + k2] = d;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = y[i];
+}
+
 // 16-point DFT on a 16-element register array
 __device__ __forceinline__ void fft16_reg(float2 (&v)[16]) { fft_reg<16>(v); }
 

@@ -344,6 +344,65 @@ void build_fast512m(const HostTables &t, Fast512MTables &f)
     f.ok = true;
 }
 
+
+void build_mel2048(const HostTables &t, Mel2048Tables &f)
+{
+    namespace L = mel2048_layout;
+    f = Mel2048Tables{};
+    const size_t M = t.params.num_filters;
+    if (t.d.n_fft != 2048 || !t.d.stft_ok || M > 128) return;
+    if (t.bank.last_bin > 513) return;  // the kernel keeps P bins 0..512 (the bank ends at (F+1)/2 when high = sr/2)
+    constexpr int32_t kRow = 516;       // P bins a tap may touch: 0..512 plus three zero pad bins
+    std::vector<int32_t> order(M);
+    for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
+    int32_t maxlen[4] = {0, 0, 0, 0};
+    for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], t.bank.len[order[q]]);
+    for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
+    if (f.wpitch == 0) f.wpitch = 4;
+    if (f.wpitch > 256) return;
+    f.tab.assign(static_cast<size_t>(L::kMelW) + 32 * f.wpitch, 0.0f);
+    const double pi = 3.14159265358979323846;
+    for (int r = 1; r < 32; ++r)
+        for (int j = 0; j < 32; ++j) {  // exp(-2 pi i j r / 1024) = tw_c[j r]
+            const int p = (r - 1) / 2, half = (r - 1) % 2;
+            f.tab[L::kTw2 + (p * 32 + j) * 4 + 2 * half] = t.tw_c[2 * (j * r)];
+            f.tab[L::kTw2 + (p * 32 + j) * 4 + 2 * half + 1] = t.tw_c[2 * (j * r) + 1];
+        }
+    for (int r = 0; r < 16; ++r)
+        for (int j = 0; j < 32; ++j) {  // exp(-2 pi i (j + 32 r) / 2048) = tw_n[j + 32 r]
+            f.tab[L::kTwn + (r * 32 + j) * 2] = t.tw_n[2 * (j + 32 * r)];
+            f.tab[L::kTwn + (r * 32 + j) * 2 + 1] = t.tw_n[2 * (j + 32 * r) + 1];
+        }
+    (void)pi;
+    for (int i = 0; i < 2048; ++i) f.tab[L::kWin + i] = t.window_stft[i];
+    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
+    int32_t off = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int32_t span = 4 * f.q4[s];
+        for (int j = 0; j < 32; ++j) {
+            const size_t q = static_cast<size_t>(s) * 32 + j;
+            start[q] = 0;
+            filt[q] = -1;
+            if (q >= M) continue;
+            const int32_t m = order[q];
+            filt[q] = m;
+            int32_t st = t.bank.start[m];
+            const int32_t len = t.bank.len[m];
+            int32_t shift = 0;
+            if (st + span > kRow) shift = st + span - kRow;
+            st -= shift;
+            start[q] = st;
+            for (int32_t i = 0; i < len; ++i)
+                f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
+        }
+        off += span;
+    }
+    f.ok = true;
+}
+
 }  // namespace ss
 
 // ---- host-only C ABI entry points ------------------------------------------------------------

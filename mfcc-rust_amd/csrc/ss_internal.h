@@ -95,4 +95,23 @@ struct Fast512MTables {
 };
 void build_fast512m(const HostTables &t, Fast512MTables &f);
 
+// Table block of the fft_points = 2048 mel-spectrogram kernel (ss_mel2048.hip), float offsets.
+namespace mel2048_layout {
+constexpr int kTw2 = 0;                  // [16][32] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 1024)
+constexpr int kTwn = kTw2 + 16 * 128;    // [16][32] float2: exp(-2 pi i (j + 32 r) / 2048)
+constexpr int kWin = kTwn + 16 * 64;     // [1024] float2: Vorbis window pairs (w[2n], w[2n+1])
+constexpr int kStart = kWin + 2048;      // [4][32] int32: first P bin of the filter owned by (slot, lane)
+constexpr int kFilt = kStart + 128;      // [4][32] int32: filter index of (slot, lane), -1 if none
+constexpr int kMelW = kFilt + 128;       // [32][pitch]
+constexpr int kPRow = 520;               // floats per P row: bins 0..512 + zero pad bins
+}  // namespace mel2048_layout
+
+struct Mel2048Tables {
+    bool ok = false;
+    std::vector<float> tab;
+    int32_t q4[4] = {0, 0, 0, 0};
+    int32_t wpitch = 0;
+};
+void build_mel2048(const HostTables &t, Mel2048Tables &f);
+
 }  // namespace ss

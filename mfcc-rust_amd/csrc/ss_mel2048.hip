@@ -1,0 +1,224 @@
+// ss_mel_c1024: fused mel spectrogram for fft_points = 2048 (C = 1024 packed complex points) on gfx950 --
+// the STFT branch of the reference: frame_analysis / stft2 (functions.rs:86-170) -> |X|^2 (feature.rs:164) ->
+// mel bank (feature.rs:173), output [clip][n_mels][rows].
+//
+// Same structure as the 512-point MFCC kernel (ss_mfcc512.hip), one size up:
+//   * 32 lanes own a frame, 32 complex points per lane; a wave carries 2 frames; an 8-wave workgroup carries the
+//     16 frames of half a 32-row output tile of one clip.
+//   * window (Vorbis, config.rs:151-160) applied on load; the window covers the last W samples ending at chunk
+//     r + n_pad (zero outside the clip: zero initial state per clip), functions.rs:137-151.
+//   * 1024-point FFT = two radix-32 register butterflies with ONE transposing exchange through wave-private LDS,
+//     one frame at a time (ds_write_b64 scatter to 66*(n1>>1) + 2*k1 + (n1&1), 16 ds_read_b128 back; both
+//     conflict-free); no workgroup barrier inside a frame.
+//   * untangle with ds_bpermute_b32 (partner = lane 32-j, register 31-r); only bins 0..512 are produced: the mel
+//     bank ends at bin (F+1)/2 (feature.rs:69-70) and this path has no frame energy.
+//   * (|X| wnorm)^2 (functions.rs:166-169, feature.rs:164) -> P row in LDS -> banded mel reduction, 4 filters per lane.
+//   * results go to a [n_mels][33] LDS tile; after the tile's 32 rows the workgroup stores it row-contiguously
+//     (the [n_mels][rows] block of a clip is contiguous in HBM).
+// Rows >= real_rows (the trailing n_pad rows the reference never writes, functions.rs:121) come out as exact zeros.
+#include "ss_device.h"
+#include "ss_fft_reg.h"
+#include "ss_internal.h"
+
+namespace ss {
+
+namespace {
+
+namespace L = mel2048_layout;
+constexpr int kWavesM = 8;
+constexpr int kExSlots = 16 * 66;            // float2 per frame exchange region (8448 B = 33 bank rows)
+constexpr int kWaveFloatsM = kExSlots * 2 + 2 * L::kPRow;  // one exchange region + two P rows (zero pads persist)
+
+__device__ __forceinline__ void wave_order_m()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float bperm_m(int addr, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ float mel_slot(const float4 *w4, const float *p, int q4)
+{
+    float acc = 0.f;
+    for (int i = 0; i < q4; ++i) {
+        const float4 w = w4[i];
+        acc = fmaf(w.x, p[4 * i], acc);
+        acc = fmaf(w.y, p[4 * i + 1], acc);
+        acc = fmaf(w.z, p[4 * i + 2], acc);
+        acc = fmaf(w.w, p[4 * i + 3], acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int half = lane >> 5;  // frame within the wave
+    const int j = lane & 31;     // lane within the frame
+
+    // ---- LDS carve: per-wave regions | output tile | table block ----
+    float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsM;
+    float2 *ex = reinterpret_cast<float2 *>(wbase);                 // exchange region (one frame at a time)
+    float *prow = wbase + kExSlots * 2 + half * L::kPRow;           // P[0..512] + zero pad bins
+    float *tile = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;  // [n_filters][33]
+    float *s_tab = tile + ((a.n_filters * 33 + 3) & ~3u);
+    const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const float *s_melw = s_tab + L::kMelW;
+
+    {
+        const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
+        for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        for (int i = lane; i < 2 * L::kPRow; i += 64) wbase[kExSlots * 2 + i] = 0.f;  // zero pad bins stay zero
+    }
+    __syncthreads();
+    int st[4], fi[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st[s] = s_start[s * 32 + j];
+        fi[s] = s_filt[s * 32 + j];
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
+    const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
+    const int wb = 66 * (j >> 1) + (j & 1);                  // exchange write base (float2 units)
+    const float hs = 0.25f * a.scale * a.scale;              // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
+    const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
+    const int M = static_cast<int>(a.n_filters);
+    const long long n_samples = a.n_samples;
+
+    for (unsigned clip = blockIdx.x; clip < a.batch; clip += gridDim.x) {
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+        for (int r0 = 0; r0 < R; r0 += 32) {
+            const int rt = min(32, R - r0);
+            for (int pass = 0; pass < 2; ++pass) {
+                const int rl = pass * 16 + wave * 2 + half;  // row within the tile
+                const int r = r0 + rl;
+                const bool active = rl < rt && r < Rreal;
+                // functions.rs:137-151: window over the last W samples ending at chunk r + n_pad
+                const long long start = static_cast<long long>(r + a.n_pad + 1) * a.hop - 2048;
+                float2 v[32];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const int n = j + 32 * e;
+                    const long long idx = start + 2 * n;
+                    float2 s = make_float2(0.f, 0.f);
+                    if (active) {
+                        if (idx >= 0 && idx + 1 < n_samples) {
+                            s = *reinterpret_cast<const float2 *>(xc + idx);
+                        } else {
+                            if (idx >= 0 && idx < n_samples) s.x = xc[idx];
+                            if (idx + 1 >= 0 && idx + 1 < n_samples) s.y = xc[idx + 1];
+                        }
+                    }
+                    const float2 w = s_win[n];
+                    v[e] = make_float2(s.x * w.x, s.y * w.y);
+                }
+                // ---- 1024-point complex FFT: radix-32, transpose through LDS (one frame at a time), twiddle, radix-32 ----
+                fft_reg<32>(v);
+                float2 u[32];
+                if (half == 0) {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) ex[wb + 2 * k] = v[k];
+                    wave_order_m();
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(&ex[66 * p + 2 * j]);
+                        u[2 * p] = make_float2(t4.x, t4.y);
+                        u[2 * p + 1] = make_float2(t4.z, t4.w);
+                    }
+                }
+                wave_order_m();
+                if (half == 1) {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) ex[wb + 2 * k] = v[k];
+                    wave_order_m();
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(&ex[66 * p + 2 * j]);
+                        u[2 * p] = make_float2(t4.x, t4.y);
+                        u[2 * p + 1] = make_float2(t4.z, t4.w);
+                    }
+                }
+                wave_order_m();
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {  // two twiddles per ds_read_b128: W^(j(2p+1)), W^(j(2p+2))
+                    const float4 w2 = s_tw2[p * 32 + j];
+                    u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+                    if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+                }
+                fft_reg<32>(u);  // u[r] = Z[j + 32 r]
+
+                // ---- untangle the bins the bank can touch: k = j + 32 r, r < 16, and k = 512 ----
+                float2 zcs[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zcs[q] = make_float2(bperm_m(paddr, u[31 - q].x), bperm_m(paddr, u[31 - q].y));
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float2 zk = u[q];
+                    // lane 0 pairs with itself: Z[1024 - 32 q] = own register (32 - q) & 31
+                    const float2 zc = j == 0 ? u[(32 - q) & 31] : zcs[q];
+                    const float2 w = s_twn[q * 32 + j];
+                    const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+                    const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
+                    const float2 wd = cmul(w, d);
+                    const float xr = s.x + wd.y, xi = s.y - wd.x;  // 2 X[k]
+                    prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
+                }
+                if (j == 0) {
+                    const float2 z = u[16];  // X[512] = conj Z[512]
+                    prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
+                }
+                wave_order_m();
+                // ---- banded mel reduction (feature.rs:173), four filters per lane, into the transposed tile ----
+                if (rl < rt) {
+                    int off = 0;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float m = mel_slot(w4 + off, prow + st[s], a.mel_q4[s]);
+                        if (fi[s] >= 0) tile[fi[s] * 33 + rl] = m;
+                        off += a.mel_q4[s];
+                    }
+                }
+                wave_order_m();
+            }
+            __syncthreads();
+            {
+                float *dst = a.out + static_cast<unsigned long long>(clip) * M * R;
+                for (int i = tid; i < M * rt; i += kWavesM * 64) {
+                    const int m = i / rt, rl = i - m * rt;
+                    dst[static_cast<unsigned long long>(m) * R + r0 + rl] = tile[m * 33 + rl];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + ((static_cast<size_t>(a.n_filters) * 33 + 3) & ~static_cast<size_t>(3)) + L::kMelW +
+                        32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.batch == 0) return hipSuccess;
+    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
+    const unsigned grid = a.batch < cap ? a.batch : cap;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c1024), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    if (info) *info = LaunchInfo{"ss_mel_c1024", grid, static_cast<unsigned>(kWavesM * 64), lds};
+    hipLaunchKernelGGL(ss_mel_c1024, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace ss
