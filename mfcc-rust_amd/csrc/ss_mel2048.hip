@@ -93,7 +93,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const float hs = 0.25f * a.scale * a.scale;              // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
     const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
     const int M = static_cast<int>(a.n_filters);
-    const long long n_samples = a.n_samples;
 
     for (unsigned clip = blockIdx.x; clip < a.batch; clip += gridDim.x) {
         const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
@@ -104,23 +103,31 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 const int r = r0 + rl;
                 const bool active = rl < rt && r < Rreal;
                 // functions.rs:137-151: window over the last W samples ending at chunk r + n_pad
-                const long long start = static_cast<long long>(r + a.n_pad + 1) * a.hop - 2048;
+                const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
+                const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
                 float2 v[32];
+                if (inside) {
+                    // whole window inside the clip: 8-byte loads at constant offsets from one base
+                    const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) v[e] = src[32 * e];
+                } else {
+                    // clip edges (zero initial state, zero padding of the last chunk) and inactive rows
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int idx = start + 2 * (j + 32 * e);
+                        float2 s = make_float2(0.f, 0.f);
+                        if (active) {
+                            if (idx >= 0 && idx < static_cast<int>(a.n_samples)) s.x = xc[idx];
+                            if (idx + 1 >= 0 && idx + 1 < static_cast<int>(a.n_samples)) s.y = xc[idx + 1];
+                        }
+                        v[e] = s;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 32; ++e) {
-                    const int n = j + 32 * e;
-                    const long long idx = start + 2 * n;
-                    float2 s = make_float2(0.f, 0.f);
-                    if (active) {
-                        if (idx >= 0 && idx + 1 < n_samples) {
-                            s = *reinterpret_cast<const float2 *>(xc + idx);
-                        } else {
-                            if (idx >= 0 && idx < n_samples) s.x = xc[idx];
-                            if (idx + 1 >= 0 && idx + 1 < n_samples) s.y = xc[idx + 1];
-                        }
-                    }
-                    const float2 w = s_win[n];
-                    v[e] = make_float2(s.x * w.x, s.y * w.y);
+                    const float2 w = s_win[j + 32 * e];
+                    v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
                 }
                 // ---- 1024-point complex FFT: radix-32, transpose through LDS (one frame at a time), twiddle, radix-32 ----
                 fft_reg<32>(v);
@@ -158,20 +165,24 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 fft_reg<32>(u);  // u[r] = Z[j + 32 r]
 
                 // ---- untangle the bins the bank can touch: k = j + 32 r, r < 16, and k = 512 ----
-                float2 zcs[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) zcs[q] = make_float2(bperm_m(paddr, u[31 - q].x), bperm_m(paddr, u[31 - q].y));
+                for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
+                    float2 zcs[8];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float2 zk = u[q];
-                    // lane 0 pairs with itself: Z[1024 - 32 q] = own register (32 - q) & 31
-                    const float2 zc = j == 0 ? u[(32 - q) & 31] : zcs[q];
-                    const float2 w = s_twn[q * 32 + j];
-                    const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
-                    const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
-                    const float2 wd = cmul(w, d);
-                    const float xr = s.x + wd.y, xi = s.y - wd.x;  // 2 X[k]
-                    prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
+                    for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm_m(paddr, u[31 - (8 * hb + q)].x), bperm_m(paddr, u[31 - (8 * hb + q)].y));
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int q = 8 * hb + qq;
+                        const float2 zk = u[q];
+                        // lane 0 pairs with itself: Z[1024 - 32 q] = own register (32 - q) & 31
+                        const float2 zc = j == 0 ? u[(32 - q) & 31] : zcs[qq];
+                        const float2 w = s_twn[q * 32 + j];
+                        const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+                        const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
+                        const float2 wd = cmul(w, d);
+                        const float xr = s.x + wd.y, xi = s.y - wd.x;  // 2 X[k]
+                        prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
+                    }
                 }
                 if (j == 0) {
                     const float2 z = u[16];  // X[512] = conj Z[512]
