@@ -3,8 +3,8 @@
 // mel bank (feature.rs:173), output [clip][n_mels][rows].
 //
 // Same structure as the 512-point MFCC kernel (ss_mfcc512.hip), one size up:
-//   * 32 lanes own a frame, 32 complex points per lane; a wave carries 2 frames; an 8-wave workgroup carries the
-//     16 frames of half a 32-row output tile of one clip.
+//   * 32 lanes own a frame, 32 complex points per lane; a wave carries 2 frames = two consecutive output rows of
+//     one clip.  One persistent 8-wave workgroup per CU; waves pull (clip, row pair) units from an LDS counter.
 //   * window (Vorbis, config.rs:151-160) applied on load; the window covers the last W samples ending at chunk
 //     r + n_pad (zero outside the clip: zero initial state per clip), functions.rs:137-151.
 //   * 1024-point FFT = two radix-32 register butterflies with ONE transposing exchange through wave-private LDS,
@@ -13,8 +13,10 @@
 //   * untangle with ds_bpermute_b32 (partner = lane 32-j, register 31-r); only bins 0..512 are produced: the mel
 //     bank ends at bin (F+1)/2 (feature.rs:69-70) and this path has no frame energy.
 //   * (|X| wnorm)^2 (functions.rs:166-169, feature.rs:164) -> P row in LDS -> banded mel reduction, 4 filters per lane.
-//   * results go to a [n_mels][33] LDS tile; after the tile's 32 rows the workgroup stores it row-contiguously
-//     (the [n_mels][rows] block of a clip is contiguous in HBM).
+//   * each lane stores its four mel values straight to out[clip][m][r]: the wave's two rows are adjacent words, so
+//     the stores are 8-byte pairs; the other rows of a line come from other waves and merge in L2.  (A workgroup-wide
+//     transposing tile with coalesced row stores measured 20 % slower: its two barriers per clip cost more than the
+//     partial-line stores.)  No barrier anywhere in the main loop.
 // Rows >= real_rows (the trailing n_pad rows the reference never writes, functions.rs:121) come out as exact zeros.
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -62,23 +64,27 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const int half = lane >> 5;  // frame within the wave
     const int j = lane & 31;     // lane within the frame
 
-    // ---- LDS carve: per-wave regions | output tile | table block ----
+    // ---- LDS carve: per-wave regions | table block | unit counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsM;
     float2 *ex = reinterpret_cast<float2 *>(wbase);                 // exchange region (one frame at a time)
     float *prow = wbase + kExSlots * 2 + half * L::kPRow;           // P[0..512] + zero pad bins
-    float *tile = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;  // [n_filters][33]
-    float *s_tab = tile + ((a.n_filters * 33 + 3) & ~3u);
+    float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
     const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_melw = s_tab + L::kMelW;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
 
     {
         const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         for (int i = lane; i < 2 * L::kPRow; i += 64) wbase[kExSlots * 2 + i] = 0.f;  // zero pad bins stay zero
+        if (tid == 0) {
+            const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+            *s_next = static_cast<unsigned>(units0 * blockIdx.x / gridDim.x) + kWavesM;
+        }
     }
     __syncthreads();
     int st[4], fi[4];
@@ -94,14 +100,24 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
     const int M = static_cast<int>(a.n_filters);
 
-    for (unsigned clip = blockIdx.x; clip < a.batch; clip += gridDim.x) {
-        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
-        for (int r0 = 0; r0 < R; r0 += 32) {
-            const int rt = min(32, R - r0);
-            for (int pass = 0; pass < 2; ++pass) {
-                const int rl = pass * 16 + wave * 2 + half;  // row within the tile
-                const int r = r0 + rl;
-                const bool active = rl < rt && r < Rreal;
+    // work unit: two consecutive rows of one clip; the workgroup owns a contiguous range of units and its waves
+    // pull them from an LDS counter
+    const unsigned pairs = (a.rows + 1) / 2;
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    unsigned unit = u_lo + wave;
+    while (unit < u_hi) {
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+        {
+            {
+                const unsigned clip = unit / pairs;
+                const int r = static_cast<int>(unit - clip * pairs) * 2 + half;
+                const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+                const bool active = r < Rreal;
+                const bool in_rows = r < R;
                 // functions.rs:137-151: window over the last W samples ending at chunk r + n_pad
                 const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
                 const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
@@ -189,28 +205,22 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
                 }
                 wave_order_m();
-                // ---- banded mel reduction (feature.rs:173), four filters per lane, into the transposed tile ----
-                if (rl < rt) {
+                // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are
+                //      adjacent words of out[clip][m][.] ----
+                if (in_rows) {
+                    float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
                     int off = 0;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const float m = mel_slot(w4 + off, prow + st[s], a.mel_q4[s]);
-                        if (fi[s] >= 0) tile[fi[s] * 33 + rl] = m;
+                        if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                         off += a.mel_q4[s];
                     }
                 }
                 wave_order_m();
             }
-            __syncthreads();
-            {
-                float *dst = a.out + static_cast<unsigned long long>(clip) * M * R;
-                for (int i = tid; i < M * rt; i += kWavesM * 64) {
-                    const int m = i / rt, rl = i - m * rt;
-                    dst[static_cast<unsigned long long>(m) * R + r0 + rl] = tile[m * 33 + rl];
-                }
-            }
-            __syncthreads();
         }
+        unit = next;
     }
 }
 
@@ -218,12 +228,15 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + ((static_cast<size_t>(a.n_filters) * 33 + 3) & ~static_cast<size_t>(3)) + L::kMelW +
+    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 +
                         32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (a.batch == 0) return hipSuccess;
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
-    const unsigned grid = a.batch < cap ? a.batch : cap;
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    if (units >= 0xffffffffull) return hipErrorInvalidValue;
+    unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
+    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c1024), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
