@@ -7,9 +7,9 @@
 //     one clip.  One persistent 8-wave workgroup per CU; waves pull (clip, row pair) units from an LDS counter.
 //   * window (Vorbis, config.rs:151-160) applied on load; the window covers the last W samples ending at chunk
 //     r + n_pad (zero outside the clip: zero initial state per clip), functions.rs:137-151.
-//   * 1024-point FFT = two radix-32 register butterflies with ONE transposing exchange through wave-private LDS,
-//     one frame at a time (ds_write_b64 scatter to 66*(n1>>1) + 2*k1 + (n1&1), 16 ds_read_b128 back; both
-//     conflict-free); no workgroup barrier inside a frame.
+//   * 1024-point FFT = two radix-32 register butterflies with ONE transposing exchange through wave-private LDS, run in
+//     two register halves (ds_write_b64 scatter to 34*(n1>>1) + 2*k1' + (n1&1), 16 ds_read_b128 back; both
+//     conflict-free) so that input and output registers of the transpose never coexist in full.
 //   * untangle with ds_bpermute_b32 (partner = lane 32-j, register 31-r); only bins 0..512 are produced: the mel
 //     bank ends at bin (F+1)/2 (feature.rs:69-70) and this path has no frame energy.
 //   * (|X| wnorm)^2 (functions.rs:166-169, feature.rs:164) -> P row in LDS -> banded mel reduction, 4 filters per lane.
@@ -22,14 +22,15 @@
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
 
+#include <cstdlib>
+
 namespace ss {
 
 namespace {
 
 namespace L = mel2048_layout;
-constexpr int kWavesM = 8;
-constexpr int kExSlots = 16 * 66;            // float2 per frame exchange region (8448 B = 33 bank rows)
-constexpr int kWaveFloatsM = kExSlots * 2 + 2 * L::kPRow;  // one exchange region + two P rows (zero pads persist)
+constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
+constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
 __device__ __forceinline__ void wave_order_m()
 {
@@ -55,6 +56,7 @@ __device__ __forceinline__ float mel_slot(const float4 *w4, const float *p, int 
     return acc;
 }
 
+template <int kWavesM>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     // ---- LDS carve: per-wave regions | table block | unit counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsM;
     float2 *ex = reinterpret_cast<float2 *>(wbase);                 // exchange region (one frame at a time)
-    float *prow = wbase + kExSlots * 2 + half * L::kPRow;           // P[0..512] + zero pad bins
+    float *prow = wbase + half * L::kPRow;                          // P[0..512] + zero pad bins, after the exchange
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
@@ -80,7 +82,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     {
         const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
-        for (int i = lane; i < 2 * L::kPRow; i += 64) wbase[kExSlots * 2 + i] = 0.f;  // zero pad bins stay zero
         if (tid == 0) {
             const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
             *s_next = static_cast<unsigned>(units0 * blockIdx.x / gridDim.x) + kWavesM;
@@ -95,7 +96,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     }
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
-    const int wb = 66 * (j >> 1) + (j & 1);                  // exchange write base (float2 units)
     const float hs = 0.25f * a.scale * a.scale;              // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
     const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
     const int M = static_cast<int>(a.n_filters);
@@ -147,26 +147,31 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 }
                 // ---- 1024-point complex FFT: radix-32, transpose through LDS (one frame at a time), twiddle, radix-32 ----
                 fft_reg<32>(v);
+                // The transpose runs in two register halves (columns k1 < 16, then k1 >= 16) so that only 16 of v's 32
+                // registers are live while u is being filled: both frames' half-columns fit one 8704-B region.
                 float2 u[32];
-                if (half == 0) {
+                float2 *exf = ex + half * (16 * 34);  // this frame's slice: [n1 pair 16][k1' 16][parity 2] + 2 pad per pair
+                const int wbh = 34 * (j >> 1) + (j & 1);
+                const int jl = j & 15;
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) ex[wb + 2 * k] = v[k];
-                    wave_order_m();
+                for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[k];
+                wave_order_m();
+                if (j < 16) {
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(&ex[66 * p + 2 * j]);
+                        const float4 t4 = *reinterpret_cast<const float4 *>(&exf[34 * p + 2 * jl]);
                         u[2 * p] = make_float2(t4.x, t4.y);
                         u[2 * p + 1] = make_float2(t4.z, t4.w);
                     }
                 }
                 wave_order_m();
-                if (half == 1) {
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) ex[wb + 2 * k] = v[k];
-                    wave_order_m();
+                for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[16 + k];
+                wave_order_m();
+                if (j >= 16) {
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(&ex[66 * p + 2 * j]);
+                        const float4 t4 = *reinterpret_cast<const float4 *>(&exf[34 * p + 2 * jl]);
                         u[2 * p] = make_float2(t4.x, t4.y);
                         u[2 * p + 1] = make_float2(t4.z, t4.w);
                     }
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     const float2 z = u[16];  // X[512] = conj Z[512]
                     prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
                 }
+                if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
                 wave_order_m();
                 // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are
                 //      adjacent words of out[clip][m][.] ----
@@ -224,12 +230,10 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     }
 }
 
-}  // namespace
-
-hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+template <int kWavesM>
+hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 +
-                        32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (a.batch == 0) return hipSuccess;
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
@@ -237,12 +241,21 @@ hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cu
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
     unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c1024), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c1024<kWavesM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
     if (info) *info = LaunchInfo{"ss_mel_c1024", grid, static_cast<unsigned>(kWavesM * 64), lds};
-    hipLaunchKernelGGL(ss_mel_c1024, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
+    hipLaunchKernelGGL(ss_mel_c1024<kWavesM>, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    static const char *w = std::getenv("SS_MEL_WAVES");  // A/B knob
+    if (w && std::atoi(w) == 12) return launch_mel_w<12>(a, stream, num_cus, info);
+    return launch_mel_w<8>(a, stream, num_cus, info);
 }
 
 }  // namespace ss
