@@ -34,6 +34,9 @@ struct ss_config {
     // fft_points = 2048 mel-spectrogram kernel tables (ss_mel2048.hip)
     ss::Mel2048Tables mel2048;
     float *d_mel2048_tab = nullptr;
+    // fft_points = 4096 MFCC kernel tables (ss_mfcc4096.hip)
+    ss::Mfcc4096Tables mfcc4096;
+    float *d_mfcc4096_tab = nullptr;
 };
 
 namespace {
@@ -228,6 +231,47 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
+    // fft_points = 4096 MFCC (256 filters): the one-frame-per-wave kernel under the same layout assumptions
+    if (!force_generic && cfg->mfcc4096.ok && fits32 && out_kind == ss::OUT_MFCC && a.frame_mode == ss::FRAME_NORMAL &&
+        a.preemph == 0.0f && a.window == nullptr && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
+        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        ss::Mfcc4096Args f{};
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tab = cfg->d_mfcc4096_tab;
+        f.mel_wpitch = cfg->mfcc4096.wpitch;
+        for (int s = 0; s < 4; ++s) f.mel_q4[s] = cfg->mfcc4096.q4[s];
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        f.out = out0;
+        static const char *rows_path = std::getenv("SS_DEBUG_ROWS");  // diagnostic only: frame 0's P row and ln(mel) row
+        if (rows_path) (void)hipMalloc(reinterpret_cast<void **>(&f.dbg), (1028 + 256 + 4 * 4096) * sizeof(float));
+        hipError_t e4 = ss::launch_mfcc_c2048(f, stream, cfg->num_cus, &info);
+        if (e4 != hipSuccess) return hip_fail(e4, "launch_mfcc_c2048");
+        if (f.dbg) {
+            std::vector<float> rows(1028 + 256 + 4 * 4096);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(rows.data(), f.dbg, rows.size() * sizeof(float), hipMemcpyDeviceToHost);
+            (void)hipFree(f.dbg);
+            if (FILE *fp = std::fopen(rows_path, "wb")) {
+                std::fwrite(rows.data(), sizeof(float), rows.size(), fp);
+                std::fclose(fp);
+            }
+        }
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
     hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
     if (e != hipSuccess) return hip_fail(e, "launch_front_generic");
     g_last_kernel = info.kernel_name;
@@ -358,6 +402,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->fast.ok) {
         SS_UP(d_fast_tab, c->fast.tab);
     }
+    ss::build_mfcc4096(h, c->mfcc4096);
+    if (c->mfcc4096.ok) SS_UP(d_mfcc4096_tab, c->mfcc4096.tab);
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
@@ -374,7 +420,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

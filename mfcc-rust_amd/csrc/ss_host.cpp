@@ -403,6 +403,74 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
     f.ok = true;
 }
 
+
+void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f)
+{
+    namespace L = mfcc4096_layout;
+    f = Mfcc4096Tables{};
+    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
+    if (t.d.n_fft != 4096 || M != 256 || Cc > 64) return;  // the symmetric DCT below is written for 256 filters
+    if (t.bank.last_bin > 1025) return;  // the kernel keeps P bins 0..1024
+    constexpr int32_t kRow = 1028;       // P bins a tap may touch: 0..1024 plus three zero pad bins
+    std::vector<int32_t> order(M);
+    for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
+    int32_t maxlen[4] = {0, 0, 0, 0};
+    for (size_t q = 0; q < M; ++q) maxlen[q / 64] = std::max(maxlen[q / 64], t.bank.len[order[q]]);
+    for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
+    if (f.wpitch == 0) f.wpitch = 4;
+    if (f.wpitch > 128) return;
+    const size_t melw0 = static_cast<size_t>(L::kCos) + Cc * L::kCosPitch;
+    f.tab.assign(melw0 + 64 * static_cast<size_t>(f.wpitch), 0.0f);
+    const double pi = 3.14159265358979323846;
+    auto cis = [&](double num, double den, float *dst) {
+        const double ang = -2.0 * pi * num / den;
+        dst[0] = static_cast<float>(std::cos(ang));
+        dst[1] = static_cast<float>(std::sin(ang));
+    };
+    for (int r = 1; r < 32; ++r)
+        for (int k1 = 0; k1 < 32; ++k1) {
+            const int p = (r - 1) / 2, half = (r - 1) % 2;
+            cis(static_cast<double>(k1 * r), 1024.0, &f.tab[L::kT1 + (p * 32 + k1) * 4 + 2 * half]);
+        }
+    for (int c2 = 0; c2 < 32; ++c2)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int k1 = lane & 31, a = lane >> 5;
+            float *dst = &f.tab[L::kT2 + (c2 * 64 + lane) * 2];
+            if (a) cis(static_cast<double>(k1 + 32 * c2), 2048.0, dst);
+            else { dst[0] = 1.0f; dst[1] = 0.0f; }
+        }
+    for (int c2 = 0; c2 < 16; ++c2)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int k1 = lane & 31, dd = lane >> 5;
+            cis(static_cast<double>(k1 + 32 * c2 + 1024 * dd), 4096.0, &f.tab[L::kTwn + (c2 * 64 + lane) * 2]);
+        }
+    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
+    int32_t off = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int32_t span = 4 * f.q4[s];
+        for (int j = 0; j < 64; ++j) {
+            const size_t q = static_cast<size_t>(s) * 64 + j;
+            const int32_t m = order[q];
+            filt[q] = m;
+            int32_t st = t.bank.start[m];
+            const int32_t len = t.bank.len[m];
+            int32_t shift = 0;
+            if (st + span > kRow) shift = st + span - kRow;
+            st -= shift;
+            start[q] = st;
+            for (int32_t i = 0; i < len; ++i)
+                f.tab[melw0 + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
+        }
+        off += span;
+    }
+    for (size_t cc = 0; cc < Cc; ++cc)
+        for (size_t m = 0; m < 128; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
+    f.ok = true;
+}
+
 }  // namespace ss
 
 // ---- host-only C ABI entry points ------------------------------------------------------------

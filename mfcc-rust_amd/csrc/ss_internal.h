@@ -114,4 +114,25 @@ struct Mel2048Tables {
 };
 void build_mel2048(const HostTables &t, Mel2048Tables &f);
 
+// Table block of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip), float offsets.  Reader lane L' = k1 + 32 a.
+namespace mfcc4096_layout {
+constexpr int kT1 = 0;                    // [16][32] float4: (W^(k1(2p+1)), W^(k1(2p+2))), W = exp(-2 pi i / 1024)
+constexpr int kT2 = kT1 + 16 * 128;       // [32][64] float2: a ? exp(-2 pi i (k1 + 32 c) / 2048) : 1
+constexpr int kTwn = kT2 + 32 * 128;      // [16][64] float2: exp(-2 pi i (k1 + 32 c + 1024 d) / 4096)
+constexpr int kStart = kTwn + 16 * 128;   // [4][64] int32: first P bin of the filter owned by (slot, lane)
+constexpr int kFilt = kStart + 256;       // [4][64] int32: filter index of (slot, lane), -1 if none
+constexpr int kCos = kFilt + 256;         // [n_ceps][132]: cos(pi c (2m+1) / 2M), m < 128 (the other half by symmetry)
+constexpr int kCosPitch = 132;
+constexpr int kPRow = 1032;               // floats per P row: bins 0..1024 + zero pad bins
+// melw [64][pitch] follows the cosine block: offset kCos + n_ceps * kCosPitch
+}  // namespace mfcc4096_layout
+
+struct Mfcc4096Tables {
+    bool ok = false;
+    std::vector<float> tab;
+    int32_t q4[4] = {0, 0, 0, 0};
+    int32_t wpitch = 0;
+};
+void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f);
+
 }  // namespace ss

@@ -1,0 +1,348 @@
+// ss_mfcc_c2048: fused MFCC for fft_points = 4096 (C = 2048 packed complex points) on gfx950 -- BASELINE config 5
+// (44.1 kHz, hop 1024, 256 mel filters, 40 cepstra).  One wave owns one frame: 64 lanes x 32 complex points.
+//
+//   * 2048-point FFT = 32 x 64: a radix-32 register butterfly over n2 (n = n1 + 64 n2, n1 = lane), ONE transposing
+//     exchange through wave-private LDS, then the 64-point transform over n1 split as n1 = a + 2b: lane (k1, a)
+//     does a radix-32 butterfly over b, and the last radix-2 over a pairs lanes L and L+32 with
+//     v_permlane32_swap (both halves' values arrive in one instruction; no LDS):
+//       Z[k1 + 32 c + 1024 d] = G0'[c] + (-1)^d G1'[c],  Ga'[c] = W2048^(a (k1 + 32 c)) FFT32_b(A[a+2b][k1] W1024^(b k1))[c].
+//     The exchange is two independent 32 x 32 transposes (even / odd n1), run in two register halves exactly like the
+//     2048-point mel kernel (ss_mel2048.hip): 8704 B of LDS per wave, conflict-free ds_write_b64 / ds_read_b128.
+//   * real-FFT untangle: lane (k1, d) register c holds bin k = k1 + 32c + 1024d; its partner 2048-k sits in lane
+//     (32-k1, 1-d), register 31-c (32-c for the k1 = 0 lanes, which expose their upper registers shifted by one);
+//     fetched with ds_bpermute_b32.  Every lane handles its 16 lower registers; k = 0, 512/1536 and 1024 are specials.
+//   * |X|/N: bins 0..1024 go to the P row (the mel bank ends at (F+1)/2, feature.rs:69-70), all 2049 feed the frame
+//     energy (feature.rs:216-219), reduced over the wave.
+//   * banded mel (4 filters per lane, host-sorted by tap count), zero handling, ln, then the DCT-II for the first
+//     n_ceps coefficients using the m <-> M-1-m symmetry of the cosine (half the table, half the multiplies).
+//   * dynamic frame scheduling from an LDS counter; no workgroup barrier in the main loop.
+// Reference semantics: feature.rs:99-148 (mfcc), :200-233 (mfe), processing.rs:65-181.
+#include "ss_device.h"
+#include "ss_fft_reg.h"
+#include "ss_internal.h"
+
+#include <cstdlib>
+
+namespace ss {
+
+namespace {
+
+namespace L = mfcc4096_layout;
+constexpr float kEpsH = 1.1920929e-7f;    // f32::EPSILON, functions.rs:70
+constexpr int kClsStride = 16 * 34 + 8;    // float2 per class slice: +8 keeps the two classes of a write group 16 banks apart
+constexpr int kExFloats = (kClsStride + 16 * 34) * 2;  // exchange region (two classes x half the columns, 8768 B); P row + ln(mel) row reuse it
+constexpr bool kDbgStages = false;        // true: SS_DEBUG_ROWS also dumps frame 0's registers after each FFT stage (tools/dbg4096.py)
+constexpr int kFRowOff = L::kPRow;        // ln(mel) row [256] behind the P row (both inside the exchange region)
+
+__device__ __forceinline__ void wave_order_h()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float bperm_h(int addr, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// value of lane (L & 31) in .x and of lane (L & 31) + 32 in .y -- identical in both halves of the wave.
+// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second.  Written as inline
+// assembly: hipcc 7.2 drops the second result of __builtin_amdgcn_permlane32_swap (both extracts read the first
+// register).  The s_nop covers the VALU-write -> permlane-read hazard the assembler does not see.
+__device__ __forceinline__ float2 both_halves(float v)
+{
+    float lo = v, hi = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    return make_float2(lo, hi);
+}
+
+__device__ __forceinline__ float fast_ln_h(float x)
+{
+    const bool tiny = x < 1.17549435e-38f;
+    const float l = __builtin_amdgcn_logf(tiny ? x * 4294967296.f : x);
+    return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
+}
+
+__device__ __forceinline__ float mel_slot_h(const float4 *w4, const float *p, int q4)
+{
+    float acc = 0.f;
+    for (int i = 0; i < q4; ++i) {
+        const float4 w = w4[i];
+        acc = fmaf(w.x, p[4 * i], acc);
+        acc = fmaf(w.y, p[4 * i + 1], acc);
+        acc = fmaf(w.z, p[4 * i + 2], acc);
+        acc = fmaf(w.w, p[4 * i + 3], acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <bool EXACT, bool POW2, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int k1 = lane & 31, d = lane >> 5;  // reader view: column k1, half a = d
+    const int cls = lane & 1, bw = lane >> 1; // writer view: n1 = lane = cls + 2 bw
+
+    float *wbase = reinterpret_cast<float *>(smem) + wave * kExFloats;
+    float2 *ex = reinterpret_cast<float2 *>(wbase);
+    float *prow = wbase;             // P[0..1024] + zero pad bins, after the exchange
+    float *frow = wbase + kFRowOff;  // ln(mel) in filter order
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kExFloats;
+    const float4 *s_t1 = reinterpret_cast<const float4 *>(s_tab + L::kT1);
+    const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const float *s_cos = s_tab + L::kCos;
+    const int Cc = static_cast<int>(a.n_ceps);
+    const int melw0 = L::kCos + Cc * L::kCosPitch;
+    const float *s_melw = s_tab + melw0;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + melw0 + 64 * a.mel_wpitch);
+
+    const unsigned total = a.batch * a.n_frames;
+    const unsigned f_lo = static_cast<unsigned>(static_cast<unsigned long long>(total) * blockIdx.x / gridDim.x);
+    const unsigned f_hi = static_cast<unsigned>(static_cast<unsigned long long>(total) * (blockIdx.x + 1) / gridDim.x);
+    {
+        const int n4 = (melw0 + 64 * a.mel_wpitch) / 4;
+        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = f_lo + WAVES;
+    }
+    __syncthreads();
+    int st[4], fi[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st[s] = s_start[s * 64 + lane];
+        fi[s] = s_filt[s * 64 + lane];
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * a.mel_wpitch);
+    const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
+    float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
+    const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
+    const float sgn = d ? -1.f : 1.f;
+    const float hscale = POW2 ? 0.25f * a.scale : 0.5f * a.scale;
+    const bool k1z = k1 == 0;
+
+    unsigned frame = f_lo + wave;
+    while (frame < f_hi) {
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+
+        const unsigned clip = frame / a.n_frames;
+        const unsigned t = frame - clip * a.n_frames;
+        // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
+        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step) + lane;
+        float2 v[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            if (EXACT) v[e] = src[64 * e];
+            else v[e] = 2 * (lane + 64 * e) < static_cast<int>(a.flen) ? src[64 * e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
+        }
+        // ---- pass 1: radix-32 over n2 ----
+        fft_reg<32>(v);
+        if (kDbgStages && a.dbg && frame == 0) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 0 * 4096)[lane * 32 + e] = v[e];
+        }
+        // ---- transpose (two 32 x 32 problems: even and odd n1), in two register halves ----
+        float2 u[32];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
+        wave_order_h();
+        if (k1 < 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&exr[34 * p]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order_h();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exw[2 * k] = v[16 + k];
+        wave_order_h();
+        if (k1 >= 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&exr[34 * p]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order_h();
+        if (kDbgStages && a.dbg && frame == 0) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 1 * 4096)[lane * 32 + e] = u[e];
+        }
+        // ---- twiddle W1024^(b k1), radix-32 over b, twiddle W2048^(a (k1 + 32 c)) ----
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float4 w2 = s_t1[p * 32 + k1];
+            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+            if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        }
+        fft_reg<32>(u);
+        if (kDbgStages && a.dbg && frame == 0) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 2 * 4096)[lane * 32 + e] = u[e];
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) u[c] = cmul(u[c], s_t2[c * 64 + lane]);
+        // ---- radix-2 over a: Z[k1 + 32 c + 1024 d] = G0'[c] + (-1)^d G1'[c] ----
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float2 rx = both_halves(u[c].x), ry = both_halves(u[c].y);
+            u[c] = make_float2(fmaf(sgn, rx.y, rx.x), fmaf(sgn, ry.y, ry.x));
+        }
+
+        if (kDbgStages && a.dbg && frame == 0) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 3 * 4096)[lane * 32 + e] = u[e];
+        }
+        // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
+        const float2 z16o = make_float2(both_halves(u[16].x).y, both_halves(u[16].y).y);  // Z[1536] (lane 32's register 16) for lane 0
+        if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        float esum = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            float2 zcs[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = 8 * hb + q;
+                // partner register 31 - c; the k1 = 0 lanes pair with register 32 - c of lane (0, 1-d): they expose their
+                // upper registers shifted by one
+                const float2 sv = k1z ? u[(32 - c) & 31] : u[31 - c];
+                zcs[q] = make_float2(bperm_h(paddr, sv.x), bperm_h(paddr, sv.y));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = 8 * hb + q;
+                const float2 zk = u[c];
+                const bool self = k1z && c == 0;  // k = 0 (d = 0) and k = 1024 (d = 1) pair with themselves
+                const float2 zc = self ? zk : zcs[q];
+                const float2 w = s_twn[c * 64 + lane];
+                const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+                const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+                const float2 wd = cmul(w, dd);
+                const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // 2 X[k]
+                const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // 2 conj X[2048-k]
+                const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
+                const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);
+                float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+                if (self && d) pb = 0.f;  // X[1024] counted once
+                // bins 0..1024 carry mel weight: d = 0 lanes hold them as X[k], d = 1 lanes as X[2048-k]
+                const bool use_a = d == 0 || self;
+                prow[d == 0 ? k1 + 32 * c : 1024 - k1 - 32 * c] = use_a ? pa : pb;
+                esum += pa + pb;
+            }
+        }
+        if (lane == 0) {
+            // the pair (512, 1536) sits in register 16 of lanes 0 and 32
+            const float2 zk = u[16], zc = z16o;
+            constexpr float h = 0.70710678118654752440f;  // exp(-2 pi i 512 / 4096) = (h, -h)
+            const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);
+            const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+            const float2 wd = cmul(make_float2(h, -h), dd);
+            const float xa_r = s.x + wd.y, xa_i = s.y - wd.x, xb_r = s.x - wd.y, xb_i = s.y + wd.x;
+            const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
+            const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na), pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+            prow[512] = pa;
+            esum += pa + pb;
+        }
+        float energy = hscale * wave_sum(esum);
+        energy = energy == 0.f ? kEpsH : energy;  // zero_handling, feature.rs:219
+        wave_order_h();
+
+        // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
+        {
+            int off = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float m = hscale * mel_slot_h(w4 + off, prow + st[s], a.mel_q4[s]);
+                m = m == 0.f ? kEpsH : m;
+                frow[fi[s]] = fast_ln_h(m);
+                off += a.mel_q4[s];
+            }
+        }
+        wave_order_h();
+        if (a.dbg && frame == 0) {
+            for (int i = lane; i < 1028; i += 64) a.dbg[i] = prow[i];
+            for (int i = lane; i < 256; i += 64) a.dbg[1028 + i] = frow[i];
+        }
+
+        // ---- DCT-II (feature.rs:120-123) with cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M = 256 ----
+        if (lane < Cc) {
+            const float par = (lane & 1) ? -1.f : 1.f;
+            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosPitch);
+            float acc = 0.f;
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {  // 8 float4s (32 filters from each end) per batch of fetches
+                float4 lo[8], hi[8], cq[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    lo[i] = *reinterpret_cast<const float4 *>(&frow[4 * (8 * g + i)]);
+                    hi[i] = *reinterpret_cast<const float4 *>(&frow[252 - 4 * (8 * g + i)]);
+                    cq[i] = c4[8 * g + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc = fmaf(fmaf(par, hi[i].w, lo[i].x), cq[i].x, acc);
+                    acc = fmaf(fmaf(par, hi[i].z, lo[i].y), cq[i].y, acc);
+                    acc = fmaf(fmaf(par, hi[i].y, lo[i].z), cq[i].z, acc);
+                    acc = fmaf(fmaf(par, hi[i].x, lo[i].w), cq[i].w, acc);
+                }
+            }
+            // scaling + column-0 replacement (feature.rs:126-146)
+            float o = acc * a.dct_scale_k;
+            if (lane == 0) o = a.dc_elimination ? fast_ln_h(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            a.out[static_cast<unsigned long long>(frame) * Cc + lane] = o;
+        }
+        wave_order_h();
+        frame = next;
+    }
+}
+
+template <int WAVES>
+hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + L::kCos + static_cast<size_t>(a.n_ceps) * L::kCosPitch +
+                        64 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
+    if (total == 0) return hipSuccess;
+    if (total >= 0xffffffffull) return hipErrorInvalidValue;
+    unsigned long long blocks = (total + WAVES - 1) / WAVES;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    if (blocks > cap) blocks = cap;
+    const unsigned grid = static_cast<unsigned>(blocks);
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096;
+    if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
+    return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
+}
+
+}  // namespace
+
+hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    return launch_h<8>(a, stream, num_cus, info);
+}
+
+}  // namespace ss
