@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native speechsauce hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg5] [--gather]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg4|cfg5] [--gather]
 
 Metric (BASELINE.json): frames/sec (+ real-time factor) for 16 kHz MFCC n_fft=512 at 1/2/4/8 MI355X.
 A "step" is one pass of the hot path over one batch of synthetic clips that already sit in HBM:
@@ -12,7 +12,9 @@ steps rotate over enough distinct input batches to exceed it (8 x 65.5 MB for cf
 Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  Clips are independent,
 so every rank processes its own batch of the same size (weak scaling) and there is no data-path
 collective; --gather adds an RCCL all-gather of the [frames x n_mfcc] blocks, overlapped on a
-side stream, for the north-star's "gather over xGMI" variant.
+side stream, for the north-star's "gather over xGMI" variant.  cfg4 (the 100 h corpus, 360 000
+clips) is the one strong-scaling workload: the corpus is split into contiguous clip shards
+(speechsauce_amd.distributed.shard_bounds), one per rank, one launch per shard per step.
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (4 B per input
 sample + 4 B per output element) / average launch duration measured with HIP events
@@ -42,6 +44,8 @@ WORKLOADS = {
     "cfg3": ("cfg3: 1024 x 1 s clips @16 kHz, mel_spectrogram n_fft=2048 hop=512 n_mels=128",
              dict(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=128,
                   high_frequency=8000.0), 16000, 1024, "mel"),
+    "cfg4": ("cfg4: 360 000 x 1 s clips @16 kHz (100 h corpus, split over the ranks), MFCC n_fft=512 hop=160 n_mels=40 n_mfcc=13",
+             dict(sample_rate=16000), 16000, 360000, "mfcc"),
     "cfg5": ("cfg5: 512 x 1 s clips @44.1 kHz, MFCC n_fft=4096 hop=1024 n_mels=256 n_mfcc=40",
              dict(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100,
                   num_cepstral=40, num_filters=256, high_frequency=22050.0), 44100, 512, "mfcc"),
@@ -52,7 +56,7 @@ def synth_batch(torch, batch, n, seed, device):
     """N(0, 0.1) clips (the distribution of the reference's own tests, lib.rs:18-22), generated on device."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    return torch.randn((batch, n), generator=g, device=device, dtype=torch.float32) * 0.1
+    return torch.randn((batch, n), generator=g, device=device, dtype=torch.float32).mul_(0.1)
 
 
 def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
@@ -131,8 +135,14 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     desc, pkw, n_samples, clips, kind = WORKLOADS[args.workload]
+    strong = args.workload == "cfg4"
     if args.clips:
         clips = args.clips
+    elif strong:  # fixed corpus: this rank's contiguous shard
+        from speechsauce_amd.distributed import shard_bounds
+
+        lo, hi = shard_bounds(clips, world, rank)
+        clips = hi - lo
     cfg = SpeechConfig(make_params(**pkw))
     lib = _lib.lib()
 
@@ -147,7 +157,7 @@ def main():
     frames_per_launch = clips * rows
 
     # distinct input batches totalling > 256 MiB so the Infinity Cache cannot hold the stream
-    n_buf = max(2, -(-300 * 1024 * 1024 // (4 * clips * n_samples)))
+    n_buf = max(1 if strong else 2, -(-300 * 1024 * 1024 // (4 * clips * n_samples)))
     xs = [synth_batch(torch, clips, n_samples, 1 + rank * 100 + i, device) for i in range(n_buf)]
     outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(2)]
     stream = torch.cuda.current_stream()
@@ -214,7 +224,7 @@ def main():
 
     if rank == 0:
         kernel = lib.ss_last_kernel_name().decode()
-        total_frames = frames_per_launch * args.steps * world
+        total_frames = frames_per_launch * args.steps * world  # equal shards (360 000 divides by 1, 2, 4, 8)
         value = total_frames / elapsed
         avg_launch_s = dev_ms * 1e-3 / args.steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
@@ -227,7 +237,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong and not args.clips else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic N(0,0.1) clips generated on device, resident in HBM; "
