@@ -137,7 +137,7 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ>
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
     constexpr bool PREFETCH = WAVES <= 12;  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
@@ -194,6 +194,17 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 #pragma unroll
         for (int r = 0; r < 8; ++r) twn[r] = s_twn[r * 16 + j];
     }
+    // RES bit 0: this lane's cosine row stays in registers; bit 1: the 15 pass-2 twiddles do
+    float4 cr[(RES & 1) ? NQ : 1];
+    float4 tw2r[(RES & 2) ? 8 : 1];
+    if (RES & 1) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) cr[i] = c4[i];
+    }
+    if (RES & 2) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) tw2r[p] = s_tw2[p * 16 + j];
+    }
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
 
@@ -208,13 +219,15 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         float2 v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
-        if (PREFETCH && next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
 
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
         fft16_reg(v);
 #pragma unroll
         for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         wave_order();
+        // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
+        // iteration ahead of their use
+        if (PREFETCH && next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         wave_order();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {  // two twiddles per ds_read_b128
-            const float4 w2 = s_tw2[p * 16 + j];
+            const float4 w2 = (RES & 2) ? tw2r[p] : s_tw2[p * 16 + j];
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
         }
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
                 lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (HB * h + i)]);
-                cq[i] = c4[HB * h + i];
+                cq[i] = (RES & 1) ? cr[HB * h + i] : c4[HB * h + i];
             }
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
@@ -355,7 +368,14 @@ hipError_t launch_w(const Fast512Args &a, hipStream_t stream, int num_cus, Launc
     };
     const bool pow2 = a.spectrum_exponent == 2;
     const bool b421 = a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1;
-    if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10>, "ss_mfcc_c256<10,exact,bank421>");
+    static const char *res_env = std::getenv("SS_RES");  // A/B knob: register-resident tables (bit 0 cosines, bit 1 twiddles)
+    const int res = res_env ? std::atoi(res_env) : 2;  // twiddles resident: 140 VGPRs, 0.7 us faster than 0; 3 spills
+    if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
+        if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
+        if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
+        if (WAVES <= 12 && res == 3) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 3>, "ss_mfcc_c256<10,exact,bank421,res3>");
+        return go(ss_mfcc_c256<10, true, false, WAVES, true, 10>, "ss_mfcc_c256<10,exact,bank421>");
+    }
     if (a.flen == 320) {
         return pow2 ? go(ss_mfcc_c256<10, true, true, WAVES, false, 12>, "ss_mfcc_c256<10,exact,pow2>")
                     : go(ss_mfcc_c256<10, true, false, WAVES, false, 12>, "ss_mfcc_c256<10,exact>");
