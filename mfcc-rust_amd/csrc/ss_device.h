@@ -85,6 +85,8 @@ struct Fast512Args {
     int32_t dc_elimination;
     float *out;
     unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
+    // filled by launch_mfcc_c256: floor(x / n_frames) = umulhi(x, nf_magic) >> nf_shift for x < 2^31 (nf_magic = 0: divide)
+    uint32_t nf_magic, nf_shift;
 };
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

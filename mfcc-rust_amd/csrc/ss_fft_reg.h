@@ -6,17 +6,17 @@
 
 namespace ss {
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+__host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 // multiply by -i
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+__host__ __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
 
 // Forward 4-point DFT (exp(-2 pi i nk/4)), natural order in and out.
-__device__ __forceinline__ void fft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
+__host__ __device__ __forceinline__ void fft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
 {
     const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2);
     const float2 a2 = cadd(v1, v3), a3 = mul_mi(csub(v1, v3));
@@ -27,10 +27,10 @@ __device__ __forceinline__ void fft4(float2 &v0, float2 &v1, float2 &v2, float2 
 }
 
 template <int R>
-__device__ __forceinline__ void fft_reg(float2 *v);
+__host__ __device__ __forceinline__ void fft_reg(float2 *v);
 
 template <>
-__device__ __forceinline__ void fft_reg<2>(float2 *v)
+__host__ __device__ __forceinline__ void fft_reg<2>(float2 *v)
 {
     const float2 a = v[0], b = v[1];
     v[0] = cadd(a, b);
@@ -38,14 +38,14 @@ __device__ __forceinline__ void fft_reg<2>(float2 *v)
 }
 
 template <>
-__device__ __forceinline__ void fft_reg<4>(float2 *v)
+__host__ __device__ __forceinline__ void fft_reg<4>(float2 *v)
 {
     fft4(v[0], v[1], v[2], v[3]);
 }
 
 // n = n1 + 2 n2, k = 4 k1 + k2: W8^(nk) = W2^(n1 k1) W8^(n1 k2) W4^(n2 k2)
 template <>
-__device__ __forceinline__ void fft_reg<8>(float2 *v)
+__host__ __device__ __forceinline__ void fft_reg<8>(float2 *v)
 {
     float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
     float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
@@ -62,37 +62,70 @@ __device__ __forceinline__ void fft_reg<8>(float2 *v)
 }
 
 // n = n1 + 4 n2, k = 4 k1 + k2: W16^(nk) = W4^(n1 k1) W16^(n1 k2) W4^(n2 k2)
+// The twiddles between the two radix-4 stages never appear as separate multiplies: W16^2 = h(1 - i) and
+// W16^6 = h(-1 - i) leave their factor h to the FMAs of the next butterfly, and the general ones are applied as
+// c (1 - i t) with the factor c folded the same way (148 instructions instead of 160; VALU issue is what bounds the
+// kernels built on this).
 template <>
-__device__ __forceinline__ void fft_reg<16>(float2 *v)
+__host__ __device__ __forceinline__ void fft_reg<16>(float2 *v)
 {
-    // step A: for each n1, 4-point DFT over n2 (elements n1, n1+4, n1+8, n1+12) -> Y[n1][k2] kept in place
+    // step A: for each n1, 4-point DFT over n2 (elements n1, n1+4, n1+8, n1+12) -> Y[n1][k2] kept in v[n1 + 4 k2]
 #pragma unroll
     for (int n1 = 0; n1 < 4; ++n1) fft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
-    // step B: Y[n1][k2] *= W16^(n1 k2); Y[n1][k2] sits in v[n1 + 4 k2]
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    constexpr float t1 = 0.41421356237309504880f, t3 = 2.41421356237309504880f;  // tan(pi/8), cot(pi/8)
     constexpr float h = 0.70710678118654752440f;
-    // n1 = 1: W16^k2, k2 = 1,2,3
-    v[5] = cmul(v[5], make_float2(c1, -s1));
-    v[9] = make_float2(h * (v[9].x + v[9].y), h * (v[9].y - v[9].x));
-    v[13] = cmul(v[13], make_float2(s1, -c1));
-    // n1 = 2: W16^(2 k2) = W8^k2
-    v[6] = make_float2(h * (v[6].x + v[6].y), h * (v[6].y - v[6].x));
-    v[10] = mul_mi(v[10]);
-    v[14] = make_float2(h * (v[14].y - v[14].x), -h * (v[14].x + v[14].y));
-    // n1 = 3: W16^(3 k2): k2=1 -> W16^3, k2=2 -> W16^6, k2=3 -> W16^9
-    v[7] = cmul(v[7], make_float2(s1, -c1));
-    v[11] = make_float2(h * (v[11].y - v[11].x), -h * (v[11].x + v[11].y));
-    v[15] = cmul(v[15], make_float2(-c1, s1));
-    // step C: for each k2, 4-point DFT over n1 (elements 4 k2 + n1) -> X[4 k1 + k2]
     float2 y[16];
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-        float2 a = v[4 * k2], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
+    // k2 = 0: no twiddles
+    {
+        float2 a = v[0], b = v[1], c = v[2], d = v[3];
         fft4(a, b, c, d);
-        y[k2] = a;
-        y[4 + k2] = b;
-        y[8 + k2] = c;
-        y[12 + k2] = d;
+        y[0] = a; y[4] = b; y[8] = c; y[12] = d;
+    }
+    // k2 = 1: b = Y1 W16^1 = c1 b'', c = Y2 W16^2 = h c', d = Y3 W16^3 = s1 d''
+    {
+        const float2 a = v[4];
+        const float2 bb = make_float2(fmaf(t1, v[5].y, v[5].x), fmaf(-t1, v[5].x, v[5].y));
+        const float2 cc = make_float2(v[6].x + v[6].y, v[6].y - v[6].x);
+        const float2 dd = make_float2(fmaf(t3, v[7].y, v[7].x), fmaf(-t3, v[7].x, v[7].y));
+        const float2 a0 = make_float2(fmaf(h, cc.x, a.x), fmaf(h, cc.y, a.y));
+        const float2 a1 = make_float2(fmaf(-h, cc.x, a.x), fmaf(-h, cc.y, a.y));
+        const float2 p = make_float2(s1 * dd.x, s1 * dd.y);
+        const float2 a2 = make_float2(fmaf(c1, bb.x, p.x), fmaf(c1, bb.y, p.y));    // b + d
+        const float2 bd = make_float2(fmaf(c1, bb.x, -p.x), fmaf(c1, bb.y, -p.y));  // b - d
+        y[1] = cadd(a0, a2);
+        y[5] = make_float2(a1.x + bd.y, a1.y - bd.x);  // a1 - i (b - d)
+        y[9] = csub(a0, a2);
+        y[13] = make_float2(a1.x - bd.y, a1.y + bd.x);
+    }
+    // k2 = 2: b = Y1 W16^2 = h b', c = Y2 W16^4 = -i Y2, d = Y3 W16^6 = h d'
+    {
+        const float2 a = v[8];
+        const float2 bb = make_float2(v[9].x + v[9].y, v[9].y - v[9].x);
+        const float2 c = make_float2(v[10].y, -v[10].x);
+        const float2 dd = make_float2(v[11].y - v[11].x, -(v[11].x + v[11].y));
+        const float2 a0 = cadd(a, c), a1 = csub(a, c);
+        const float2 u1 = cadd(bb, dd), u2 = csub(bb, dd);  // (b + d) / h, (b - d) / h
+        y[2] = make_float2(fmaf(h, u1.x, a0.x), fmaf(h, u1.y, a0.y));
+        y[6] = make_float2(fmaf(h, u2.y, a1.x), fmaf(-h, u2.x, a1.y));  // a1 - i (b - d)
+        y[10] = make_float2(fmaf(-h, u1.x, a0.x), fmaf(-h, u1.y, a0.y));
+        y[14] = make_float2(fmaf(-h, u2.y, a1.x), fmaf(h, u2.x, a1.y));
+    }
+    // k2 = 3: b = Y1 W16^3 = s1 b'', c = Y2 W16^6 = h c', d = Y3 W16^9 = -c1 d''
+    {
+        const float2 a = v[12];
+        const float2 bb = make_float2(fmaf(t3, v[13].y, v[13].x), fmaf(-t3, v[13].x, v[13].y));
+        const float2 cc = make_float2(v[14].y - v[14].x, -(v[14].x + v[14].y));
+        const float2 dd = make_float2(fmaf(t1, v[15].y, v[15].x), fmaf(-t1, v[15].x, v[15].y));
+        const float2 a0 = make_float2(fmaf(h, cc.x, a.x), fmaf(h, cc.y, a.y));
+        const float2 a1 = make_float2(fmaf(-h, cc.x, a.x), fmaf(-h, cc.y, a.y));
+        const float2 p = make_float2(c1 * dd.x, c1 * dd.y);
+        const float2 a2 = make_float2(fmaf(s1, bb.x, -p.x), fmaf(s1, bb.y, -p.y));  // b + d
+        const float2 bd = make_float2(fmaf(s1, bb.x, p.x), fmaf(s1, bb.y, p.y));    // b - d
+        y[3] = cadd(a0, a2);
+        y[7] = make_float2(a1.x + bd.y, a1.y - bd.x);
+        y[11] = csub(a0, a2);
+        y[15] = make_float2(a1.x - bd.y, a1.y + bd.x);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = y[i];
@@ -101,7 +134,7 @@ __device__ __forceinline__ void fft_reg<16>(float2 *v)
 
 // 32-point DFT: n = n1 + 4 n2 (n1 < 4, n2 < 8), k = 8 k1 + k2: W32^(nk) = W4^(n1 k1) W32^(n1 k2) W8^(n2 k2)
 template <>
-__device__ __forceinline__ void fft_reg<32>(float2 *v)
+__host__ __device__ __forceinline__ void fft_reg<32>(float2 *v)
 {
     // step A: for each n1 an 8-point DFT over n2 (elements n1 + 4 n2) -> Y[n1][k2] written back to v[n1 + 4 k2]
 #pragma unroll
@@ -145,6 +178,6 @@ __device__ __forceinline__ void fft_reg<32>(float2 *v)
 }
 
 // 16-point DFT on a 16-element register array
-__device__ __forceinline__ void fft16_reg(float2 (&v)[16]) { fft_reg<16>(v); }
+__host__ __device__ __forceinline__ void fft16_reg(float2 (&v)[16]) { fft_reg<16>(v); }
 
 }  // namespace ss

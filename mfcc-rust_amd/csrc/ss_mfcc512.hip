@@ -84,13 +84,33 @@ __device__ __forceinline__ float fast_ln(float x)
     return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
 }
 
-template <int NE, bool EXACT>
-__device__ __forceinline__ void load_quad(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE])
+// ln(x) for a value handed over as x * 2^32 (the factor rides on the scale multiply that produced it): no
+// denormal test is needed, v_log_f32 sees a normal number for every non-zero f32 x.
+constexpr float kTwo32 = 4294967296.f;
+__device__ __forceinline__ float ln_scaled(float xs)
 {
-    unsigned gf = quad * 4 + f;
-    gf = gf < total ? gf : total - 1;
-    const unsigned clip = gf / a.n_frames;
-    const unsigned t = gf - clip * a.n_frames;
+    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
+}
+
+// Issues the loads of one quad; returns this lane's frame index within its clip.
+template <int NE, bool EXACT>
+__device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE])
+{
+    const unsigned q4 = quad * 4;                                // uniform
+    const unsigned fl = min(static_cast<unsigned>(f), total - 1 - q4);  // lanes past the last frame redo it
+    unsigned clip, t;
+    if (a.nf_magic) {
+        // scalar quotient of the quad's first frame (multiply-high by the host's reciprocal), one conditional wrap per lane
+        clip = __umulhi(q4, a.nf_magic) >> a.nf_shift;
+        t = q4 - clip * a.n_frames + fl;
+        const bool wrap = t >= a.n_frames;
+        t -= wrap ? a.n_frames : 0u;
+        clip += wrap ? 1u : 0u;
+    } else {
+        const unsigned gf = q4 + fl;
+        clip = gf / a.n_frames;
+        t = gf - clip * a.n_frames;
+    }
     // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
     const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
 #pragma unroll
@@ -99,6 +119,7 @@ __device__ __forceinline__ void load_quad(const Fast512Args &a, unsigned quad, u
         if (EXACT) vin[e] = src[n];
         else vin[e] = 2 * n < static_cast<int>(a.flen) ? src[n] : make_float2(0.f, 0.f);
     }
+    return t;
 }
 
 // One mel slot with a compile-time tap count (multiple of 4): weights and P taps are all requested before
@@ -178,15 +199,22 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     // first quad of this wave; its loads are in flight across the barrier
     unsigned quad = q_lo + wave;
     float2 vin[NE];
-    if (quad < q_hi) load_quad<NE, EXACT>(a, quad, total, f, j, vin);
+    unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
+    if (quad < q_hi) t_next = load_quad<NE, EXACT>(a, quad, total, f, j, vin);
 
     const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
     const int Cc = static_cast<int>(a.n_ceps);
     // |X| = (1/2)|...|: the 1/2 of the untangle is folded into the scale (1/4 for the squared form)
-    const float hscale = POW2 ? 0.25f * a.scale : 0.5f * a.scale;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     __syncthreads();
-    const int st0 = s_start[j], st1 = s_start[16 + j], st2 = s_start[32 + j];  // first bin of this lane's three filters
+    // first P bin of this lane's three filters, as float indices into LDS; opaque so that the full address stays in a
+    // register (the compiler otherwise re-adds the P-row offset in front of every ds_read2)
+    int st0 = wave * kWaveFloats + kPOff + f * kPRow + s_start[j];
+    int st1 = wave * kWaveFloats + kPOff + f * kPRow + s_start[16 + j];
+    int st2 = wave * kWaveFloats + kPOff + f * kPRow + s_start[32 + j];
+    asm volatile("" : "+v"(st0), "+v"(st1), "+v"(st2));
+    const float *smem_f = reinterpret_cast<const float *>(smem);
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
     float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512): resident when the register budget allows (<= 3 waves per SIMD)
@@ -215,7 +243,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         next = __builtin_amdgcn_readfirstlane(next);
         ++n_done;
 
-        if (!PREFETCH && n_done > 1) load_quad<NE, EXACT>(a, quad, total, f, j, vin);
+        if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT>(a, quad, total, f, j, vin);
+        const unsigned t_cur = t_next;
         float2 v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         wave_order();
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
-        if (PREFETCH && next < q_hi) load_quad<NE, EXACT>(a, next, total, f, j, vin);
+        if (PREFETCH && next < q_hi) t_next = load_quad<NE, EXACT>(a, next, total, f, j, vin);
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -258,9 +287,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             const float2 w = PREFETCH ? twn[r] : s_twn[r * 16 + j];
             const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
             const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
-            const float2 wd = cmul(w, d);
-            const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // 2 X[k]
-            const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // 2 conj X[256-k]
+            // 2 X[k] = s - i w d, 2 conj X[256-k] = s + i w d = 2 s - 2 X[k]: six FMAs instead of a product and four adds
+            const float xa_r = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
+            const float xa_i = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
+            const float xb_r = fmaf(2.f, s.x, -xa_r), xb_i = fmaf(2.f, s.y, -xa_i);
             const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
             const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);  // unscaled; hscale is applied to the sums below
             const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
@@ -275,27 +305,27 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             prow[128] = p128;
             esum += p128;
         }
-        float energy = hscale * row16_sum(esum);
-        energy = energy == 0.f ? kEpsF : energy;  // zero_handling, feature.rs:219
+        float energy = hscale32 * row16_sum(esum);      // E * 2^32
+        energy = energy == 0.f ? kEpsF * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
         float m0, m1, m2;
         if (BANK421) {
-            m0 = mel_slot_fixed<4>(w4, prow + st0);
-            m1 = mel_slot_fixed<2>(w4 + 4, prow + st1);
-            m2 = mel_slot_fixed<1>(w4 + 6, prow + st2);
+            m0 = mel_slot_fixed<4>(w4, smem_f + st0);
+            m1 = mel_slot_fixed<2>(w4 + 4, smem_f + st1);
+            m2 = mel_slot_fixed<1>(w4 + 6, smem_f + st2);
         } else {
-            m0 = mel_slot_loop(w4, prow + st0, a.mel_q4[0]);
-            m1 = mel_slot_loop(w4 + a.mel_q4[0], prow + st1, a.mel_q4[1]);
-            m2 = mel_slot_loop(w4 + a.mel_q4[0] + a.mel_q4[1], prow + st2, a.mel_q4[2]);
+            m0 = mel_slot_loop(w4, smem_f + st0, a.mel_q4[0]);
+            m1 = mel_slot_loop(w4 + a.mel_q4[0], smem_f + st1, a.mel_q4[1]);
+            m2 = mel_slot_loop(w4 + a.mel_q4[0] + a.mel_q4[1], smem_f + st2, a.mel_q4[2]);
         }
-        m0 *= hscale;
-        m1 *= hscale;
-        m2 *= hscale;
-        frow[j] = fast_ln(m0 == 0.f ? kEpsF : m0);
-        frow[16 + j] = fast_ln(m1 == 0.f ? kEpsF : m1);
-        frow[32 + j] = fast_ln(m2 == 0.f ? kEpsF : m2);
+        m0 *= hscale32;  // mel energies * 2^32 (see ln_scaled)
+        m1 *= hscale32;
+        m2 *= hscale32;
+        frow[j] = ln_scaled(m0 == 0.f ? kEpsF * kTwo32 : m0);
+        frow[16 + j] = ln_scaled(m1 == 0.f ? kEpsF * kTwo32 : m1);
+        frow[32 + j] = ln_scaled(m2 == 0.f ? kEpsF * kTwo32 : m2);
         wave_order();
 
         // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 48-entry row ----
@@ -323,10 +353,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             float o = acc * a.dct_scale_k;
             if (j == 0) {
                 if (a.dc_elimination) {
-                    o = fast_ln(energy);
+                    o = ln_scaled(energy);
                 } else {
-                    const unsigned gfc = min(gf, total - 1);
-                    o = acc * (gfc % a.n_frames == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                    o = acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
                 }
             }
             if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
@@ -344,8 +373,23 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 }
 
 template <int WAVES>
-hipError_t launch_w(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
+    Fast512Args a = a_in;
+    a.nf_magic = 0;
+    a.nf_shift = 0;
+    {
+        // floor(x / d) for x < 2^31 as umulhi(x, ceil(2^(31+l) / d)) >> (l - 1), l = ceil(log2 d) (Granlund-Montgomery);
+        // the kernel's one-wrap lane fix-up needs d >= 4
+        const unsigned long long tot = static_cast<unsigned long long>(a.batch) * a.n_frames, d = a.n_frames;
+        if (d >= 4 && d < (1ull << 31) && tot + 4 < (1ull << 31)) {
+            unsigned l = 0;
+            while ((1ull << l) < d) ++l;
+            const unsigned __int128 num = static_cast<unsigned __int128>(1) << (31 + l);
+            a.nf_magic = static_cast<uint32_t>((num + d - 1) / d);
+            a.nf_shift = l - 1;
+        }
+    }
     const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloats + L::kMelW + 16 * a.mel_wpitch) * sizeof(float) + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
