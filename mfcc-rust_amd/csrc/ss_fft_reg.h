@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace ss {
 
 __host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -52,13 +54,14 @@ __host__ __device__ __forceinline__ void fft_reg<8>(float2 *v)
     fft4(e0, e1, e2, e3);
     fft4(o0, o1, o2, o3);
     constexpr float h = 0.70710678118654752440f;
-    o1 = make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));   // * (h - i h)
-    o2 = mul_mi(o2);                                           // * -i
-    o3 = make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));  // * (-h - i h)
+    // W8^1 = h (1 - i), W8^3 = h (-1 - i): the factor h rides on the FMAs of the last butterfly
+    o1 = make_float2(o1.x + o1.y, o1.y - o1.x);
+    o2 = mul_mi(o2);  // * -i
+    o3 = make_float2(o3.y - o3.x, -(o3.x + o3.y));
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[1] = make_float2(fmaf(h, o1.x, e1.x), fmaf(h, o1.y, e1.y)); v[5] = make_float2(fmaf(-h, o1.x, e1.x), fmaf(-h, o1.y, e1.y));
     v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
-    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+    v[3] = make_float2(fmaf(h, o3.x, e3.x), fmaf(h, o3.y, e3.y)); v[7] = make_float2(fmaf(-h, o3.x, e3.x), fmaf(-h, o3.y, e3.y));
 }
 
 // n = n1 + 4 n2, k = 4 k1 + k2: W16^(nk) = W4^(n1 k1) W16^(n1 k2) W4^(n2 k2)
@@ -132,6 +135,43 @@ __host__ __device__ __forceinline__ void fft_reg<16>(float2 *v)
 }
 
 
+// W32^m = cos(2 pi m / 32) - i sin(2 pi m / 32) from the first-octant table
+struct W32 {
+    float c, s;
+};
+__host__ __device__ constexpr W32 w32(int m)
+{
+    constexpr float c32[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                              0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f};
+    m &= 31;
+    if (m <= 8) return W32{c32[m], c32[8 - m]};
+    if (m <= 16) return W32{-c32[16 - m], c32[m - 8]};
+    if (m <= 24) return W32{-c32[m - 16], -c32[24 - m]};
+    return W32{c32[32 - m], -c32[m - 24]};
+}
+// z * W32^M = scale * rot(z): the rotation costs two FMAs (or nothing for the axis angles); `scale` is left to the caller's
+// butterfly FMAs.  |cos| >= |sin|: W = c (1 - i t), t = s/c; otherwise W = s (t - i), t = c/s.
+template <int M>
+__host__ __device__ __forceinline__ float2 rot32(float2 z, float &scale)
+{
+    constexpr W32 w = w32(M);
+    if constexpr ((M & 7) == 0) {
+        scale = 1.0f;
+        if constexpr ((M & 31) == 0) return z;
+        else if constexpr ((M & 31) == 8) return make_float2(z.y, -z.x);
+        else if constexpr ((M & 31) == 16) return make_float2(-z.x, -z.y);
+        else return make_float2(-z.y, z.x);
+    } else if constexpr ((w.c < 0 ? -w.c : w.c) >= (w.s < 0 ? -w.s : w.s)) {
+        constexpr float t = w.s / w.c;
+        scale = w.c;
+        return make_float2(fmaf(t, z.y, z.x), fmaf(-t, z.x, z.y));
+    } else {
+        constexpr float t = w.c / w.s;
+        scale = w.s;
+        return make_float2(fmaf(t, z.x, z.y), fmaf(t, z.y, -z.x));
+    }
+}
+
 // 32-point DFT: n = n1 + 4 n2 (n1 < 4, n2 < 8), k = 8 k1 + k2: W32^(nk) = W4^(n1 k1) W32^(n1 k2) W8^(n2 k2)
 template <>
 __host__ __device__ __forceinline__ void fft_reg<32>(float2 *v)
@@ -146,33 +186,34 @@ __host__ __device__ __forceinline__ void fft_reg<32>(float2 *v)
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[n1 + 4 * i] = t[i];
     }
-    // step B: Y[n1][k2] *= W32^(n1 k2)
-    constexpr float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-                              0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
-#pragma unroll
-    for (int n1 = 1; n1 < 4; ++n1) {
-#pragma unroll
-        for (int k2 = 1; k2 < 8; ++k2) {
-            const int m = n1 * k2;  // 1..21: W32^m = cos(2 pi m / 32) - i sin(2 pi m / 32)
-            // cos(m) for m in 0..8 is c32[m]; use symmetries for m up to 21
-            float cr, sr;
-            if (m <= 8) { cr = m == 8 ? 0.0f : c32[m]; sr = m == 8 ? 1.0f : c32[8 - m]; }
-            else if (m <= 16) { cr = m == 16 ? -1.0f : -c32[16 - m]; sr = m == 16 ? 0.0f : c32[m - 8]; }
-            else { cr = -c32[m - 16]; sr = -c32[24 - m]; }
-            v[n1 + 4 * k2] = cmul(v[n1 + 4 * k2], make_float2(cr, -sr));
-        }
-    }
-    // step C: for each k2 a 4-point DFT over n1 (elements 4 k2 + n1) -> X[8 k1 + k2]
+    // steps B + C: for each k2 the twiddles W32^(n1 k2) and the 4-point DFT over n1 (elements 4 k2 + n1) -> X[8 k1 + k2];
+    // the twiddle magnitudes are folded into the butterfly's FMAs
     float2 y[32];
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-        float2 a = v[4 * k2], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
-        fft4(a, b, c, d);
-        y[k2] = a;
-        y[8 + k2] = b;
-        y[16 + k2] = c;
-        y[24 + k2] = d;
-    }
+    auto group = [&](auto k2c) {
+        constexpr int k2 = decltype(k2c)::value;
+        float sb, sc, sd;
+        const float2 a = v[4 * k2];
+        const float2 b = rot32<k2>(v[4 * k2 + 1], sb);
+        const float2 c = rot32<2 * k2>(v[4 * k2 + 2], sc);
+        const float2 d = rot32<3 * k2>(v[4 * k2 + 3], sd);
+        const float2 a0 = make_float2(fmaf(sc, c.x, a.x), fmaf(sc, c.y, a.y));
+        const float2 a1 = make_float2(fmaf(-sc, c.x, a.x), fmaf(-sc, c.y, a.y));
+        const float2 p = make_float2(sd * d.x, sd * d.y);
+        const float2 a2 = make_float2(fmaf(sb, b.x, p.x), fmaf(sb, b.y, p.y));    // b + d
+        const float2 bd = make_float2(fmaf(sb, b.x, -p.x), fmaf(sb, b.y, -p.y));  // b - d
+        y[k2] = cadd(a0, a2);
+        y[8 + k2] = make_float2(a1.x + bd.y, a1.y - bd.x);  // a1 - i (b - d)
+        y[16 + k2] = csub(a0, a2);
+        y[24 + k2] = make_float2(a1.x - bd.y, a1.y + bd.x);
+    };
+    group(std::integral_constant<int, 0>{});
+    group(std::integral_constant<int, 1>{});
+    group(std::integral_constant<int, 2>{});
+    group(std::integral_constant<int, 3>{});
+    group(std::integral_constant<int, 4>{});
+    group(std::integral_constant<int, 5>{});
+    group(std::integral_constant<int, 6>{});
+    group(std::integral_constant<int, 7>{});
 #pragma unroll
     for (int i = 0; i < 32; ++i) v[i] = y[i];
 }

@@ -434,17 +434,11 @@ void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f)
             const int p = (r - 1) / 2, half = (r - 1) % 2;
             cis(static_cast<double>(k1 * r), 1024.0, &f.tab[L::kT1 + (p * 32 + k1) * 4 + 2 * half]);
         }
-    for (int c2 = 0; c2 < 32; ++c2)
+    for (int i = 0; i < 16; ++i)
         for (int lane = 0; lane < 64; ++lane) {
-            const int k1 = lane & 31, a = lane >> 5;
-            float *dst = &f.tab[L::kT2 + (c2 * 64 + lane) * 2];
-            if (a) cis(static_cast<double>(k1 + 32 * c2), 2048.0, dst);
-            else { dst[0] = 1.0f; dst[1] = 0.0f; }
-        }
-    for (int c2 = 0; c2 < 16; ++c2)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int k1 = lane & 31, dd = lane >> 5;
-            cis(static_cast<double>(k1 + 32 * c2 + 1024 * dd), 4096.0, &f.tab[L::kTwn + (c2 * 64 + lane) * 2]);
+            const int k1 = lane & 31, hh = lane >> 5;
+            cis(static_cast<double>(k1 + 32 * (i + 16 * hh)), 2048.0, &f.tab[L::kT2 + (i * 64 + lane) * 2]);
+            cis(static_cast<double>(k1 + 32 * i + 512 * hh), 4096.0, &f.tab[L::kTwn + (i * 64 + lane) * 2]);
         }
     int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
     int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);

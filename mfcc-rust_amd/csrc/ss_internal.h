@@ -117,8 +117,8 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f);
 // Table block of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip), float offsets.  Reader lane L' = k1 + 32 a.
 namespace mfcc4096_layout {
 constexpr int kT1 = 0;                    // [16][32] float4: (W^(k1(2p+1)), W^(k1(2p+2))), W = exp(-2 pi i / 1024)
-constexpr int kT2 = kT1 + 16 * 128;       // [32][64] float2: a ? exp(-2 pi i (k1 + 32 c) / 2048) : 1
-constexpr int kTwn = kT2 + 32 * 128;      // [16][64] float2: exp(-2 pi i (k1 + 32 c + 1024 d) / 4096)
+constexpr int kT2 = kT1 + 16 * 128;       // [16][64] float2: exp(-2 pi i (k1 + 32 (i + 16 h)) / 2048), lane = k1 + 32 h
+constexpr int kTwn = kT2 + 16 * 128;      // [16][64] float2: exp(-2 pi i (k1 + 32 i + 512 h) / 4096)
 constexpr int kStart = kTwn + 16 * 128;   // [4][64] int32: first P bin of the filter owned by (slot, lane)
 constexpr int kFilt = kStart + 256;       // [4][64] int32: filter index of (slot, lane), -1 if none
 constexpr int kCos = kFilt + 256;         // [n_ceps][132]: cos(pi c (2m+1) / 2M), m < 128 (the other half by symmetry)
