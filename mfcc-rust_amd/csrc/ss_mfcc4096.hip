@@ -45,22 +45,20 @@ __device__ __forceinline__ float bperm_h(int addr, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-// value of lane (L & 31) in .x and of lane (L & 31) + 32 in .y -- identical in both halves of the wave.
-// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second.  Written as inline
-// assembly: hipcc 7.2 drops the second result of __builtin_amdgcn_permlane32_swap (both extracts read the first
-// register).  The s_nop covers the VALU-write -> permlane-read hazard the assembler does not see.
-__device__ __forceinline__ float2 both_halves(float v)
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.  Inline assembly: hipcc 7.2 drops the
+// second result of __builtin_amdgcn_permlane32_swap (both extracts read the first register).  The s_nop covers the
+// VALU-write -> permlane-read hazard, which the assembler does not see.
+__device__ __forceinline__ void swap_halves(float &a, float &b)
 {
-    float lo = v, hi = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-    return make_float2(lo, hi);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-__device__ __forceinline__ float fast_ln_h(float x)
+// ln(x) for a value handed over as x * 2^32 (the factor rides on the scale multiply that produced it): v_log_f32 then
+// sees a normal number for every non-zero f32 x and no denormal test is needed
+constexpr float kTwo32H = 4294967296.f;
+__device__ __forceinline__ float ln_scaled_h(float xs)
 {
-    const bool tiny = x < 1.17549435e-38f;
-    const float l = __builtin_amdgcn_logf(tiny ? x * 4294967296.f : x);
-    return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
+    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
 }
 
 __device__ __forceinline__ float mel_slot_h(const float4 *w4, const float *p, int q4)
@@ -128,8 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
     float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
     const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
-    const float sgn = d ? -1.f : 1.f;
-    const float hscale = POW2 ? 0.25f * a.scale : 0.5f * a.scale;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32H;
     const bool k1z = k1 == 0;
 
     unsigned frame = f_lo + wave;
@@ -191,76 +188,79 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
         }
-        fft_reg<32>(u);
+        fft_reg<32>(u);  // u[c] = G_a[c], a = lane >> 5
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 2 * 4096)[lane * 32 + e] = u[e];
         }
+        // ---- radix-2 over a.  One v_permlane32_swap of registers (i, 16 + i) hands the lower half-wave both halves'
+        // column i and the upper half-wave both halves' column 16 + i; each lane then forms BOTH outputs
+        //   Z[k1 + 32 c + 1024 d] = G0[c] + (-1)^d W2048^(k1 + 32 c) G1[c],  c = i + 16 h, h = lane >> 5
+        // r0[i] (d = 0) and r1[i] (d = 1): half the swaps, half the twiddle products, no copies ----
+        float2 r0[16], r1[16];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) u[c] = cmul(u[c], s_t2[c * 64 + lane]);
-        // ---- radix-2 over a: Z[k1 + 32 c + 1024 d] = G0'[c] + (-1)^d G1'[c] ----
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const float2 rx = both_halves(u[c].x), ry = both_halves(u[c].y);
-            u[c] = make_float2(fmaf(sgn, rx.y, rx.x), fmaf(sgn, ry.y, ry.x));
+        for (int i = 0; i < 16; ++i) {
+            float px = u[i].x, qx = u[16 + i].x, py = u[i].y, qy = u[16 + i].y;
+            swap_halves(px, qx);
+            swap_halves(py, qy);
+            const float2 wq = cmul(make_float2(qx, qy), s_t2[i * 64 + lane]);
+            r0[i] = make_float2(px + wq.x, py + wq.y);
+            r1[i] = make_float2(px - wq.x, py - wq.y);
         }
-
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
-            for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 3 * 4096)[lane * 32 + e] = u[e];
+            for (int e = 0; e < 16; ++e) {
+                reinterpret_cast<float2 *>(a.dbg + 1284 + 3 * 4096)[lane * 32 + e] = r0[e];
+                reinterpret_cast<float2 *>(a.dbg + 1284 + 3 * 4096)[lane * 32 + 16 + e] = r1[e];
+            }
         }
+
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
-        const float2 z16o = make_float2(both_halves(u[16].x).y, both_halves(u[16].y).y);  // Z[1536] (lane 32's register 16) for lane 0
+        // Lane (k1, h) register r0[i] holds bin k = k1 + 32 i + 512 h (< 1024); its partner 2048 - k is r1[15 - i] of lane
+        // (32 - k1, 1 - h).  The k1 = 0 lanes pair with r1[16 - i] of the other k1 = 0 lane (they expose r1 shifted by one);
+        // their i = 0 pairs are in-lane: lane 0 has k = 0 (X[0] and X[2048] come from Z[0] alone), lane 32 has
+        // (512, 1536) = (r0[0], r1[0]).  Z[1024] = lane 0's r1[0] is the one bin left over.
         if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float esum = 0.f;
+        float *pdst = prow + k1 + 512 * d;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             float2 zcs[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int c = 8 * hb + q;
-                // partner register 31 - c; the k1 = 0 lanes pair with register 32 - c of lane (0, 1-d): they expose their
-                // upper registers shifted by one
-                const float2 sv = k1z ? u[(32 - c) & 31] : u[31 - c];
+                const int i = 8 * hb + q;
+                const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
                 zcs[q] = make_float2(bperm_h(paddr, sv.x), bperm_h(paddr, sv.y));
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int c = 8 * hb + q;
-                const float2 zk = u[c];
-                const bool self = k1z && c == 0;  // k = 0 (d = 0) and k = 1024 (d = 1) pair with themselves
-                const float2 zc = self ? zk : zcs[q];
-                const float2 w = s_twn[c * 64 + lane];
+                const int i = 8 * hb + q;
+                const float2 zk = r0[i];
+                float2 zc = zcs[q];
+                if (i == 0) zc = k1z ? (d ? r1[0] : zk) : zc;
+                const float2 w = s_twn[i * 64 + lane];
                 const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
                 const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
-                const float2 wd = cmul(w, dd);
-                const float xa_r = s.x + wd.y, xa_i = s.y - wd.x;  // 2 X[k]
-                const float xb_r = s.x - wd.y, xb_i = s.y + wd.x;  // 2 conj X[2048-k]
+                // 2 X[k] = s - i w dd, 2 conj X[2048-k] = s + i w dd = 2 s - 2 X[k]
+                const float xa_r = fmaf(w.y, dd.x, fmaf(w.x, dd.y, s.x));
+                const float xa_i = fmaf(w.y, dd.y, fmaf(-w.x, dd.x, s.y));
+                const float xb_r = fmaf(2.f, s.x, -xa_r), xb_i = fmaf(2.f, s.y, -xa_i);
                 const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
                 const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);
-                float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
-                if (self && d) pb = 0.f;  // X[1024] counted once
-                // bins 0..1024 carry mel weight: d = 0 lanes hold them as X[k], d = 1 lanes as X[2048-k]
-                const bool use_a = d == 0 || self;
-                prow[d == 0 ? k1 + 32 * c : 1024 - k1 - 32 * c] = use_a ? pa : pb;
+                const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+                pdst[32 * i] = pa;  // bins 0..1023 carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70), as does 1024 below
                 esum += pa + pb;
             }
         }
         if (lane == 0) {
-            // the pair (512, 1536) sits in register 16 of lanes 0 and 32
-            const float2 zk = u[16], zc = z16o;
-            constexpr float h = 0.70710678118654752440f;  // exp(-2 pi i 512 / 4096) = (h, -h)
-            const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);
-            const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
-            const float2 wd = cmul(make_float2(h, -h), dd);
-            const float xa_r = s.x + wd.y, xa_i = s.y - wd.x, xb_r = s.x - wd.y, xb_i = s.y + wd.x;
-            const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
-            const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na), pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
-            prow[512] = pa;
-            esum += pa + pb;
+            const float2 z = r1[0];  // X[1024] = conj Z[1024]
+            const float n = 4.f * (z.x * z.x + z.y * z.y);
+            const float p1024 = POW2 ? n : __builtin_amdgcn_sqrtf(n);
+            prow[1024] = p1024;
+            esum += p1024;
         }
-        float energy = hscale * wave_sum(esum);
-        energy = energy == 0.f ? kEpsH : energy;  // zero_handling, feature.rs:219
+        float energy = hscale32 * wave_sum(esum);          // E * 2^32 (see ln_scaled_h)
+        energy = energy == 0.f ? kEpsH * kTwo32H : energy;  // zero_handling, feature.rs:219
         wave_order_h();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float m = hscale * mel_slot_h(w4 + off, prow + st[s], a.mel_q4[s]);
-                m = m == 0.f ? kEpsH : m;
-                frow[fi[s]] = fast_ln_h(m);
+                float m = hscale32 * mel_slot_h(w4 + off, prow + st[s], a.mel_q4[s]);
+                m = m == 0.f ? kEpsH * kTwo32H : m;
+                frow[fi[s]] = ln_scaled_h(m);
                 off += a.mel_q4[s];
             }
         }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (lane == 0) o = a.dc_elimination ? fast_ln_h(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (lane == 0) o = a.dc_elimination ? ln_scaled_h(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
             a.out[static_cast<unsigned long long>(frame) * Cc + lane] = o;
         }
         wave_order_h();

@@ -76,14 +76,6 @@ __device__ __forceinline__ float bperm(int addr, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-// ln(x) from v_log_f32 (log2) with the denormal pre-scale the library form uses; ~1 ulp of log2.
-__device__ __forceinline__ float fast_ln(float x)
-{
-    const bool tiny = x < 1.17549435e-38f;
-    const float l = __builtin_amdgcn_logf(tiny ? x * 4294967296.f : x);
-    return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
-}
-
 // ln(x) for a value handed over as x * 2^32 (the factor rides on the scale multiply that produced it): no
 // denormal test is needed, v_log_f32 sees a normal number for every non-zero f32 x.
 constexpr float kTwo32 = 4294967296.f;

@@ -40,12 +40,12 @@ for L in range(64):
     u[L] *= W(np.arange(32) * k1, 1024)
 u = np.fft.fft(u, axis=1)
 cmp("pass2", st[2], u)
-for L in range(32, 64):
-    u[L] *= W((L & 31) + 32 * np.arange(32), 2048)
 Z = np.zeros((64, 32), complex)
 for L in range(64):
-    k1, d = L & 31, L >> 5
-    Z[L] = u[k1] + (-1) ** d * u[k1 + 32]
+    k1, h = L & 31, L >> 5
+    for e in range(32):
+        c = (e & 15) + 16 * h
+        Z[L, e] = u[k1, c] + (-1) ** (e >> 4) * W(k1 + 32 * c, 2048) * u[k1 + 32, c]  # bin k1 + 32 c + 1024 (e >> 4)
 cmp("radix2", st[3], Z)
 ref = 2 * np.abs(np.fft.rfft(xx))
 print("P bad:", int((np.abs(P[:1025] - ref[:1025]) > 1e-4 * ref.max()).sum()))
