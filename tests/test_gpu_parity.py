@@ -215,6 +215,20 @@ def test_ragged_lengths_and_errors(ss, oracle):
         ss.mfcc(np.zeros(16000, np.float64), 16000)
 
 
+def test_short_clip_batches(ss, oracle):
+    """Batches of very short clips: a quad of the 512-point kernel then spans several clips (frame -> (clip, t) wraps),
+    with and without the [0,0]-scaled DCT row that depends on t == 0 (feature.rs:126-146)."""
+    import torch
+
+    for n in (480, 640, 800, 960, 1120, 1600):  # 1, 2, 3, 4, 5, 8 frames per clip
+        x = _signal(40 + n, (37, n))
+        for dc in (True, False):
+            got = ss.mfcc_batch(torch.from_numpy(x).cuda(), 16000, dc_elimination=dc).cpu().numpy()
+            p = oracle.make_params(**dict(CFG1, dc_elimination=int(dc)))
+            for b in (0, 1, 17, 36):
+                assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (n, dc, b)
+
+
 def test_reference_test_shapes(ss):
     """speechsauce/src/lib.rs:93-134: mfcc (6248, 13), mfe (6248, 40)/(6248,), no NaN, for 1e6 samples."""
     x = _signal(11, 1_000_000)
