@@ -19,6 +19,7 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, unsigned long l
                 if (MODE == 1) p[i] = p[i] * m + c;
                 if (MODE == 2) a[i] = __builtin_amdgcn_sqrtf(a[i]);
                 if (MODE == 3) a[i] = a[i] + c;
+                if (MODE == 4) { if (u == 0) a[i] = __builtin_amdgcn_sqrtf(a[i]); else a[i] = __builtin_fmaf(a[i], m, c); }  // 1 sqrt : 3 fma
             }
         }
     }
@@ -33,14 +34,15 @@ int main()
     float *out; unsigned long long *cyc, h[32];
     hipMalloc(&out, 1024 * 512 * 4); hipMalloc(&cyc, 32 * 8);
     const int iters = 2000;
-    const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_sqrt_f32", "v_add_f32"};
-    for (int mode = 0; mode < 4; ++mode)
+    const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_sqrt_f32", "v_add_f32", "sqrt:fma 1:3"};
+    for (int mode = 0; mode < 5; ++mode)
         for (int threads : {64, 256, 512, 1024}) {  // one block on one CU: 0.25 / 1 / 2 / 4 waves per SIMD
             for (int rep = 0; rep < 2; ++rep) {
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(threads), 0, 0, out, iters, cyc);
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(threads), 0, 0, out, iters, cyc);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(1), dim3(threads), 0, 0, out, iters, cyc);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(1), dim3(threads), 0, 0, out, iters, cyc);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(1), dim3(threads), 0, 0, out, iters, cyc);
                 hipDeviceSynchronize();
             }
             hipMemcpy(h, cyc, 32 * 8, hipMemcpyDeviceToHost);
