@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -145,6 +145,31 @@ int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, si
 int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
                               size_t ld, float *d_out, void *stream);
 int ss_preemphasis_device(const float *d_x, size_t n_samples, long shift, float cof, float *d_y, void *stream);
+
+/* ---- post-processing on the feature matrix (row-major [rows x cols] f32) ---------- */
+
+/* speechsauce::processing::cmvn(ArrayView2<f32>, variance_normalization) -> Array2<f32>  (processing.rs:265-300):
+ * subtract the column means; optionally divide by (population std + 2^-30). */
+int ss_cmvn(const float *vec, size_t rows, size_t cols, int variance_normalization, float *out);
+/* the same for `batch` matrices stored back to back ([batch x rows x cols], e.g. the block ss_mfcc_batch_device wrote) */
+int ss_cmvn_batch_device(const float *d_vec, size_t batch, size_t rows, size_t cols, int variance_normalization,
+                         float *d_out, void *stream);
+/* speechsauce::processing::cmvnw(Array2<f32>, win_size = 301, variance_normalization)  (processing.rs:315-371):
+ * sliding-window normalisation over win_size rows of the symmetric-padded matrix (np.pad 'symmetric', util.rs:108-115).
+ * SS_ERR_BAD_CONFIG for an even win_size (the reference asserts). */
+int ss_cmvnw(const float *vec, size_t rows, size_t cols, size_t win_size, int variance_normalization, float *out);
+int ss_cmvnw_batch_device(const float *d_vec, size_t batch, size_t rows, size_t cols, size_t win_size,
+                          int variance_normalization, float *d_out, void *stream);
+/* speechsauce::processing::derivative_extraction(&Array2<f32>, delta_windows)  (processing.rs:222-254): edge-padded
+ * differences along the FEATURE axis, sum_R (R f[c+R] - f[c-R]) / sum_R 2R^2 (the reference's literal arithmetic).
+ * Rows are independent, so a [batch x rows x cols] block is passed as batch*rows rows. */
+int ss_derivative_extraction(const float *feat, size_t rows, size_t cols, size_t delta_windows, float *out);
+int ss_derivative_extraction_device(const float *d_feat, size_t rows, size_t cols, size_t delta_windows, float *d_out,
+                                    void *stream);
+/* speechsauce::feature::extract_derivative_feature(Array2<f32>) -> Array3<f32>  (feature.rs:253-269):
+ * cube [rows x cols x 3] = (feature, derivative_extraction(feature, 2), derivative_extraction(that, 2)) */
+int ss_extract_derivative_feature(const float *feat, size_t rows, size_t cols, float *cube);
+int ss_extract_derivative_feature_device(const float *d_feat, size_t rows, size_t cols, float *d_cube, void *stream);
 
 /* stage outputs (parity triage; pub fns of the reference too):
  * power_spectrum (processing.rs:179-181) over the frames of each clip: [batch x n_frames x (fft_points/2+1)] */

@@ -3,6 +3,8 @@
 //   speechsauce::config::{SpeechConfigBuilder, SpeechConfig}   (speechsauce/src/config.rs:10-190)
 //   speechsauce::feature::{mfcc, mfe, mel_spectrogram1, mel_spectrogram2}  (feature.rs:99-233)
 //   speechsauce::processing::preemphasis                        (processing.rs:31-53)
+//   speechsauce::processing::{cmvn, cmvnw, derivative_extraction}, feature::extract_derivative_feature
+//                                                               (processing.rs:222-371, feature.rs:253-269)
 // Where the reference panics, these throw speechsauce::Error carrying the ss_status.
 // Arrays are plain row-major std::vector<float> plus shapes (the reference returns ndarray::ArrayN<f32>).
 #pragma once
@@ -151,6 +153,45 @@ inline std::vector<float> preemphasis(const std::vector<float> &signal, long shi
     std::vector<float> y(signal.size());
     check(ss_preemphasis(signal.data(), signal.size(), shift, cof, y.data()));
     return y;
+}
+
+// ---- post-processing on a row-major [rows x cols] feature matrix ----
+
+// processing.rs:265-300
+inline std::vector<float> cmvn(const std::vector<float> &vec, size_t rows, size_t cols, bool variance_normalization = false)
+{
+    if (vec.size() != rows * cols) throw Error(SS_ERR_ARG, "cmvn: shape mismatch");
+    std::vector<float> out(vec.size());
+    check(ss_cmvn(vec.data(), rows, cols, variance_normalization ? 1 : 0, out.data()));
+    return out;
+}
+
+// processing.rs:315-371 (win_size must be odd, as the reference asserts)
+inline std::vector<float> cmvnw(const std::vector<float> &vec, size_t rows, size_t cols, size_t win_size = 301,
+                                bool variance_normalization = false)
+{
+    if (vec.size() != rows * cols) throw Error(SS_ERR_ARG, "cmvnw: shape mismatch");
+    std::vector<float> out(vec.size());
+    check(ss_cmvnw(vec.data(), rows, cols, win_size, variance_normalization ? 1 : 0, out.data()));
+    return out;
+}
+
+// processing.rs:222-254
+inline std::vector<float> derivative_extraction(const std::vector<float> &feat, size_t rows, size_t cols, size_t delta_windows)
+{
+    if (feat.size() != rows * cols) throw Error(SS_ERR_ARG, "derivative_extraction: shape mismatch");
+    std::vector<float> out(feat.size());
+    check(ss_derivative_extraction(feat.data(), rows, cols, delta_windows, out.data()));
+    return out;
+}
+
+// feature.rs:253-269: [rows x cols x 3]
+inline std::vector<float> extract_derivative_feature(const std::vector<float> &feature, size_t rows, size_t cols)
+{
+    if (feature.size() != rows * cols) throw Error(SS_ERR_ARG, "extract_derivative_feature: shape mismatch");
+    std::vector<float> cube(3 * feature.size());
+    check(ss_extract_derivative_feature(feature.data(), rows, cols, cube.data()));
+    return cube;
 }
 
 }  // namespace speechsauce

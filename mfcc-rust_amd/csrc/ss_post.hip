@@ -1,0 +1,292 @@
+// Post-processing on the feature matrix: cmvn, cmvnw, derivative_extraction, extract_derivative_feature.
+// Reference: speechsauce/src/processing.rs:222-254 (derivative_extraction), :265-300 (cmvn), :315-371 (cmvnw),
+// feature.rs:253-269 (extract_derivative_feature); the pads are np.pad 'edge' / 'symmetric' as util.rs:108-124 quotes.
+//
+// The data is the [clips x rows x cols] feature block the hot path just wrote (5 MB for 1024 one-second clips), so these
+// are plain HBM/L2-bound element kernels: one thread per output element (or per column for the global statistics),
+// neighbouring threads on neighbouring addresses, f64 accumulators for the statistics (full rate on gfx950; it keeps the
+// result within an ulp of the f64 oracle for 6 000-row matrices too).  No LDS, no cross-workgroup state.
+#include "ss_internal.h"
+#include "speechsauce_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+namespace ss {
+
+namespace {
+
+constexpr double kEps30 = 9.313225746154785e-10;  // 2f32.powf(-30.), processing.rs:266, :324
+
+// np.pad(..., 'symmetric') index along an axis of length n (reflection that repeats the edge sample, period 2n)
+__device__ __forceinline__ unsigned sym_index(long long p, unsigned n)
+{
+    const long long period = 2ll * n;
+    long long m = p % period;
+    if (m < 0) m += period;
+    return static_cast<unsigned>(m < n ? m : period - 1 - m);
+}
+
+// cmvn: thread = (clip, column); three passes over the column (mean, centred second moment, write)
+__global__ __launch_bounds__(256) void ss_cmvn_kernel(const float *__restrict__ x, float *__restrict__ out, unsigned long long n_cols_total,
+                                                      unsigned rows, unsigned cols, int variance)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= n_cols_total) return;
+    const unsigned long long clip = g / cols;
+    const unsigned c = static_cast<unsigned>(g - clip * cols);
+    const float *src = x + clip * rows * cols + c;
+    float *dst = out + clip * rows * cols + c;
+    double s = 0.0;
+    for (unsigned r = 0; r < rows; ++r) s += static_cast<double>(src[static_cast<size_t>(r) * cols]);
+    const double mean = s / rows;
+    double inv = 1.0;
+    if (variance) {
+        // std_axis(Axis(0), 0.) of the mean-subtracted column (processing.rs:283)
+        double v = 0.0;
+        for (unsigned r = 0; r < rows; ++r) {
+            const double d = static_cast<double>(src[static_cast<size_t>(r) * cols]) - mean;
+            v += d * d;
+        }
+        inv = 1.0 / (sqrt(v / rows) + kEps30);
+    }
+    for (unsigned r = 0; r < rows; ++r)
+        dst[static_cast<size_t>(r) * cols] = static_cast<float>((static_cast<double>(src[static_cast<size_t>(r) * cols]) - mean) * inv);
+}
+
+// cmvnw pass 1: thread = (clip, row, column): x - mean over the win_size rows of the symmetric-padded clip centred on row
+__global__ __launch_bounds__(256) void ss_cmvnw_mean_kernel(const float *__restrict__ x, float *__restrict__ ms, unsigned long long total,
+                                                            unsigned rows, unsigned cols, unsigned win)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const unsigned long long per_clip = static_cast<unsigned long long>(rows) * cols;
+    const unsigned long long clip = g / per_clip;
+    const unsigned rc = static_cast<unsigned>(g - clip * per_clip);
+    const unsigned i = rc / cols, c = rc - i * cols;
+    const float *src = x + clip * per_clip + c;
+    const long long pad = (win - 1) / 2;
+    double s = 0.0;
+    for (unsigned w = 0; w < win; ++w) s += static_cast<double>(src[static_cast<size_t>(sym_index(static_cast<long long>(i) + w - pad, rows)) * cols]);
+    ms[g] = static_cast<float>(static_cast<double>(src[static_cast<size_t>(i) * cols]) - s / win);
+}
+
+// cmvnw pass 2 (variance_normalization): ms / (population std of ms over the same symmetric window + 2^-30)
+__global__ __launch_bounds__(256) void ss_cmvnw_var_kernel(const float *__restrict__ ms, float *__restrict__ out, unsigned long long total,
+                                                           unsigned rows, unsigned cols, unsigned win)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const unsigned long long per_clip = static_cast<unsigned long long>(rows) * cols;
+    const unsigned long long clip = g / per_clip;
+    const unsigned rc = static_cast<unsigned>(g - clip * per_clip);
+    const unsigned i = rc / cols, c = rc - i * cols;
+    const float *src = ms + clip * per_clip + c;
+    const long long pad = (win - 1) / 2;
+    double s = 0.0, q = 0.0;
+    for (unsigned w = 0; w < win; ++w) s += static_cast<double>(src[static_cast<size_t>(sym_index(static_cast<long long>(i) + w - pad, rows)) * cols]);
+    const double m = s / win;
+    for (unsigned w = 0; w < win; ++w) {
+        const double d = static_cast<double>(src[static_cast<size_t>(sym_index(static_cast<long long>(i) + w - pad, rows)) * cols]) - m;
+        q += d * d;
+    }
+    out[g] = static_cast<float>(static_cast<double>(src[static_cast<size_t>(i) * cols]) / (sqrt(q / win) + kEps30));
+}
+
+// derivative along the FEATURE axis with edge clamping, literal reference arithmetic: sum_R (R f[c+R] - f[c-R]) / sum_R 2R^2
+__device__ __forceinline__ float deriv_at(const float *row, unsigned cols, unsigned c, unsigned dw, float inv_scale)
+{
+    float acc = 0.f;
+    for (unsigned R = 1; R <= dw; ++R) {
+        const unsigned hi = c + R < cols ? c + R : cols - 1;
+        const unsigned lo = c >= R ? c - R : 0;
+        acc += row[hi] * static_cast<float>(R) - row[lo];
+    }
+    return acc * inv_scale;
+}
+
+__global__ __launch_bounds__(256) void ss_derivative_kernel(const float *__restrict__ x, float *__restrict__ out, unsigned long long total,
+                                                            unsigned cols, unsigned dw, float inv_scale)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const unsigned long long r = g / cols;
+    const unsigned c = static_cast<unsigned>(g - r * cols);
+    out[g] = deriv_at(x + r * cols, cols, c, dw, inv_scale);
+}
+
+// cube[r][c][0..2] = (f, d1, d2), d1 = derivative(f, 2), d2 = derivative(d1, 2); d1 is recomputed for the 5 clamped neighbours
+__global__ __launch_bounds__(256) void ss_derivative_cube_kernel(const float *__restrict__ x, float *__restrict__ cube, unsigned long long total,
+                                                                 unsigned cols)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const unsigned long long r = g / cols;
+    const unsigned c = static_cast<unsigned>(g - r * cols);
+    const float *row = x + r * cols;
+    constexpr float inv10 = 1.0f / 10.0f;  // sum_{R=1,2} 2 R^2
+    float acc = 0.f;
+    for (unsigned R = 1; R <= 2; ++R) {
+        const unsigned hi = c + R < cols ? c + R : cols - 1;
+        const unsigned lo = c >= R ? c - R : 0;
+        acc += deriv_at(row, cols, hi, 2, inv10) * static_cast<float>(R) - deriv_at(row, cols, lo, 2, inv10);
+    }
+    cube[3 * g] = row[c];
+    cube[3 * g + 1] = deriv_at(row, cols, c, 2, inv10);
+    cube[3 * g + 2] = acc * inv10;
+}
+
+int hip_err(hipError_t e, const char *what) { return fail(SS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+
+unsigned blocks_for(unsigned long long n) { return static_cast<unsigned>((n + 255) / 256); }
+
+int check_shape(const void *a, const void *b, size_t batch, size_t rows, size_t cols)
+{
+    if (!a || !b) return fail(SS_ERR_ARG, "null buffer");
+    if (rows == 0 || cols == 0) return fail(SS_ERR_ARG, "empty feature matrix");
+    if (rows >= (1ull << 31) || cols >= (1ull << 31) || batch * rows * cols / 256 >= (1ull << 31)) return fail(SS_ERR_ARG, "feature block too large");
+    return SS_OK;
+}
+
+// host-pointer wrapper: upload, run the device entry point, download
+template <typename F>
+int via_device(const float *in, size_t n_in, float *out, size_t n_out, F &&run)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SS_ERR_HIP, "no usable HIP device: the speechsauce_amd path has no CPU fallback");
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), n_in * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), n_out * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, n_in * sizeof(float), hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? run(d_in, d_out) : hip_err(e, "host staging");
+    if (rc == SS_OK) {
+        e = hipMemcpy(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_err(e, "hipMemcpy D2H");
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+}  // namespace
+
+}  // namespace ss
+
+extern "C" {
+
+int ss_cmvn_batch_device(const float *d_vec, size_t batch, size_t rows, size_t cols, int variance_normalization, float *d_out,
+                         void *stream)
+{
+    int rc = ss::check_shape(d_vec, d_out, batch, rows, cols);
+    if (rc) return rc;
+    if (batch == 0) return SS_OK;
+    const unsigned long long n = static_cast<unsigned long long>(batch) * cols;
+    hipLaunchKernelGGL(ss::ss_cmvn_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_vec, d_out, n,
+                       static_cast<unsigned>(rows), static_cast<unsigned>(cols), variance_normalization);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_cmvn_kernel");
+}
+
+int ss_cmvnw_batch_device(const float *d_vec, size_t batch, size_t rows, size_t cols, size_t win_size, int variance_normalization,
+                          float *d_out, void *stream)
+{
+    int rc = ss::check_shape(d_vec, d_out, batch, rows, cols);
+    if (rc) return rc;
+    if (win_size % 2 != 1) return ss::fail(SS_ERR_BAD_CONFIG, "Windows size must be odd!");  // assert, processing.rs:327
+    if (win_size >= (1ull << 31)) return ss::fail(SS_ERR_ARG, "window too large");
+    if (batch == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned long long n = static_cast<unsigned long long>(batch) * rows * cols;
+    const unsigned r = static_cast<unsigned>(rows), c = static_cast<unsigned>(cols), w = static_cast<unsigned>(win_size);
+    if (!variance_normalization) {
+        hipLaunchKernelGGL(ss::ss_cmvnw_mean_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_vec, d_out, n, r, c, w);
+    } else {
+        // the second pass reads its neighbours' mean-subtracted values: they go through a stream-ordered scratch block
+        float *d_ms = nullptr;
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&d_ms), n * sizeof(float), s);
+        if (e != hipSuccess) return ss::hip_err(e, "hipMallocAsync");
+        hipLaunchKernelGGL(ss::ss_cmvnw_mean_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_vec, d_ms, n, r, c, w);
+        hipLaunchKernelGGL(ss::ss_cmvnw_var_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_ms, d_out, n, r, c, w);
+        e = hipFreeAsync(d_ms, s);
+        if (e != hipSuccess) return ss::hip_err(e, "hipFreeAsync");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_cmvnw kernels");
+}
+
+int ss_derivative_extraction_device(const float *d_feat, size_t rows, size_t cols, size_t delta_windows, float *d_out, void *stream)
+{
+    int rc = ss::check_shape(d_feat, d_out, 1, rows, cols);
+    if (rc) return rc;
+    if (delta_windows == 0 || delta_windows >= (1u << 20)) return ss::fail(SS_ERR_ARG, "delta_windows must be >= 1");  // scale = 0 in the reference
+    double scale = 0.0;
+    for (size_t R = 1; R <= delta_windows; ++R) scale += 2.0 * static_cast<double>(R) * static_cast<double>(R);
+    const unsigned long long n = static_cast<unsigned long long>(rows) * cols;
+    hipLaunchKernelGGL(ss::ss_derivative_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_feat, d_out, n,
+                       static_cast<unsigned>(cols), static_cast<unsigned>(delta_windows), static_cast<float>(1.0 / scale));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_derivative_kernel");
+}
+
+int ss_extract_derivative_feature_device(const float *d_feat, size_t rows, size_t cols, float *d_cube, void *stream)
+{
+    int rc = ss::check_shape(d_feat, d_cube, 1, rows, cols);
+    if (rc) return rc;
+    const unsigned long long n = static_cast<unsigned long long>(rows) * cols;
+    hipLaunchKernelGGL(ss::ss_derivative_cube_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_feat, d_cube,
+                       n, static_cast<unsigned>(cols));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_derivative_cube_kernel");
+}
+
+// ---- host-pointer variants (synchronous) ----
+
+int ss_cmvn(const float *vec, size_t rows, size_t cols, int variance_normalization, float *out)
+{
+    int rc = ss::check_shape(vec, out, 1, rows, cols);
+    if (rc) return rc;
+    return ss::via_device(vec, rows * cols, out, rows * cols, [&](const float *di, float *dout) {
+        int r = ss_cmvn_batch_device(di, 1, rows, cols, variance_normalization, dout, nullptr);
+        if (r == SS_OK && hipDeviceSynchronize() != hipSuccess) r = ss::fail(SS_ERR_HIP, "ss_cmvn: device error");
+        return r;
+    });
+}
+
+int ss_cmvnw(const float *vec, size_t rows, size_t cols, size_t win_size, int variance_normalization, float *out)
+{
+    int rc = ss::check_shape(vec, out, 1, rows, cols);
+    if (rc) return rc;
+    if (win_size % 2 != 1) return ss::fail(SS_ERR_BAD_CONFIG, "Windows size must be odd!");
+    return ss::via_device(vec, rows * cols, out, rows * cols, [&](const float *di, float *dout) {
+        int r = ss_cmvnw_batch_device(di, 1, rows, cols, win_size, variance_normalization, dout, nullptr);
+        if (r == SS_OK && hipDeviceSynchronize() != hipSuccess) r = ss::fail(SS_ERR_HIP, "ss_cmvnw: device error");
+        return r;
+    });
+}
+
+int ss_derivative_extraction(const float *feat, size_t rows, size_t cols, size_t delta_windows, float *out)
+{
+    int rc = ss::check_shape(feat, out, 1, rows, cols);
+    if (rc) return rc;
+    if (delta_windows == 0) return ss::fail(SS_ERR_ARG, "delta_windows must be >= 1");
+    return ss::via_device(feat, rows * cols, out, rows * cols, [&](const float *di, float *dout) {
+        int r = ss_derivative_extraction_device(di, rows, cols, delta_windows, dout, nullptr);
+        if (r == SS_OK && hipDeviceSynchronize() != hipSuccess) r = ss::fail(SS_ERR_HIP, "ss_derivative_extraction: device error");
+        return r;
+    });
+}
+
+int ss_extract_derivative_feature(const float *feat, size_t rows, size_t cols, float *cube)
+{
+    int rc = ss::check_shape(feat, cube, 1, rows, cols);
+    if (rc) return rc;
+    return ss::via_device(feat, rows * cols, cube, 3 * rows * cols, [&](const float *di, float *dout) {
+        int r = ss_extract_derivative_feature_device(di, rows, cols, dout, nullptr);
+        if (r == SS_OK && hipDeviceSynchronize() != hipSuccess) r = ss::fail(SS_ERR_HIP, "ss_extract_derivative_feature: device error");
+        return r;
+    });
+}
+
+}  // extern "C"

@@ -58,6 +58,10 @@ extern "C" {
     fn ss_mfcc_batch_device(cfg: *const SsConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
                             stream: *mut c_void) -> c_int;
     fn ss_preemphasis(x: *const f32, n: usize, shift: c_long, cof: f32, y: *mut f32) -> c_int;
+    fn ss_cmvn(vec: *const f32, rows: usize, cols: usize, variance_normalization: c_int, out: *mut f32) -> c_int;
+    fn ss_cmvnw(vec: *const f32, rows: usize, cols: usize, win_size: usize, variance_normalization: c_int, out: *mut f32) -> c_int;
+    fn ss_derivative_extraction(feat: *const f32, rows: usize, cols: usize, delta_windows: usize, out: *mut f32) -> c_int;
+    fn ss_extract_derivative_feature(feat: *const f32, rows: usize, cols: usize, cube: *mut f32) -> c_int;
     fn ss_last_error_string() -> *const c_char;
 }
 
@@ -237,4 +241,41 @@ pub fn preemphasis(signal: Array1<f32>, shift: isize, cof: f32) -> Array1<f32> {
     let mut y = Array1::<f32>::zeros(x.len());
     check(unsafe { ss_preemphasis(x.as_ptr(), x.len(), shift as c_long, cof, y.as_mut_ptr()) }).expect("preemphasis");
     y
+}
+
+/// processing.rs:265-300
+pub fn cmvn(vec: ArrayView2<f32>, variance_normalization: bool) -> Array2<f32> {
+    let x = vec.as_standard_layout();
+    let (rows, cols) = x.dim();
+    let mut out = Array2::<f32>::zeros((rows, cols));
+    check(unsafe { ss_cmvn(x.as_ptr(), rows, cols, variance_normalization as c_int, out.as_mut_ptr()) }).expect("cmvn");
+    out
+}
+
+/// processing.rs:315-371 (panics on an even `win_size`, like the reference's assert)
+pub fn cmvnw(vec: Array2<f32>, win_size: usize, variance_normalization: bool) -> Array2<f32> {
+    let x = vec.as_standard_layout();
+    let (rows, cols) = x.dim();
+    let mut out = Array2::<f32>::zeros((rows, cols));
+    check(unsafe { ss_cmvnw(x.as_ptr(), rows, cols, win_size, variance_normalization as c_int, out.as_mut_ptr()) })
+        .expect("Windows size must be odd!");
+    out
+}
+
+/// processing.rs:222-254
+pub fn derivative_extraction(feat: &Array2<f32>, delta_windows: usize) -> Array2<f32> {
+    let x = feat.as_standard_layout();
+    let (rows, cols) = x.dim();
+    let mut out = Array2::<f32>::zeros((rows, cols));
+    check(unsafe { ss_derivative_extraction(x.as_ptr(), rows, cols, delta_windows, out.as_mut_ptr()) }).expect("derivative_extraction");
+    out
+}
+
+/// feature.rs:253-269: N x M x 3 cube of static, first and second derivative features
+pub fn extract_derivative_feature(feature: Array2<f32>) -> Array3<f32> {
+    let x = feature.as_standard_layout();
+    let (rows, cols) = x.dim();
+    let mut cube = Array3::<f32>::zeros((rows, cols, 3));
+    check(unsafe { ss_extract_derivative_feature(x.as_ptr(), rows, cols, cube.as_mut_ptr()) }).expect("extract_derivative_feature");
+    cube
 }

@@ -20,7 +20,8 @@ import numpy as np
 from . import _lib
 from ._lib import SpeechSauceError, SsParams, make_params  # noqa: F401
 
-__all__ = ["mfcc", "mel_spectrogram", "preemphasis", "mfe", "mfcc_batch", "mfe_batch", "SpeechConfig",
+__all__ = ["mfcc", "mel_spectrogram", "preemphasis", "cmvn", "cmvnw", "derivative_extraction", "extract_derivative_feature",
+           "mfe", "mfcc_batch", "mfe_batch", "SpeechConfig",
            "SpeechSauceError"]
 
 
@@ -255,3 +256,72 @@ def preemphasis(signal, shift=1, cof=0.98):
     y = np.empty_like(x)
     _lib.check(lib.ss_preemphasis(x.ctypes.data, n, int(shift), float(cof), y.ctypes.data))
     return y
+
+
+# ---- post-processing on the feature matrix (processing.rs:222-371, feature.rs:253-269; `cmvn` is exported by the
+# reference's Python package, py lib.rs:217-224).  numpy [rows, cols] in -> numpy out; a ROCm tensor of shape
+# [rows, cols] or [batch, rows, cols] stays on the device (current stream). ----
+
+def _feature_matrix(vec, what):
+    if _is_torch(vec):
+        import torch
+
+        if vec.dtype != torch.float32:
+            raise TypeError(f"{what}: expected float32")
+        if vec.dim() not in (2, 3):
+            raise ValueError(f"{what}: expected a [rows, cols] or [batch, rows, cols] tensor")
+        if not vec.is_cuda:
+            return np.ascontiguousarray(vec.numpy()), False
+        return vec.contiguous(), True
+    arr = np.asarray(vec)
+    if arr.dtype != np.float32:
+        raise TypeError(f"{what}: expected float32 (the reference binding takes PyReadonlyArray2<f32>)")
+    if arr.ndim != 2:
+        raise ValueError(f"{what}: expected a 2-D [rows, cols] array")
+    return np.ascontiguousarray(arr), False
+
+
+def _post(vec, what, host_fn, dev_fn, out_tail=()):
+    x, on_device = _feature_matrix(vec, what)
+    if on_device:
+        import torch
+
+        batch = x.shape[0] if x.dim() == 3 else 1
+        rows, cols = x.shape[-2], x.shape[-1]
+        out = torch.empty(tuple(x.shape) + tuple(out_tail), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(dev_fn(x.data_ptr(), batch, rows, cols, out.data_ptr(), _stream_ptr()))
+        return out
+    if x.ndim == 3:  # CPU tensor with a batch axis: one matrix at a time through the host entry point
+        return np.stack([_post(m, what, host_fn, dev_fn, out_tail) for m in x])
+    out = np.empty(x.shape + tuple(out_tail), dtype=np.float32)
+    _lib.check(host_fn(x.ctypes.data, x.shape[0], x.shape[1], out.ctypes.data))
+    return out
+
+
+def cmvn(vec, variance_normalization=False):
+    """Global cepstral mean (and variance) normalisation, one observation per row (processing.rs:265-300)."""
+    lib, var = _lib.lib(), int(bool(variance_normalization))
+    return _post(vec, "cmvn", lambda p, r, c, o: lib.ss_cmvn(p, r, c, var, o),
+                 lambda p, b, r, c, o, s: lib.ss_cmvn_batch_device(p, b, r, c, var, o, s))
+
+
+def cmvnw(vec, win_size=301, variance_normalization=False):
+    """Sliding-window mean (and variance) normalisation over win_size rows (processing.rs:315-371)."""
+    lib, var, w = _lib.lib(), int(bool(variance_normalization)), int(win_size)
+    return _post(vec, "cmvnw", lambda p, r, c, o: lib.ss_cmvnw(p, r, c, w, var, o),
+                 lambda p, b, r, c, o, s: lib.ss_cmvnw_batch_device(p, b, r, c, w, var, o, s))
+
+
+def derivative_extraction(feat, delta_windows):
+    """Derivative features along the feature axis (processing.rs:222-254)."""
+    lib, dw = _lib.lib(), int(delta_windows)
+    return _post(feat, "derivative_extraction", lambda p, r, c, o: lib.ss_derivative_extraction(p, r, c, dw, o),
+                 lambda p, b, r, c, o, s: lib.ss_derivative_extraction_device(p, b * r, c, dw, o, s))
+
+
+def extract_derivative_feature(feature):
+    """[..., rows, cols] -> [..., rows, cols, 3]: static, first and second derivative features (feature.rs:253-269)."""
+    lib = _lib.lib()
+    return _post(feature, "extract_derivative_feature", lambda p, r, c, o: lib.ss_extract_derivative_feature(p, r, c, o),
+                 lambda p, b, r, c, o, s: lib.ss_extract_derivative_feature_device(p, b * r, c, o, s), out_tail=(3,))

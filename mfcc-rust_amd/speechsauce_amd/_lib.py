@@ -84,6 +84,14 @@ PROTOTYPES = {
     "ss_preemphasis_device": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp, C.c_void_p]),
     "ss_power_spectrum_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_stft_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_cmvn": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_int, _fp]),
+    "ss_cmvn_batch_device": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _fp, C.c_void_p]),
+    "ss_cmvnw": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _fp]),
+    "ss_cmvnw_batch_device": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _fp, C.c_void_p]),
+    "ss_derivative_extraction": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp]),
+    "ss_derivative_extraction_device": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_extract_derivative_feature": (C.c_int, [_fp, C.c_size_t, C.c_size_t, _fp]),
+    "ss_extract_derivative_feature_device": (C.c_int, [_fp, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_device_count": (C.c_int, [_P(C.c_int)]),
     "ss_set_device": (C.c_int, [C.c_int]),
     "ss_last_kernel_name": (C.c_char_p, []),
@@ -115,7 +123,7 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.ss_abi_version() != 1:
+    if handle.ss_abi_version() != 2:
         raise ImportError("libspeechsauce_amd.so ABI version mismatch")
     _lib = handle
     return _lib

@@ -203,6 +203,40 @@ def preemphasis(x, shift=1, cof=0.98):
     return y
 
 
+# ---- post-processing on the feature matrix (processing.rs:222-371, feature.rs:253-269) ----
+
+def cmvn(vec, variance_normalization=False):
+    v = np.ascontiguousarray(vec, dtype=np.float32)
+    out = np.empty(v.shape, dtype=np.float64)
+    _chk(lib().orc_cmvn(_ptr(v, C.c_float), C.c_size_t(v.shape[0]), C.c_size_t(v.shape[1]), C.c_int(int(variance_normalization)),
+                        _ptr(out, C.c_double)))
+    return out
+
+
+def cmvnw(vec, win_size=301, variance_normalization=False):
+    v = np.ascontiguousarray(vec, dtype=np.float32)
+    out = np.empty(v.shape, dtype=np.float64)
+    _chk(lib().orc_cmvnw(_ptr(v, C.c_float), C.c_size_t(v.shape[0]), C.c_size_t(v.shape[1]), C.c_size_t(win_size),
+                         C.c_int(int(variance_normalization)), _ptr(out, C.c_double)))
+    return out
+
+
+def derivative_extraction(feat, delta_windows):
+    f = np.ascontiguousarray(feat, dtype=np.float64)
+    out = np.empty(f.shape, dtype=np.float64)
+    _chk(lib().orc_derivative_extraction(_ptr(f, C.c_double), C.c_size_t(f.shape[0]), C.c_size_t(f.shape[1]),
+                                         C.c_size_t(delta_windows), _ptr(out, C.c_double)))
+    return out
+
+
+def extract_derivative_feature(feat):
+    f = np.ascontiguousarray(feat, dtype=np.float32)
+    out = np.empty(f.shape + (3,), dtype=np.float64)
+    _chk(lib().orc_extract_derivative_feature(_ptr(f, C.c_float), C.c_size_t(f.shape[0]), C.c_size_t(f.shape[1]),
+                                              _ptr(out, C.c_double)))
+    return out
+
+
 # ---- reference-shaped f32 port (timed CPU baseline) ----
 
 def port_mfcc(p, x):

@@ -230,3 +230,48 @@ def mel_spectrogram(p: Params, x: np.ndarray) -> np.ndarray:
     fb, _ = filterbank(p)
     out = np.einsum("ntf,mf->nmt", P, fb.astype(np.float64))
     return out[0] if one_d else out
+
+
+# ---- post-processing on the feature matrix, written with np.pad (the semantics the reference quotes, util.rs:108-124) ----
+
+def cmvn(vec: np.ndarray, variance_normalization: bool = False) -> np.ndarray:
+    """processing.rs:265-300."""
+    v = np.asarray(vec, dtype=np.float64)
+    ms = v - v.mean(axis=0, keepdims=True)
+    if variance_normalization:
+        return ms / (ms.std(axis=0, keepdims=True) + 2.0 ** -30)
+    return ms
+
+
+def cmvnw(vec: np.ndarray, win_size: int = 301, variance_normalization: bool = False) -> np.ndarray:
+    """processing.rs:315-371."""
+    if win_size % 2 != 1:
+        raise ValueError("Windows size must be odd!")
+    v = np.asarray(vec, dtype=np.float64)
+    pad = (win_size - 1) // 2
+    vp = np.pad(v, ((pad, pad), (0, 0)), "symmetric")
+    ms = np.stack([v[i] - vp[i:i + win_size].mean(axis=0) for i in range(v.shape[0])])
+    if not variance_normalization:
+        return ms
+    mp = np.pad(ms, ((pad, pad), (0, 0)), "symmetric")
+    return np.stack([ms[i] / (mp[i:i + win_size].std(axis=0) + 2.0 ** -30) for i in range(v.shape[0])])
+
+
+def derivative_extraction(feat: np.ndarray, delta_windows: int) -> np.ndarray:
+    """processing.rs:222-254 (literal: Range * f[c + Range] - f[c - Range], along the feature axis)."""
+    f = np.asarray(feat, dtype=np.float64)
+    cols = f.shape[1]
+    fp = np.pad(f, ((0, 0), (delta_windows, delta_windows)), "edge")
+    acc, scale, off = np.zeros_like(f), 0.0, delta_windows
+    for i in range(delta_windows):
+        r = i + 1
+        acc += fp[:, off + r:off + r + cols] * r - fp[:, off - r:off - r + cols]
+        scale += 2.0 * r ** 2
+    return acc / scale
+
+
+def extract_derivative_feature(feat: np.ndarray) -> np.ndarray:
+    """feature.rs:253-269."""
+    f = np.asarray(feat, dtype=np.float64)
+    d1 = derivative_extraction(f, 2)
+    return np.stack([f, d1, derivative_extraction(d1, 2)], axis=2)

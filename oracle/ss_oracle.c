@@ -246,6 +246,126 @@ static void rfft_f64(const double *x, size_t n, double *out_re, double *out_im, 
 /* ------------------------------------------------------------------------------------------ */
 /* Part 1: f64 oracle                                                                         */
 /* ------------------------------------------------------------------------------------------ */
+/* Post-processing on the feature matrix.  No golden vectors exist in the reference for these
+ * either ("parity unpinned"); the pads follow the numpy semantics the reference quotes in its comments
+ * (util.rs:108-124: np.pad 'symmetric' / 'edge'), the arithmetic follows the Rust expressions literally. */
+
+/* np.pad(..., 'symmetric') index map along an axis of length n: reflection including the edge sample, period 2n */
+static size_t sym_index(long p, size_t n)
+{
+    long period = 2 * (long)n;
+    long m = p % period;
+    if (m < 0) m += period;
+    return (size_t)(m < (long)n ? m : period - 1 - m);
+}
+
+/* processing.rs:265-300: column mean over the rows; optionally divide by (population std + 2^-30) */
+int orc_cmvn(const float *vec, size_t rows, size_t cols, int variance_normalization, double *out)
+{
+    if (rows == 0 || cols == 0) return ORC_ERR_ARG;
+    const double eps = 9.313225746154785e-10; /* 2f32.powf(-30.), processing.rs:266 */
+    for (size_t c = 0; c < cols; ++c) {
+        double mean = 0.0;
+        for (size_t r = 0; r < rows; ++r) mean += (double)vec[r * cols + c];
+        mean /= (double)rows;
+        double var = 0.0;
+        for (size_t r = 0; r < rows; ++r) {
+            double d = (double)vec[r * cols + c] - mean;
+            out[r * cols + c] = d;
+            var += d * d;
+        }
+        if (variance_normalization) {
+            /* std_axis(Axis(0), 0.) of the mean-subtracted matrix (its own mean is 0 up to rounding; ndarray subtracts it) */
+            double m2 = 0.0;
+            for (size_t r = 0; r < rows; ++r) m2 += out[r * cols + c];
+            m2 /= (double)rows;
+            var = 0.0;
+            for (size_t r = 0; r < rows; ++r) {
+                double d = out[r * cols + c] - m2;
+                var += d * d;
+            }
+            double sd = sqrt(var / (double)rows);
+            for (size_t r = 0; r < rows; ++r) out[r * cols + c] /= (sd + eps);
+        }
+    }
+    return ORC_OK;
+}
+
+/* processing.rs:315-371: sliding-window mean (and std) over win_size rows of the symmetric-padded matrix */
+int orc_cmvnw(const float *vec, size_t rows, size_t cols, size_t win_size, int variance_normalization, double *out)
+{
+    if (rows == 0 || cols == 0) return ORC_ERR_ARG;
+    if (win_size % 2 != 1) return ORC_ERR_BAD_CONFIG; /* assert!(win_size % 2 == 1), processing.rs:327 */
+    const double eps = 9.313225746154785e-10;
+    const long pad = (long)((win_size - 1) / 2);
+    double *ms = (double *)malloc(rows * cols * sizeof(double));
+    if (!ms) return ORC_ERR_ARG;
+    for (size_t i = 0; i < rows; ++i)
+        for (size_t c = 0; c < cols; ++c) {
+            double s = 0.0;
+            for (size_t w = 0; w < win_size; ++w) s += (double)vec[sym_index((long)i + (long)w - pad, rows) * cols + c];
+            ms[i * cols + c] = (double)vec[i * cols + c] - s / (double)win_size;
+        }
+    if (!variance_normalization) {
+        memcpy(out, ms, rows * cols * sizeof(double));
+    } else {
+        for (size_t i = 0; i < rows; ++i)
+            for (size_t c = 0; c < cols; ++c) {
+                double s = 0.0;
+                for (size_t w = 0; w < win_size; ++w) s += ms[sym_index((long)i + (long)w - pad, rows) * cols + c];
+                const double m = s / (double)win_size;
+                double v = 0.0;
+                for (size_t w = 0; w < win_size; ++w) {
+                    double d = ms[sym_index((long)i + (long)w - pad, rows) * cols + c] - m;
+                    v += d * d;
+                }
+                out[i * cols + c] = ms[i * cols + c] / (sqrt(v / (double)win_size) + eps);
+            }
+    }
+    free(ms);
+    return ORC_OK;
+}
+
+/* processing.rs:222-254, literally: edge pad along the FEATURE axis, dif_R = R * f[c + R] - f[c - R],
+ * out = sum_R dif_R / sum_R 2 R^2 */
+int orc_derivative_extraction(const double *feat, size_t rows, size_t cols, size_t delta_windows, double *out)
+{
+    if (rows == 0 || cols == 0 || delta_windows == 0) return ORC_ERR_ARG; /* scale = 0 -> division by zero */
+    double scale = 0.0;
+    for (size_t R = 1; R <= delta_windows; ++R) scale += 2.0 * (double)R * (double)R;
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) {
+            double acc = 0.0;
+            for (size_t R = 1; R <= delta_windows; ++R) {
+                size_t hi = c + R < cols ? c + R : cols - 1;
+                size_t lo = c >= R ? c - R : 0;
+                acc += feat[r * cols + hi] * (double)R - feat[r * cols + lo];
+            }
+            out[r * cols + c] = acc / scale;
+        }
+    return ORC_OK;
+}
+
+/* feature.rs:253-269: cube [rows x cols x 3] = (feature, derivative(feature, 2), derivative(that, 2)) */
+int orc_extract_derivative_feature(const float *feat, size_t rows, size_t cols, double *cube)
+{
+    if (rows == 0 || cols == 0) return ORC_ERR_ARG;
+    double *f0 = (double *)malloc(3 * rows * cols * sizeof(double));
+    if (!f0) return ORC_ERR_ARG;
+    double *d1 = f0 + rows * cols, *d2 = d1 + rows * cols;
+    for (size_t i = 0; i < rows * cols; ++i) f0[i] = (double)feat[i];
+    orc_derivative_extraction(f0, rows, cols, 2, d1);
+    orc_derivative_extraction(d1, rows, cols, 2, d2);
+    for (size_t i = 0; i < rows * cols; ++i) {
+        cube[3 * i] = f0[i];
+        cube[3 * i + 1] = d1[i];
+        cube[3 * i + 2] = d2[i];
+    }
+    free(f0);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 
 /* processing.rs:31-53: y[n] = x[n] - cof * x[(n - shift) mod L]  (np.roll semantics) */
 int orc_preemphasis(const float *x, size_t n, long shift, float cof, double *y)

@@ -94,6 +94,11 @@ int orc_stft(const orc_params *p, const float *x, size_t channels, size_t n,
 int orc_mel_spectrogram(const orc_params *p, const float *x, size_t channels, size_t n,
                         double *out /* ch x M x R */);
 int orc_preemphasis(const float *x, size_t n, long shift, float cof, double *y);
+/* post-processing (processing.rs:222-371, feature.rs:253-269); matrices row-major [rows x cols] */
+int orc_cmvn(const float *vec, size_t rows, size_t cols, int variance_normalization, double *out);
+int orc_cmvnw(const float *vec, size_t rows, size_t cols, size_t win_size, int variance_normalization, double *out);
+int orc_derivative_extraction(const double *feat, size_t rows, size_t cols, size_t delta_windows, double *out);
+int orc_extract_derivative_feature(const float *feat, size_t rows, size_t cols, double *cube);
 
 /* Reference-shaped single-thread f32 port: pass-for-pass the structure of the Rust code
  * (materialised frames, pad copy, per-row FFT, magnitude pass, dense mel GEMM, full DCT).

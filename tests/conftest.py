@@ -27,3 +27,14 @@ def sslib():
     from speechsauce_amd import _lib
 
     return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def ss():
+    """The Python front on a real device (GPU tests only)."""
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import speechsauce_amd
+
+    return speechsauce_amd

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(sslib):
     for n in names:
         assert hasattr(sslib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in the Python front"
-    assert sslib.ss_abi_version() == 1
+    assert sslib.ss_abi_version() == 2
 
 
 def test_params_struct_matches_header(sslib):

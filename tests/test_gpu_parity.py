@@ -28,16 +28,6 @@ def _rel(got, want):
     return float(np.abs(got.astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
 
 
-@pytest.fixture(scope="module")
-def ss():
-    import torch
-
-    assert torch.cuda.is_available(), "GPU tests need a HIP device"
-    import speechsauce_amd
-
-    return speechsauce_amd
-
-
 def _cfg(ss, **kw):
     from speechsauce_amd import SpeechConfig, make_params
 
