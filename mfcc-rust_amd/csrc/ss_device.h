@@ -76,6 +76,7 @@ struct Fast512Args {
     //   twn   [8][16]  float2  exp(-2 pi i (j + 16 r) / 512)
     //   cos   [16][52]         row c: cos(pi c (2 m_q + 1) / 2M) for q = slot*16 + lane < 48 (0 for unused q / c >= n_ceps)
     //   start [3][16]  int32   first P bin of the filter owned by (slot, lane)
+    //   filt  [3][16]  int32   its filter index (-1: none)
     //   melw  [16][mel_wpitch] lane row: taps of slot 0, 1, 2, each zero-padded to a multiple of 4
     const float *tab;
     int32_t mel_wpitch;  // floats per lane row = 4 * (mel_q4[0] + mel_q4[1] + mel_q4[2])
@@ -83,13 +84,17 @@ struct Fast512Args {
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
-    float *out;
+    float *out;          // MFCC [frames x n_ceps], or (out_mfe) mel energies [frames x n_filters]
+    float *out_energy;   // out_mfe: frame energies [frames] (feature.rs:216-219)
+    int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)
     unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
     // filled by launch_mfcc_c256: floor(x / n_frames) = umulhi(x, nf_magic) >> nf_shift for x < 2^31 (nf_magic = 0: divide)
     uint32_t nf_magic, nf_shift;
 };
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+// whether the kernel has an mfe-output build for this shape (the default bank at flen 320)
+bool mfcc_c256_has_mfe(const Fast512Args &a);
 
 // Arguments of the second-generation fft_points = 512 MFCC kernel (ss_mfcc512_mfma.hip).
 struct Fast512MArgs {

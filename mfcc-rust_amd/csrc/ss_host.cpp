@@ -270,14 +270,17 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
             f.tab[L::kTwn + (r * 16 + j) * 2 + 1] = t.tw_n[2 * (j + 16 * r) + 1];
         }
     int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
     int32_t off = 0;
     for (int s = 0; s < 3; ++s) {
         const int32_t span = 4 * f.q4[s];
         for (int j = 0; j < 16; ++j) {
             const size_t q = static_cast<size_t>(s) * 16 + j;
             start[q] = 0;
+            filt[q] = -1;
             if (q >= M) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
             const int32_t m = order[q];
+            filt[q] = m;
             int32_t st = t.bank.start[m];
             const int32_t len = t.bank.len[m];
             // the lock-step loop reads `span` taps: keep st + span inside the 132-bin row

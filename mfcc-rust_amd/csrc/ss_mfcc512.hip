@@ -150,7 +150,7 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0>
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, bool MFE = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
     constexpr bool PREFETCH = WAVES <= 12;  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
@@ -207,6 +207,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     int st2 = wave * kWaveFloats + kPOff + f * kPRow + s_start[32 + j];
     asm volatile("" : "+v"(st0), "+v"(st1), "+v"(st2));
     const float *smem_f = reinterpret_cast<const float *>(smem);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const int fidx0 = MFE ? s_filt[j] : 0, fidx1 = MFE ? s_filt[16 + j] : 0, fidx2 = MFE ? s_filt[32 + j] : 0;
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
     float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512): resident when the register budget allows (<= 3 waves per SIMD)
@@ -312,6 +314,25 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             m1 = mel_slot_loop(w4 + a.mel_q4[0], smem_f + st1, a.mel_q4[1]);
             m2 = mel_slot_loop(w4 + a.mel_q4[0] + a.mel_q4[1], smem_f + st2, a.mel_q4[2]);
         }
+        if (MFE) {
+            // mfe (feature.rs:200-233): the mel energies and the frame energy themselves, in filter order
+            const float hs = hscale32 * (1.0f / kTwo32);
+            const unsigned gf = quad * 4 + f;
+            if (gf < total) {
+                float *row = a.out + static_cast<unsigned long long>(gf) * a.n_filters;
+                const float e0 = m0 * hs, e1 = m1 * hs, e2 = m2 * hs;
+                if (fidx0 >= 0) row[fidx0] = e0 == 0.f ? kEpsF : e0;
+                if (fidx1 >= 0) row[fidx1] = e1 == 0.f ? kEpsF : e1;
+                if (fidx2 >= 0) row[fidx2] = e2 == 0.f ? kEpsF : e2;
+                if (j == 0) {
+                    const float en = energy * (1.0f / kTwo32);  // exact: power-of-two scaling
+                    a.out_energy[gf] = en;
+                }
+            }
+            wave_order();
+            quad = next;
+            continue;
+        }
         m0 *= hscale32;  // mel energies * 2^32 (see ln_scaled)
         m1 *= hscale32;
         m2 *= hscale32;
@@ -407,6 +428,7 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
     static const char *res_env = std::getenv("SS_RES");  // A/B knob: register-resident tables (bit 0 cosines, bit 1 twiddles)
     const int res = res_env ? std::atoi(res_env) : 2;  // twiddles resident: 140 VGPRs, 0.7 us faster than 0; 3 spills
     if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
+        if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, true>, "ss_mfcc_c256<10,exact,bank421,mfe>");
         if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
         if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
         if (WAVES <= 12 && res == 3) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 3>, "ss_mfcc_c256<10,exact,bank421,res3>");
@@ -426,8 +448,14 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
 
 }  // namespace
 
+bool mfcc_c256_has_mfe(const Fast512Args &a)
+{
+    return a.flen == 320 && a.spectrum_exponent != 2 && a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1 && a.n_filters <= 40;
+}
+
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
+    if (a.out_mfe && !mfcc_c256_has_mfe(a)) return hipErrorInvalidValue;
     // 12 waves per CU (3 per SIMD, <= 168 VGPRs, 138 KB of LDS): measured equal to 14 and 16 and 8 % faster than 8
     static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
     if (w && std::atoi(w) == 8) return launch_w<8>(a, stream, num_cus, info);

@@ -81,6 +81,24 @@ def test_mfe(ss, oracle):
     assert _rel(feat, wf) <= 1e-5 and _rel(en, we) <= 1e-5
 
 
+def test_mfe_batch_fast_path(ss, oracle, sslib):
+    """mfe (feature.rs:200-233) over a batch: served by the mfe-output build of the 512-point kernel."""
+    import torch
+
+    x = _signal(8, (96, 16000))
+    feat, en = ss.mfe_batch(torch.from_numpy(x).cuda(), 16000)
+    assert feat.shape == (96, 98, 40) and en.shape == (96, 98)
+    assert b"mfe" in sslib.ss_last_kernel_name()
+    p = oracle.make_params(**CFG1)
+    for b in (0, 50, 95):
+        wf, we = oracle.mfe(p, x[b])
+        assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL
+    # all-zero clip: every value is exactly f32::EPSILON (functions.rs:66-71)
+    z = torch.zeros((3, 16000), dtype=torch.float32, device="cuda")
+    feat, en = ss.mfe_batch(z, 16000)
+    assert torch.all(feat == 1.1920929e-7) and torch.all(en == 1.1920929e-7)
+
+
 def test_cfg2_batch_1024(ss, oracle):
     import torch
 
