@@ -88,6 +88,43 @@ def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
     }
 
 
+def cpu_baseline_all_cores(kind, pkw, n_samples, budget_s=6.0):
+    """The same port on every host core at once (ctypes releases the GIL): what a data-parallel CPU run of the reference
+    path could reach on this box.  Extra information next to the contract's single-thread `cpu_baseline`."""
+    import threading
+
+    import numpy as np
+
+    import oracle_c
+
+    p = oracle_c.make_params(**pkw)
+    fn = oracle_c.port_mfcc if kind == "mfcc" else oracle_c.port_mel_spectrogram
+    rows_per_clip = oracle_c.num_frames(p, n_samples) if kind == "mfcc" else oracle_c.stft_rows(p, n_samples)[0]
+    cores = os.cpu_count() or 1
+    pool = (np.random.default_rng(4321).standard_normal((16, n_samples)) * 0.1).astype(np.float32)
+    fn(p, pool[0])
+    counts = [0] * cores
+    stop = time.perf_counter() + budget_s
+
+    def work(i):
+        k = 0
+        while time.perf_counter() < stop:
+            fn(p, pool[(i + k) % 16])
+            k += 1
+        counts[i] = k
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.perf_counter() - t0
+    clips = sum(counts)
+    return {"value": clips * rows_per_clip / el, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{clips} clips in {el:.1f} s on {cores} threads (one per logical core), same port as cpu_baseline"}
+
+
 def load_traffic(kernel_name, workload):
     """HBM bytes per launch from the committed PMC profile of this kernel+workload (or None)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -265,6 +302,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kind, pkw, n_samples, args.cpu_seconds)
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(kind, pkw, n_samples, args.cpu_seconds / 2)
         print(json.dumps(res), flush=True)
 
     if world > 1:
