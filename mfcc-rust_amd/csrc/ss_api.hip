@@ -314,7 +314,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     ss::LaunchInfo info{};
     // fft_points = 2048 mel spectrogram: the wave-private kernel when its layout assumptions hold
     static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
-    if (!force_generic && out_kind == ss::OUT_MEL && cfg->mel2048.ok && (a.hop % 2 == 0) && (ld % 2 == 0) &&
+    if (!force_generic && out_kind == ss::OUT_MEL && cfg->mel2048.ok && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mel2048Args m{};
         m.x = d_x;

@@ -122,21 +122,25 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
                 const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
                 float2 v[32];
-                if (inside) {
-                    // whole window inside the clip: 8-byte loads at constant offsets from one base
-                    const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
+                const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
+                if (__all(inside)) {
+                    // both windows of the pair inside the clip: 8-byte loads at constant offsets from one base
 #pragma unroll
                     for (int e = 0; e < 32; ++e) v[e] = src[32 * e];
                 } else {
-                    // clip edges (zero initial state, zero padding of the last chunk) and inactive rows
+                    // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows.  start and
+                    // n_samples are even here, so a sample pair is inside or outside as a whole, and because the pair index
+                    // grows with e the valid ones form one range [e_lo, e_hi) per lane: loads outside it are masked off
+                    // (the address may lie before the clip; it is never dereferenced) and read as zero.
+                    const int base = start + 2 * j;
+                    const int n = static_cast<int>(a.n_samples);
+                    int e_lo = base >= 0 ? 0 : (63 - base) >> 6;
+                    int e_hi = base >= n ? 0 : min(32, (n - base + 63) >> 6);
+                    if (!active) e_hi = 0;
 #pragma unroll
                     for (int e = 0; e < 32; ++e) {
-                        const int idx = start + 2 * (j + 32 * e);
                         float2 s = make_float2(0.f, 0.f);
-                        if (active) {
-                            if (idx >= 0 && idx < static_cast<int>(a.n_samples)) s.x = xc[idx];
-                            if (idx + 1 >= 0 && idx + 1 < static_cast<int>(a.n_samples)) s.y = xc[idx + 1];
-                        }
+                        if (e >= e_lo && e < e_hi) s = src[32 * e];
                         v[e] = s;
                     }
                 }
