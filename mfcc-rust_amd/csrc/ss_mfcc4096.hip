@@ -33,6 +33,7 @@ constexpr int kClsStride = 16 * 34 + 8;    // float2 per class slice: +8 keeps t
 constexpr int kExFloats = (kClsStride + 16 * 34) * 2;  // exchange region (two classes x half the columns, 8768 B); P row + ln(mel) row reuse it
 constexpr bool kDbgStages = false;        // true: SS_DEBUG_ROWS also dumps frame 0's registers after each FFT stage (tools/dbg4096.py)
 constexpr int kFRowOff = L::kPRow;        // ln(mel) row [256] behind the P row (both inside the exchange region)
+constexpr int kSRowOff = kFRowOff + 256;  // s[128] and d[128] rows of the symmetric DCT, behind the ln(mel) row
 
 __device__ __forceinline__ void wave_order_h()
 {
@@ -280,26 +281,38 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int i = lane; i < 256; i += 64) a.dbg[1028 + i] = frow[i];
         }
 
-        // ---- DCT-II (feature.rs:120-123) with cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M = 256 ----
+        // ---- DCT-II (feature.rs:120-123) with cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M = 256:
+        // the wave first forms s[m] = L[m] + L[255-m] and d[m] = L[m] - L[255-m] once (2 + 2 values per lane); an even
+        // coefficient is then a 128-term product with s, an odd one with d -- half the FMAs and half the LDS reads ----
+        {
+            float *srow = wbase + kSRowOff, *drow = wbase + kSRowOff + 128;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int m = lane + 64 * h2;
+                const float lo = frow[m], hi = frow[255 - m];
+                srow[m] = lo + hi;
+                drow[m] = lo - hi;
+            }
+        }
+        wave_order_h();
         if (lane < Cc) {
-            const float par = (lane & 1) ? -1.f : 1.f;
+            const float4 *r4 = reinterpret_cast<const float4 *>(wbase + kSRowOff + ((lane & 1) ? 128 : 0));
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosPitch);
             float acc = 0.f;
 #pragma unroll 1
-            for (int g = 0; g < 4; ++g) {  // 8 float4s (32 filters from each end) per batch of fetches
-                float4 lo[8], hi[8], cq[8];
+            for (int g = 0; g < 2; ++g) {  // 16 float4s per batch of fetches
+                float4 rq[16], cq[16];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    lo[i] = *reinterpret_cast<const float4 *>(&frow[4 * (8 * g + i)]);
-                    hi[i] = *reinterpret_cast<const float4 *>(&frow[252 - 4 * (8 * g + i)]);
-                    cq[i] = c4[8 * g + i];
+                for (int i = 0; i < 16; ++i) {
+                    rq[i] = r4[16 * g + i];
+                    cq[i] = c4[16 * g + i];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc = fmaf(fmaf(par, hi[i].w, lo[i].x), cq[i].x, acc);
-                    acc = fmaf(fmaf(par, hi[i].z, lo[i].y), cq[i].y, acc);
-                    acc = fmaf(fmaf(par, hi[i].y, lo[i].z), cq[i].z, acc);
-                    acc = fmaf(fmaf(par, hi[i].x, lo[i].w), cq[i].w, acc);
+                for (int i = 0; i < 16; ++i) {
+                    acc = fmaf(rq[i].x, cq[i].x, acc);
+                    acc = fmaf(rq[i].y, cq[i].y, acc);
+                    acc = fmaf(rq[i].z, cq[i].z, acc);
+                    acc = fmaf(rq[i].w, cq[i].w, acc);
                 }
             }
             // scaling + column-0 replacement (feature.rs:126-146)
