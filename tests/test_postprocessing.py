@@ -69,7 +69,37 @@ def test_known_answers(oracle):
         oracle.cmvnw(v, 4, False)
 
 
+def _golden_cases():
+    from golden.make_golden_post import CASES, matrix
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_post_v1.npz"))
+    return CASES, matrix, g
+
+
+def _check_against_golden(fns, tol):
+    cases, matrix, g = _golden_cases()
+    for name, (seed, shape) in cases.items():
+        v = matrix(seed, shape)
+        for var in (0, 1):
+            assert _rel(fns.cmvn(v, bool(var)), g[f"{name}/cmvn{var}"]) <= tol
+            for win in (3, 31, 301):
+                assert _rel(fns.cmvnw(v, win, bool(var)), g[f"{name}/cmvnw{var}_{win}"]) <= tol, (name, var, win)
+        for dw in (1, 2, 9):
+            assert _rel(fns.derivative_extraction(v, dw), g[f"{name}/deriv{dw}"]) <= tol
+        assert _rel(fns.extract_derivative_feature(v), g[f"{name}/cube"]) <= tol
+
+
+def test_oracle_against_committed_fixtures(oracle):
+    """tests/golden/golden_post_v1.npz (np.pad-based restatement) pins the C oracle."""
+    _check_against_golden(oracle, 1e-12)
+
+
 # ------------------------------------------------------------------------------------------------------- HIP path (GPU)
+
+@pytest.mark.gpu
+def test_gpu_against_committed_fixtures(ss):
+    _check_against_golden(ss, RTOL)
+
 
 @pytest.mark.gpu
 def test_cmvn_gpu(ss, oracle):
