@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the workload's)")
     ap.add_argument("--gather", action="store_true", help="add an overlapped RCCL all-gather of the outputs")
+    ap.add_argument("--params", default="", help='JSON dict of extra ss_params switches, e.g. \'{"mfcc_window": 1, "preemph_coef": 0.97}\' (not the headline config)')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -172,6 +173,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     desc, pkw, n_samples, clips, kind = WORKLOADS[args.workload]
+    if args.params:
+        pkw = dict(pkw, **json.loads(args.params))
+        desc += " + " + args.params
     strong = args.workload == "cfg4"
     if args.clips:
         clips = args.clips

@@ -146,9 +146,10 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // the mfe-output build of that kernel exists for the default bank shape only
     const bool mfe_shape = a.flen == 320 && a.spectrum_exponent != 2 && cfg->fast.q4[0] == 4 && cfg->fast.q4[1] == 2 &&
                            cfg->fast.q4[2] == 1 && a.n_filters <= 40;
+    const bool front = a.preemph != 0.0f || a.window != nullptr;  // optional window / fused pre-emphasis: default-bank build only
     const bool fast_ok = !force_generic && cfg->fast.ok && (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape)) &&
-                         a.frame_mode == ss::FRAME_NORMAL &&
-                         a.preemph == 0.0f && a.window == nullptr && (a.flen % 2 == 0) && (a.step % 2 == 0) &&
+                         (!front || mfe_shape) && a.frame_mode == ss::FRAME_NORMAL &&
+                         (a.flen % 2 == 0) && (a.step % 2 == 0) &&
                          (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
     // SS_MFCC512_VARIANT=mfma selects the block-sparse f32-MFMA mel+DCT build (ss_mfcc512_mfma.hip) for A/B runs
     static const char *variant = std::getenv("SS_MFCC512_VARIANT");
@@ -156,7 +157,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool fits32 = static_cast<unsigned long long>(batch) * T < 0xffffffffull;
     static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only: per-wave realtime stamps of ONE launch
     static bool dbg_done = false;
-    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC) {
+    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC && !front) {
         ss::Fast512MArgs f{};
         f.x = d_x;
         f.ld = ld;
@@ -208,6 +209,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out = out0;
         f.out_energy = out1;
         f.out_mfe = out_kind == ss::OUT_MFE;
+        f.win_floats = a.window ? cfg->fast.win_floats : 0;
+        f.preemph = a.preemph;
+        f.preemph_shift = a.preemph_shift;
         if (dbg_path && !dbg_done && !f.out_mfe) {
             dbg_done = true;
             const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;

@@ -87,13 +87,17 @@ struct Fast512Args {
     float *out;          // MFCC [frames x n_ceps], or (out_mfe) mel energies [frames x n_filters]
     float *out_energy;   // out_mfe: frame energies [frames] (feature.rs:216-219)
     int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)
+    // optional front end (the switches of ss_params; default off, as in the reference's mfcc):
+    int32_t win_floats;     // > 0: frame window [flen] behind the mel rows of the table block
+    float preemph;          // != 0: y[n] = x[n] - preemph * x[(n - preemph_shift) mod n_samples] (processing.rs:31-53) on load
+    uint32_t preemph_shift;
     unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
     // filled by launch_mfcc_c256: floor(x / n_frames) = umulhi(x, nf_magic) >> nf_shift for x < 2^31 (nf_magic = 0: divide)
     uint32_t nf_magic, nf_shift;
 };
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
-// whether the kernel has an mfe-output build for this shape (the default bank at flen 320)
+// whether the kernel has an mfe-output / windowed / pre-emphasised build for this shape (the default bank at flen 320)
 bool mfcc_c256_has_mfe(const Fast512Args &a);
 
 // Arguments of the second-generation fft_points = 512 MFCC kernel (ss_mfcc512_mfma.hip).

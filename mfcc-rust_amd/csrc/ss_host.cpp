@@ -294,6 +294,12 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
         }
         off += span;
     }
+    if (!t.window_mfcc.empty()) {  // optional frame window (mfcc_window switch), read as sample pairs by the kernel
+        f.win_floats = static_cast<int32_t>((t.window_mfcc.size() + 3) / 4 * 4);
+        const size_t base = f.tab.size();
+        f.tab.resize(base + static_cast<size_t>(f.win_floats), 0.0f);
+        for (size_t i = 0; i < t.window_mfcc.size(); ++i) f.tab[base + i] = t.window_mfcc[i];
+    }
     f.ok = true;
 }
 

@@ -75,6 +75,7 @@ struct Fast512Tables {
     std::vector<float> tab;
     int32_t q4[3] = {0, 0, 0};  // taps / 4 per slot
     int32_t wpitch = 0;
+    int32_t win_floats = 0;     // frame window appended behind the mel rows (kMelW + 16 * wpitch): flen floats padded to 4, 0 = rectangular
 };
 void build_fast512(const HostTables &t, Fast512Tables &f);
 

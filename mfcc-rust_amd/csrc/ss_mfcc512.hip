@@ -85,8 +85,9 @@ __device__ __forceinline__ float ln_scaled(float xs)
 }
 
 // Issues the loads of one quad; returns this lane's frame index within its clip.
-template <int NE, bool EXACT>
-__device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE])
+template <int NE, bool EXACT, bool PRE>
+__device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE],
+                                              float2 (&pin)[PRE ? NE : 1])
 {
     const unsigned q4 = quad * 4;                                // uniform
     const unsigned fl = min(static_cast<unsigned>(f), total - 1 - q4);  // lanes past the last frame redo it
@@ -110,6 +111,15 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
         const int n = j + 16 * e;
         if (EXACT) vin[e] = src[n];
         else vin[e] = 2 * n < static_cast<int>(a.flen) ? src[n] : make_float2(0.f, 0.f);
+        if (PRE) {
+            // pre-emphasis taps x[(i - shift) mod L] of the sample pair (processing.rs:31-53, np.roll semantics over the clip)
+            const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+            const unsigned i0 = t * a.step + 2 * n, sh = a.preemph_shift % a.n_samples;
+            const unsigned j0 = i0 >= sh ? i0 - sh : i0 + a.n_samples - sh;
+            const unsigned j1 = i0 + 1 >= sh ? i0 + 1 - sh : i0 + 1 + a.n_samples - sh;
+            if (EXACT || 2 * n < static_cast<int>(a.flen)) pin[e] = make_float2(xc[j0], xc[j1]);
+            else pin[e] = make_float2(0.f, 0.f);
+        }
     }
     return t;
 }
@@ -150,10 +160,11 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, bool MFE = false>
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, bool MFE = false, int FRONT = 0>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
-    constexpr bool PREFETCH = WAVES <= 12;  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
+    constexpr bool PREFETCH = WAVES <= 12;
+    constexpr bool WIN = (FRONT & 1) != 0, PRE = (FRONT & 2) != 0;  // optional frame window / fused pre-emphasis  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const float *s_cos = s_tab + L::kCos;
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
     const float *s_melw = s_tab + L::kMelW;
-    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 16 * a.mel_wpitch);
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kMelW + 16 * a.mel_wpitch);  // WIN: window sample pairs
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0));
 
     // quad range of this workgroup (contiguous, balanced to within one quad)
     const unsigned total = a.batch * a.n_frames;
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 
     // the table block arrives as float4s, global layout == LDS layout
     {
-        const int n4 = (L::kMelW + 16 * a.mel_wpitch) / 4;
+        const int n4 = (L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0)) / 4;
         for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) *s_next = q_lo + WAVES;
         if (j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
@@ -191,8 +203,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     // first quad of this wave; its loads are in flight across the barrier
     unsigned quad = q_lo + wave;
     float2 vin[NE];
+    float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
-    if (quad < q_hi) t_next = load_quad<NE, EXACT>(a, quad, total, f, j, vin);
+    if (quad < q_hi) t_next = load_quad<NE, EXACT, PRE>(a, quad, total, f, j, vin, pin);
 
     const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
@@ -237,11 +250,19 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         next = __builtin_amdgcn_readfirstlane(next);
         ++n_done;
 
-        if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT>(a, quad, total, f, j, vin);
+        if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE>(a, quad, total, f, j, vin, pin);
         const unsigned t_cur = t_next;
         float2 v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
+        for (int e = 0; e < 16; ++e) {
+            float2 s = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
+            if (PRE && e < NE) s = make_float2(fmaf(-a.preemph, pin[e].x, s.x), fmaf(-a.preemph, pin[e].y, s.y));
+            if (WIN && e < NE) {
+                const float2 w = s_win[j + 16 * e];
+                s = make_float2(s.x * w.x, s.y * w.y);
+            }
+            v[e] = s;
+        }
 
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
         fft16_reg(v);
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         wave_order();
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
-        if (PREFETCH && next < q_hi) t_next = load_quad<NE, EXACT>(a, next, total, f, j, vin);
+        if (PREFETCH && next < q_hi) t_next = load_quad<NE, EXACT, PRE>(a, next, total, f, j, vin, pin);
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -403,7 +424,7 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             a.nf_shift = l - 1;
         }
     }
-    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloats + L::kMelW + 16 * a.mel_wpitch) * sizeof(float) + 16;
+    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloats + L::kMelW + 16 * a.mel_wpitch + (a.win_floats > 0 ? a.win_floats : 0)) * sizeof(float) + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
     if (total == 0) return hipSuccess;
@@ -428,6 +449,18 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
     static const char *res_env = std::getenv("SS_RES");  // A/B knob: register-resident tables (bit 0 cosines, bit 1 twiddles)
     const int res = res_env ? std::atoi(res_env) : 2;  // twiddles resident: 140 VGPRs, 0.7 us faster than 0; 3 spills
     if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
+        const int front = (a.win_floats > 0 ? 1 : 0) | (a.preemph != 0.0f ? 2 : 0);
+        if (front) {
+            if (WAVES > 12) return hipErrorInvalidValue;
+            if (a.out_mfe) {
+                if (front == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, true, 1>, "ss_mfcc_c256<10,exact,bank421,mfe,win>");
+                if (front == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 0, true, 2>, "ss_mfcc_c256<10,exact,bank421,mfe,pre>");
+                return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 0, true, 3>, "ss_mfcc_c256<10,exact,bank421,mfe,win,pre>");
+            }
+            if (front == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, false, 1>, "ss_mfcc_c256<10,exact,bank421,win>");
+            if (front == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, false, 2>, "ss_mfcc_c256<10,exact,bank421,pre>");
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, false, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
+        }
         if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, true>, "ss_mfcc_c256<10,exact,bank421,mfe>");
         if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
         if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
@@ -455,7 +488,8 @@ bool mfcc_c256_has_mfe(const Fast512Args &a)
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    if (a.out_mfe && !mfcc_c256_has_mfe(a)) return hipErrorInvalidValue;
+    // mfe output, frame window and pre-emphasis exist for the default-bank build only
+    if ((a.out_mfe || a.win_floats > 0 || a.preemph != 0.0f) && !mfcc_c256_has_mfe(a)) return hipErrorInvalidValue;
     // 12 waves per CU (3 per SIMD, <= 168 VGPRs, 138 KB of LDS): measured equal to 14 and 16 and 8 % faster than 8
     static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
     if (w && std::atoi(w) == 8) return launch_w<8>(a, stream, num_cus, info);

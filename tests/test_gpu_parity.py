@@ -181,6 +181,27 @@ def test_switches(ss, oracle):
     assert _rel(got, want) <= RTOL
 
 
+def test_front_end_fast_path(ss, oracle, sslib):
+    """Frame window and fused pre-emphasis (the north-star's "Hann window + pre-emphasis framing loop") are served by
+    builds of the 512-point kernel, for mfcc and mfe, over batches whose quads span clip boundaries."""
+    import torch
+
+    x = _signal(14, (21, 16000))
+    xd = torch.from_numpy(x).cuda()
+    for sw, tag in [(dict(mfcc_window="hann"), b"win"), (dict(preemph_coef=0.97), b"pre"),
+                    (dict(mfcc_window="vorbis", preemph_coef=0.9, preemph_shift=3), b"win,pre")]:
+        got = ss.mfcc_batch(xd, 16000, **sw).cpu().numpy()
+        name = sslib.ss_last_kernel_name()
+        assert name.startswith(b"ss_mfcc_c256<") and tag in name, name
+        p = oracle.make_params(**CFG1, **sw)
+        for b in (0, 10, 20):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
+        feat, en = ss.mfe_batch(xd, 16000, **sw)
+        assert b"mfe" in sslib.ss_last_kernel_name() and tag in sslib.ss_last_kernel_name()
+        wf, we = oracle.mfe(p, x[20])
+        assert _rel(feat[20].cpu().numpy(), wf) <= RTOL and _rel(en[20].cpu().numpy(), we) <= RTOL
+
+
 def test_literal_framing_known_answer(ss, oracle):
     """processing.rs:110-120 as written copies nothing for > 2 frames: output is signal-independent."""
     x = _signal(10, 16000)
