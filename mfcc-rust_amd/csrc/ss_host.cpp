@@ -364,9 +364,11 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
     constexpr int32_t kRow = 516;       // P bins a tap may touch: 0..512 plus three zero pad bins
     std::vector<int32_t> order(M);
     for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
+    // taps are read as aligned float4s of the P row: a filter's span starts at its first bin rounded down to a multiple of 4
+    auto alen = [&](int32_t m) { return t.bank.len[m] ? (t.bank.start[m] & 3) + t.bank.len[m] : 0; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return alen(a) > alen(b); });
     int32_t maxlen[4] = {0, 0, 0, 0};
-    for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], t.bank.len[order[q]]);
+    for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], alen(order[q]));
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
@@ -398,11 +400,13 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
             if (q >= M) continue;
             const int32_t m = order[q];
             filt[q] = m;
-            int32_t st = t.bank.start[m];
             const int32_t len = t.bank.len[m];
-            int32_t shift = 0;
-            if (st + span > kRow) shift = st + span - kRow;
-            st -= shift;
+            int32_t shift = len ? (t.bank.start[m] & 3) : 0;
+            int32_t st = len ? t.bank.start[m] - shift : 0;
+            if (st + span > kRow) {  // keep the span inside the row (both are multiples of 4)
+                shift += st + span - kRow;
+                st = kRow - span;
+            }
             start[q] = st;
             for (int32_t i = 0; i < len; ++i)
                 f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];

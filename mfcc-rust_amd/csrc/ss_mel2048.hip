@@ -43,15 +43,33 @@ __device__ __forceinline__ float bperm_m(int addr, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-__device__ __forceinline__ float mel_slot(const float4 *w4, const float *p, int q4)
+// One mel slot: q4 aligned float4s of weights against the same span of the P row (the host rounds a filter's first bin down
+// to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip per four taps.
+__device__ __forceinline__ float mel_slot(const float4 *w4, const float4 *p4, int q4)
 {
     float acc = 0.f;
-    for (int i = 0; i < q4; ++i) {
-        const float4 w = w4[i];
-        acc = fmaf(w.x, p[4 * i], acc);
-        acc = fmaf(w.y, p[4 * i + 1], acc);
-        acc = fmaf(w.z, p[4 * i + 2], acc);
-        acc = fmaf(w.w, p[4 * i + 3], acc);
+    int i = 0;
+    for (; i + 4 <= q4; i += 4) {
+        float4 w[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = w4[i + u];
+            t[u] = p4[i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = fmaf(w[u].x, t[u].x, acc);
+            acc = fmaf(w[u].y, t[u].y, acc);
+            acc = fmaf(w[u].z, t[u].z, acc);
+            acc = fmaf(w[u].w, t[u].w, acc);
+        }
+    }
+    for (; i < q4; ++i) {
+        const float4 w = w4[i], t = p4[i];
+        acc = fmaf(w.x, t.x, acc);
+        acc = fmaf(w.y, t.y, acc);
+        acc = fmaf(w.z, t.z, acc);
+        acc = fmaf(w.w, t.w, acc);
     }
     return acc;
 }
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     int off = 0;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float m = mel_slot(w4 + off, prow + st[s], a.mel_q4[s]);
+                        const float m = mel_slot(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                         off += a.mel_q4[s];
                     }
