@@ -372,6 +372,7 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
+    if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the lanes' ds_read_b128 of their rows spread over all banks
     if (f.wpitch > 256) return;
     f.tab.assign(static_cast<size_t>(L::kMelW) + 32 * f.wpitch, 0.0f);
     const double pi = 3.14159265358979323846;
@@ -435,6 +436,7 @@ void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f)
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
+    if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the lanes' ds_read_b128 of their rows spread over all banks
     if (f.wpitch > 128) return;
     const size_t melw0 = static_cast<size_t>(L::kCos) + Cc * L::kCosPitch;
     f.tab.assign(melw0 + 64 * static_cast<size_t>(f.wpitch), 0.0f);
