@@ -77,6 +77,7 @@ __device__ __forceinline__ float mel_slot(const float4 *w4, const float4 *p4, in
 template <int kWavesM>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
+    constexpr bool PREFETCH_M = kWavesM <= 8;  // the next unit's samples are requested while the current one is in its second pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -124,7 +125,42 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
     const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
     const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    // (clip, row) of this half-wave within a unit, and the loads of its window: functions.rs:137-151, the window covers the
+    // last W samples ending at chunk r + n_pad
+    auto load_unit = [&](unsigned un, float2 (&vv)[32]) {
+        const unsigned clip = un / pairs;
+        const int r = static_cast<int>(un - clip * pairs) * 2 + half;
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+        const bool active = r < Rreal;
+        const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
+        const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
+        const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
+        if (__all(inside)) {
+            // both windows of the pair inside the clip: 8-byte loads at constant offsets from one base
+#pragma unroll
+            for (int e = 0; e < 32; ++e) vv[e] = src[32 * e];
+        } else {
+            // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows.  start and
+            // n_samples are even here, so a sample pair is inside or outside as a whole, and because the pair index
+            // grows with e the valid ones form one range [e_lo, e_hi) per lane: loads outside it are masked off
+            // (the address may lie before the clip; it is never dereferenced) and read as zero.
+            const int base = start + 2 * j;
+            const int n = static_cast<int>(a.n_samples);
+            int e_lo = base >= 0 ? 0 : (63 - base) >> 6;
+            int e_hi = base >= n ? 0 : min(32, (n - base + 63) >> 6);
+            if (!active) e_hi = 0;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                float2 s = make_float2(0.f, 0.f);
+                if (e >= e_lo && e < e_hi) s = src[32 * e];
+                vv[e] = s;
+            }
+        }
+    };
+
     unsigned unit = u_lo + wave;
+    float2 v[32];
+    if (unit < u_hi) load_unit(unit, v);
     while (unit < u_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);
@@ -133,35 +169,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
             {
                 const unsigned clip = unit / pairs;
                 const int r = static_cast<int>(unit - clip * pairs) * 2 + half;
-                const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
-                const bool active = r < Rreal;
                 const bool in_rows = r < R;
-                // functions.rs:137-151: window over the last W samples ending at chunk r + n_pad
-                const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
-                const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
-                float2 v[32];
-                const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
-                if (__all(inside)) {
-                    // both windows of the pair inside the clip: 8-byte loads at constant offsets from one base
-#pragma unroll
-                    for (int e = 0; e < 32; ++e) v[e] = src[32 * e];
-                } else {
-                    // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows.  start and
-                    // n_samples are even here, so a sample pair is inside or outside as a whole, and because the pair index
-                    // grows with e the valid ones form one range [e_lo, e_hi) per lane: loads outside it are masked off
-                    // (the address may lie before the clip; it is never dereferenced) and read as zero.
-                    const int base = start + 2 * j;
-                    const int n = static_cast<int>(a.n_samples);
-                    int e_lo = base >= 0 ? 0 : (63 - base) >> 6;
-                    int e_hi = base >= n ? 0 : min(32, (n - base + 63) >> 6);
-                    if (!active) e_hi = 0;
-#pragma unroll
-                    for (int e = 0; e < 32; ++e) {
-                        float2 s = make_float2(0.f, 0.f);
-                        if (e >= e_lo && e < e_hi) s = src[32 * e];
-                        v[e] = s;
-                    }
-                }
 #pragma unroll
                 for (int e = 0; e < 32; ++e) {
                     const float2 w = s_win[j + 32 * e];
@@ -199,6 +207,8 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     }
                 }
                 wave_order_m();
+                // the window registers are dead now: the next unit's samples load into them while this one is finished
+                if (PREFETCH_M && next < u_hi) load_unit(next, v);
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {  // two twiddles per ds_read_b128: W^(j(2p+1)), W^(j(2p+2))
                     const float4 w2 = s_tw2[p * 32 + j];
@@ -248,6 +258,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 wave_order_m();
             }
         }
+        if (!PREFETCH_M && next < u_hi) load_unit(next, v);
         unit = next;
     }
 }
