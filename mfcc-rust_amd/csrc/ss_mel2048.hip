@@ -232,8 +232,9 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         const float2 w = s_twn[q * 32 + j];
                         const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
                         const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
-                        const float2 wd = cmul(w, d);
-                        const float xr = s.x + wd.y, xi = s.y - wd.x;  // 2 X[k]
+                        // 2 X[k] = s - i w d: two chained FMAs per component
+                        const float xr = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
+                        const float xi = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
                         prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
                     }
                 }
