@@ -389,6 +389,29 @@ def test_cfg5_full_batch(ss, oracle):
         assert _rel(a[b].cpu().numpy(), oracle.mfcc(p, x[b])) <= RTOL
 
 
+def test_cfg4_corpus_properties(ss, oracle):
+    """BASELINE config 4 at full size (360 000 x 1 s clips, one launch): the corpus is 7 distinct clips repeated, so the
+    feature block must repeat bit-exactly with period 7 (large-batch indexing: 35 M frames, 23 GB of input), and the
+    first period must match the oracle."""
+    import torch
+
+    base = _signal(44, (7, 16000))
+    n = 360_000
+    idx = torch.arange(n, device="cuda") % 7
+    x = torch.from_numpy(base).cuda()[idx]  # [360000, 16000]
+    out = ss.mfcc_batch(x, 16000)
+    del x
+    assert out.shape == (n, 98, 13)
+    first = out[:7]
+    # 360 000 = 7 * 51 428 + 4
+    body = out[: 7 * 51_428].view(51_428, 7, 98, 13)
+    assert bool((body == first.unsqueeze(0)).all())
+    assert bool((out[7 * 51_428:] == first[:4]).all())
+    p = oracle.make_params(**CFG1)
+    for b in range(7):
+        assert _rel(first[b].cpu().numpy(), oracle.mfcc(p, base[b])) <= RTOL
+
+
 def test_kernel_variants_agree(ss):
     """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
     the variant is chosen once per process from the environment)."""
