@@ -6,6 +6,8 @@ ill-posed).
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -410,6 +412,40 @@ def test_cfg4_corpus_properties(ss, oracle):
     p = oracle.make_params(**CFG1)
     for b in range(7):
         assert _rel(first[b].cpu().numpy(), oracle.mfcc(p, base[b])) <= RTOL
+
+
+def test_cpp_mirror_parity(tmp_path, oracle):
+    """The header-only C++ mirror of the crate's API (include/speechsauce_amd.hpp), built with plain g++ against the
+    library: mfcc -> cmvn on a seeded clip, compared with the oracle."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    x = _signal(51, 16000)
+    x.tofile(tmp_path / "x.f32")
+    src = tmp_path / "t.cpp"
+    src.write_text(
+        '#include "speechsauce_amd.hpp"\n#include <cstdio>\n'
+        "int main(int argc, char **argv) {\n"
+        "  std::vector<float> x(16000); FILE *f = std::fopen(argv[1], \"rb\");\n"
+        "  if (!f || std::fread(x.data(), 4, x.size(), f) != x.size()) return 2; std::fclose(f);\n"
+        "  speechsauce::SpeechConfig cfg = speechsauce::SpeechConfigBuilder(16000).build();\n"
+        "  auto m = speechsauce::mfcc(x, cfg);\n"
+        "  auto n = speechsauce::cmvn(m.data, m.rows, m.cols, true);\n"
+        "  f = std::fopen(argv[2], \"wb\"); std::fwrite(m.data.data(), 4, m.data.size(), f); std::fwrite(n.data(), 4, n.size(), f);\n"
+        "  std::fclose(f); return m.rows == 98 && m.cols == 13 ? 0 : 3; }\n")
+    libdir = os.path.join(root, "mfcc-rust_amd", "lib")
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-L", libdir, "-lspeechsauce_amd",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    subprocess.run([str(exe), str(tmp_path / "x.f32"), str(tmp_path / "o.f32")], check=True)
+    o = np.fromfile(tmp_path / "o.f32", dtype=np.float32)
+    m, n = o[:98 * 13].reshape(98, 13), o[98 * 13:].reshape(98, 13)
+    want = oracle.mfcc(oracle.make_params(**CFG1), x)
+    assert _rel(m, want) <= RTOL
+    assert _rel(n, oracle.cmvn(m, True)) <= RTOL
 
 
 def test_kernel_variants_agree(ss):
