@@ -318,7 +318,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     ss::LaunchInfo info{};
     // fft_points = 2048 mel spectrogram: the wave-private kernel when its layout assumptions hold
     static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
-    if (!force_generic && out_kind == ss::OUT_MEL && cfg->mel2048.ok && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
+    if (!force_generic && (out_kind == ss::OUT_MEL || out_kind == ss::OUT_STFT) && cfg->mel2048.ok && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mel2048Args m{};
         m.x = d_x;
@@ -335,6 +335,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         for (int s = 0; s < 4; ++s) m.mel_q4[s] = cfg->mel2048.q4[s];
         m.n_filters = a.n_filters;
         m.out = out0;
+        m.out_stft = out_kind == ss::OUT_STFT;
         hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, "launch_mel_c1024");
         g_last_kernel = info.kernel_name;

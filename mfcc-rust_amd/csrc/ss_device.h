@@ -138,7 +138,8 @@ struct Mel2048Args {
     int32_t mel_wpitch;  // floats per lane weight row
     int32_t mel_q4[4];   // taps / 4 per slot
     uint32_t n_filters;
-    float *out;  // [batch][n_filters][rows]
+    float *out;       // [batch][n_filters][rows], or (out_stft) [batch][rows][1025][2]
+    int32_t out_stft; // 1: write the scaled complex spectrum stft2 returns (functions.rs:86-123) instead of the mel rows
 };
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

@@ -74,7 +74,7 @@ __device__ __forceinline__ float mel_slot(const float4 *w4, const float4 *p4, in
     return acc;
 }
 
-template <int kWavesM>
+template <int kWavesM, bool STFT>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
     constexpr bool PREFETCH_M = kWavesM <= 8;  // the next unit's samples are requested while the current one is in its second pass
@@ -217,7 +217,12 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 }
                 fft_reg<32>(u);  // u[r] = Z[j + 32 r]
 
-                // ---- untangle the bins the bank can touch: k = j + 32 r, r < 16, and k = 512 ----
+                // ---- untangle: k = j + 32 r, r < 16 (and its mirror 1024 - k for the stft output), and k = 512 ----
+                // stft output (functions.rs:86-123, :166-169): X[k] * wnorm for all 1025 bins of the row, interleaved re, im;
+                // lanes of a half-wave write 256 contiguous bytes per register on both sides of the spectrum
+                float2 *srow = nullptr;
+                if (STFT && in_rows) srow = reinterpret_cast<float2 *>(a.out) + (static_cast<unsigned long long>(clip) * R + r) * 1025ull;
+                const float cs = 0.5f * a.scale;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
                     float2 zcs[8];
@@ -235,12 +240,30 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         // 2 X[k] = s - i w d: two chained FMAs per component
                         const float xr = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
                         const float xi = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
-                        prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
+                        if (STFT) {
+                            if (srow) {
+                                srow[j + 32 * q] = make_float2(cs * xr, cs * xi);
+                                // 2 conj X[1024 - k] = 2 s - 2 X[k]
+                                srow[1024 - j - 32 * q] = make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
+                            }
+                        } else {
+                            prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
+                        }
                     }
                 }
                 if (j == 0) {
                     const float2 z = u[16];  // X[512] = conj Z[512]
-                    prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
+                    if (STFT) {
+                        if (srow) srow[512] = make_float2(a.scale * z.x, -a.scale * z.y);
+                    } else {
+                        prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
+                    }
+                }
+                if (STFT) {
+                    wave_order_m();
+                    if (!PREFETCH_M && next < u_hi) load_unit(next, v);
+                    unit = next;
+                    continue;
                 }
                 if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
                 wave_order_m();
@@ -275,12 +298,14 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
     unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c1024<kWavesM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    if (info) *info = LaunchInfo{"ss_mel_c1024", grid, static_cast<unsigned>(kWavesM * 64), lds};
-    hipLaunchKernelGGL(ss_mel_c1024<kWavesM>, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
-    return hipGetLastError();
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kWavesM * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    return a.out_stft ? go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>") : go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
 }
 
 }  // namespace

@@ -161,6 +161,20 @@ def test_stft_stage(ss, oracle, sslib):
     g = got[..., 0] + 1j * got[..., 1]
     assert np.abs(g - want).max() <= 1e-5 * np.abs(want).max()
     assert np.all(g[:, Rreal:] == 0)
+    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<stft>"
+    # an odd number of rows (the last row pair is half empty) and a batch whose units span clip boundaries
+    x = _signal(71, (37, 16100))
+    R, Rreal = cfg.stft_rows(16100)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.full((37, R, 1025, 2), 7.0, dtype=torch.float32, device="cuda")
+    _lib.check(sslib.ss_stft_device(cfg.handle, xd.data_ptr(), 37, 16100, 16100, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    g = got[..., 0] + 1j * got[..., 1]
+    for b in (0, 18, 36):
+        want = oracle.stft(oracle.make_params(**CFG3), x[b:b + 1])[0]
+        assert np.abs(g[b] - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.all(g[:, Rreal:] == 0)
 
 
 def test_preemphasis(ss, oracle):
