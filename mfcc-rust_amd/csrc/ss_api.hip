@@ -147,7 +147,8 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool mfe_shape = a.flen == 320 && a.spectrum_exponent != 2 && cfg->fast.q4[0] == 4 && cfg->fast.q4[1] == 2 &&
                            cfg->fast.q4[2] == 1 && a.n_filters <= 40;
     const bool front = a.preemph != 0.0f || a.window != nullptr;  // optional window / fused pre-emphasis: default-bank build only
-    const bool fast_ok = !force_generic && cfg->fast.ok && (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape)) &&
+    const bool fast_ok = !force_generic && cfg->fast.ok &&
+                         (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape) || (out_kind == ss::OUT_POWER && mfe_shape && !front)) &&
                          (!front || mfe_shape) && a.frame_mode == ss::FRAME_NORMAL &&
                          (a.flen % 2 == 0) && (a.step % 2 == 0) &&
                          (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
@@ -208,7 +209,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.dc_elimination = a.dc_elimination;
         f.out = out0;
         f.out_energy = out1;
-        f.out_mfe = out_kind == ss::OUT_MFE;
+        f.out_mfe = out_kind == ss::OUT_MFE ? 1 : (out_kind == ss::OUT_POWER ? 2 : 0);
         f.win_floats = a.window ? cfg->fast.win_floats : 0;
         f.preemph = a.preemph;
         f.preemph_shift = a.preemph_shift;

@@ -86,7 +86,8 @@ struct Fast512Args {
     int32_t dc_elimination;
     float *out;          // MFCC [frames x n_ceps], or (out_mfe) mel energies [frames x n_filters]
     float *out_energy;   // out_mfe: frame energies [frames] (feature.rs:216-219)
-    int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)
+    int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233);
+                         // 2: stop after the spectrum and write power_spectrum's rows [frames x 257] (processing.rs:179-181)
     // optional front end (the switches of ss_params; default off, as in the reference's mfcc):
     int32_t win_floats;     // > 0: frame window [flen] behind the mel rows of the table block
     float preemph;          // != 0: y[n] = x[n] - preemph * x[(n - preemph_shift) mod n_samples] (processing.rs:31-53) on load

@@ -160,10 +160,11 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, bool MFE = false, int FRONT = 0>
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, int OUTK = 0, int FRONT = 0>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
     constexpr bool PREFETCH = WAVES <= 12;
+    constexpr bool MFE = OUTK == 1, PWR = OUTK == 2;  // output: 0 MFCC, 1 mfe's (features, energy), 2 the power_spectrum rows
     constexpr bool WIN = (FRONT & 1) != 0, PRE = (FRONT & 2) != 0;  // optional frame window / fused pre-emphasis  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -294,6 +295,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 #pragma unroll
         for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         float esum = 0.f;
+        // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
+        // per register and frame on either side of the spectrum
+        float *pw_row = nullptr;
+        const float hs_pw = hscale32 * (1.0f / kTwo32);
+        if (PWR) {
+            const unsigned gfp = quad * 4 + f;
+            if (gfp < total) pw_row = a.out + static_cast<unsigned long long>(gfp) * 257ull;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float2 zk = u[r];
@@ -309,6 +318,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
             const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);  // unscaled; hscale is applied to the sums below
             const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+            if (PWR) {
+                if (pw_row) {
+                    pw_row[j + 16 * r] = hs_pw * pa;
+                    pw_row[256 - j - 16 * r] = hs_pw * pb;
+                }
+                continue;
+            }
             prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70)
             esum += pa + pb;
         }
@@ -317,8 +333,17 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             const float2 z = u[8];
             const float n = 4.f * (z.x * z.x + z.y * z.y);
             const float p128 = POW2 ? n : __builtin_amdgcn_sqrtf(n);
-            prow[128] = p128;
-            esum += p128;
+            if (PWR) {
+                if (pw_row) pw_row[128] = hs_pw * p128;
+            } else {
+                prow[128] = p128;
+                esum += p128;
+            }
+        }
+        if (PWR) {
+            wave_order();
+            quad = next;
+            continue;
         }
         float energy = hscale32 * row16_sum(esum);      // E * 2^32
         energy = energy == 0.f ? kEpsF * kTwo32 : energy;  // zero_handling, feature.rs:219
@@ -450,18 +475,22 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
     const int res = res_env ? std::atoi(res_env) : 2;  // twiddles resident: 140 VGPRs, 0.7 us faster than 0; 3 spills
     if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
         const int front = (a.win_floats > 0 ? 1 : 0) | (a.preemph != 0.0f ? 2 : 0);
+        if (a.out_mfe == 2) {
+            if (front || WAVES > 12) return hipErrorInvalidValue;
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 2>, "ss_mfcc_c256<10,exact,power>");
+        }
         if (front) {
             if (WAVES > 12) return hipErrorInvalidValue;
             if (a.out_mfe) {
-                if (front == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, true, 1>, "ss_mfcc_c256<10,exact,bank421,mfe,win>");
-                if (front == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 0, true, 2>, "ss_mfcc_c256<10,exact,bank421,mfe,pre>");
-                return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 0, true, 3>, "ss_mfcc_c256<10,exact,bank421,mfe,win,pre>");
+                if (front == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 1, 1>, "ss_mfcc_c256<10,exact,bank421,mfe,win>");
+                if (front == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 0, 1, 2>, "ss_mfcc_c256<10,exact,bank421,mfe,pre>");
+                return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 0, 1, 3>, "ss_mfcc_c256<10,exact,bank421,mfe,win,pre>");
             }
-            if (front == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, false, 1>, "ss_mfcc_c256<10,exact,bank421,win>");
-            if (front == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, false, 2>, "ss_mfcc_c256<10,exact,bank421,pre>");
-            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, false, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
+            if (front == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 1>, "ss_mfcc_c256<10,exact,bank421,win>");
+            if (front == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 2>, "ss_mfcc_c256<10,exact,bank421,pre>");
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
         }
-        if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, true>, "ss_mfcc_c256<10,exact,bank421,mfe>");
+        if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 1>, "ss_mfcc_c256<10,exact,bank421,mfe>");
         if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
         if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
         if (WAVES <= 12 && res == 3) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 3>, "ss_mfcc_c256<10,exact,bank421,res3>");

@@ -73,6 +73,14 @@ def test_power_spectrum_stage(ss, oracle, sslib):
     p = oracle.make_params(**CFG1)
     for b in range(3):
         assert _rel(P[b].cpu().numpy(), oracle.power_spectrum(p, x[b])) <= 1e-5
+    assert b"power" in sslib.ss_last_kernel_name()  # the power-spectrum build of the 512-point kernel
+    # same rows through the generic kernel's configuration space (power = 2 switch)
+    cfg2 = _cfg(ss, **CFG1, spectrum_exponent=2)
+    P.fill_(7.0)
+    _lib.check(sslib.ss_power_spectrum_batch_device(cfg2.handle, xd.data_ptr(), 3, 16000, 16000, P.data_ptr(), None))
+    torch.cuda.synchronize()
+    p2 = oracle.make_params(**CFG1, spectrum_exponent=2)
+    assert _rel(P[1].cpu().numpy(), oracle.power_spectrum(p2, x[1])) <= 1e-5
 
 
 def test_mfe(ss, oracle):
