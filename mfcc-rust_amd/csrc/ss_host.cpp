@@ -294,6 +294,9 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
         }
         off += span;
     }
+    if (M == 40)  // half rows for the symmetric DCT of the default filter count
+        for (size_t c = 0; c < Cc; ++c)
+            for (size_t m = 0; m < 20; ++m) f.tab[L::kCosH + c * 20 + m] = t.dct[c * M + m];
     if (!t.window_mfcc.empty()) {  // optional frame window (mfcc_window switch), read as sample pairs by the kernel
         f.win_floats = static_cast<int32_t>((t.window_mfcc.size() + 3) / 4 * 4);
         const size_t base = f.tab.size();

@@ -65,7 +65,8 @@ constexpr int kTwn = kTw2 + 8 * 64;      // [8][16] float2
 constexpr int kCos = kTwn + 8 * 32;      // [16][52]
 constexpr int kStart = kCos + 16 * 52;   // [3][16] int32
 constexpr int kFilt = kStart + 48;       // [3][16] int32: filter index of (slot, lane), -1 if none (mfe output order)
-constexpr int kMelW = kFilt + 48;        // [16][pitch]
+constexpr int kCosH = kFilt + 48;        // [16][20]: row c: cos(pi c (2m+1) / 80), m < 20, natural order (40 filters: symmetric DCT)
+constexpr int kMelW = kCosH + 16 * 20;   // [16][pitch]
 }  // namespace fast512_layout
 
 // Filters sorted by tap count and dealt to 3 slots x 16 lanes so the lock-step tap loops are short;

@@ -222,7 +222,17 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     asm volatile("" : "+v"(st0), "+v"(st1), "+v"(st2));
     const float *smem_f = reinterpret_cast<const float *>(smem);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
-    const int fidx0 = MFE ? s_filt[j] : 0, fidx1 = MFE ? s_filt[16 + j] : 0, fidx2 = MFE ? s_filt[32 + j] : 0;
+    constexpr bool SYM = (RES & 4) != 0;  // 40 filters: DCT against sum/difference rows with the half cosine row in registers
+    const int fidx0 = (MFE || SYM) ? s_filt[j] : 0, fidx1 = (MFE || SYM) ? s_filt[16 + j] : 0, fidx2 = (MFE || SYM) ? s_filt[32 + j] : 0;
+    float4 ch[SYM ? 5 : 1];
+    if (SYM) {
+        const float4 *h4 = reinterpret_cast<const float4 *>(s_tab + L::kCosH + j * 20);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ch[i] = h4[i];
+    }
+    // SYM: where this lane's three ln(mel) values go in the natural-order row (slots without a filter go to the pad entries)
+    float *fr0 = frow + (fidx0 >= 0 ? fidx0 : 47), *fr1 = frow + (fidx1 >= 0 ? fidx1 : 47), *fr2 = frow + (fidx2 >= 0 ? fidx2 : 47);
+    float *sd = wbase + 192 + f * 40;  // s[20] = L[m] + L[39-m], d[20] = L[m] - L[39-m] of this frame
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
     float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512): resident when the register budget allows (<= 3 waves per SIMD)
@@ -382,13 +392,42 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         m0 *= hscale32;  // mel energies * 2^32 (see ln_scaled)
         m1 *= hscale32;
         m2 *= hscale32;
+        float acc = 0.f;
+        if (SYM) {
+            // ---- DCT-II with cos(pi c (2(39-m)+1)/80) = (-1)^c cos(pi c (2m+1)/80): natural-order row, then the sum and
+            // difference rows once per frame; an even coefficient is a 20-term product with s, an odd one with d ----
+            fr0[0] = ln_scaled(m0 == 0.f ? kEpsF * kTwo32 : m0);
+            fr1[0] = ln_scaled(m1 == 0.f ? kEpsF * kTwo32 : m1);
+            fr2[0] = ln_scaled(m2 == 0.f ? kEpsF * kTwo32 : m2);
+            wave_order();
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int m = j + 16 * h2;
+                if (m < 20) {
+                    const float lo = frow[m], hi = frow[39 - m];
+                    sd[m] = lo + hi;
+                    sd[20 + m] = lo - hi;
+                }
+            }
+            wave_order();
+            const float4 *r4 = reinterpret_cast<const float4 *>(sd + ((j & 1) ? 20 : 0));
+            float4 rq[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) rq[i] = r4[i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                acc = fmaf(rq[i].x, ch[i].x, acc);
+                acc = fmaf(rq[i].y, ch[i].y, acc);
+                acc = fmaf(rq[i].z, ch[i].z, acc);
+                acc = fmaf(rq[i].w, ch[i].w, acc);
+            }
+        } else {
         frow[j] = ln_scaled(m0 == 0.f ? kEpsF * kTwo32 : m0);
         frow[16 + j] = ln_scaled(m1 == 0.f ? kEpsF * kTwo32 : m1);
         frow[32 + j] = ln_scaled(m2 == 0.f ? kEpsF * kTwo32 : m2);
         wave_order();
 
         // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 48-entry row ----
-        float acc = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // NQ float4s of the (slot, lane)-ordered row carry filters; two batches of fetches
             constexpr int HB = NQ / 2;
@@ -405,6 +444,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 acc = fmaf(lq[i].z, cq[i].z, acc);
                 acc = fmaf(lq[i].w, cq[i].w, acc);
             }
+        }
         }
         // ---- scaling + column-0 replacement (feature.rs:126-146) and the store ----
         {
@@ -472,7 +512,7 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
     const bool pow2 = a.spectrum_exponent == 2;
     const bool b421 = a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1;
     static const char *res_env = std::getenv("SS_RES");  // A/B knob: register-resident tables (bit 0 cosines, bit 1 twiddles)
-    const int res = res_env ? std::atoi(res_env) : 2;  // twiddles resident: 140 VGPRs, 0.7 us faster than 0; 3 spills
+    int res = res_env ? std::atoi(res_env) : 6;  // 2: twiddles resident (140 VGPRs, 0.7 us faster than 0; 3 spills); 6: + symmetric DCT (165 VGPRs, another 1.2 %)
     if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
         const int front = (a.win_floats > 0 ? 1 : 0) | (a.preemph != 0.0f ? 2 : 0);
         if (a.out_mfe == 2) {
@@ -491,6 +531,8 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
         }
         if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 1>, "ss_mfcc_c256<10,exact,bank421,mfe>");
+        if (WAVES <= 12 && res == 6 && a.n_filters == 40) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 6>, "ss_mfcc_c256<10,exact,bank421,sym>");
+        if (res == 6) res = 2;  // the symmetric DCT is written for exactly 40 filters
         if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
         if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
         if (WAVES <= 12 && res == 3) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 3>, "ss_mfcc_c256<10,exact,bank421,res3>");
