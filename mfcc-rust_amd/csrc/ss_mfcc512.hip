@@ -10,8 +10,8 @@
 //     exchange is private to a wave (LDS operations of one wave execute in order), so the main loop has
 //     NO workgroup barrier.  Each frame has a 2304-B slot: ds_write_b64 scatter to
 //     (n1,k1) -> 34*(n1>>1) + 2*k1 + (n1&1), read back with 8 ds_read_b128 per lane; conflict-free on
-//     both sides (2304 B = 9 bank rows keeps the b128 lane groups of neighbouring frames apart).  Zero padding is compile-time (template NE: a 320-sample frame fills
-//     10 of the 16 first-pass inputs).
+//     both sides (2304 B = 9 bank rows keeps the b128 lane groups of neighbouring frames apart).  Zero padding
+//     is compile-time (template NE: a 320-sample frame fills 10 of the 16 first-pass inputs).
 //   * The real-FFT untangle needs Z[256-k], which sits in lane 16-j, register 15-r: fetched with
 //     ds_bpermute_b32 (LDS crossbar, no memory round trip).
 //   * |X|/N for bins 0..128 goes to a P row in LDS (the mel bank ends at bin (F+1)/2, feature.rs:69-70);
@@ -23,8 +23,15 @@
 //     the VALU (measured: a VALU wave and an f32-MFMA wave on one SIMD take the SUM of their times),
 //     so a block-dense product costs 8x the sparse one (tools/ubench/mfma_valu_overlap.hip; the
 //     MFMA build of this kernel is kept as ss_mfcc512_mfma.hip for the A/B).
-//   * DCT-II: lane c < n_ceps accumulates its coefficient from the 48-entry log-mel row (ds_read_b128
-//     broadcasts) against its own cosine row (ds_read_b128, pitch 52 floats: conflict-free).
+//   * DCT-II: with 40 filters the log-mel row is written in filter order, each frame forms s[m] = L[m] + L[39-m]
+//     and d[m] = L[m] - L[39-m] once, and lane c < n_ceps multiplies 20 terms of s (even c) or d (odd c) with its
+//     half cosine row held in registers (template RES bit 2).  Other filter counts: 48-entry (slot, lane)-ordered
+//     row against the lane's cosine row in LDS (pitch 52 floats: conflict-free).
+//   * The kernel is bound by VALU issue (one instruction per 4 cycles per SIMD; 96 % busy), so the code is
+//     written for instruction count: twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2
+//     twiddles in registers (RES bit 1), ln on values pre-scaled by 2^32, scalar frame -> (clip, t) division.
+//   * Builds (template OUTK / FRONT): MFCC; mfe's (features, energy); power_spectrum rows; each optionally with a
+//     frame window and fused pre-emphasis on load.
 //   * HBM traffic: samples once (the 50 % frame overlap is served by L1/L2), n_ceps floats per frame out.
 // Compiled with -fno-slp-vectorize: v_pk_*_f32 issues at half the rate of the scalar forms on gfx950
 // (tools/ubench/valu_rate.hip), so packing buys nothing and costs registers.
