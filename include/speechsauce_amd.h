@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2
+#define SS_ABI_VERSION 3
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -43,9 +43,13 @@ typedef enum ss_status {
     SS_ERR_UNSUPPORTED = 5   /* valid in the reference but not built here (e.g. non power-of-two fft_points) */
 } ss_status;
 
-enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1 };
+enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1, SS_FRAMING_CENTER = 2 };
 enum { SS_DCT_REFERENCE = 0, SS_DCT_ORTHO = 1 };
-enum { SS_WINDOW_RECT = 0, SS_WINDOW_HANN = 1, SS_WINDOW_VORBIS = 2 };
+enum { SS_WINDOW_RECT = 0, SS_WINDOW_HANN = 1 /* periodic, functions.rs:349-357 */, SS_WINDOW_VORBIS = 2 };
+/* librosa-compatible variants (the reference's stated goal, README.md:3,44) */
+enum { SS_MEL_REFERENCE = 0, SS_MEL_SLANEY = 1, SS_MEL_HTK = 2 };
+enum { SS_MEL_NORM_NONE = 0, SS_MEL_NORM_SLANEY = 1 };
+enum { SS_PAD_REFLECT = 0, SS_PAD_CONSTANT = 1 };
 
 /* DCT-II gain of the un-vendored ndrustfft `nddct2` (feature.rs:123): scipy's un-normalised
  * convention y[k] = 2 * sum x[n] cos(pi k (2n+1) / 2N).  One named constant; "parity unpinned". */
@@ -70,7 +74,9 @@ typedef struct ss_params {
     /* ---- switches (reference mode = what ss_params_default sets) ---- */
     int32_t  framing;           /* SS_FRAMING_CONTRACT: frames[t,:] = x[t*step : t*step+flen], the documented
                                    contract (processing.rs:55-64).  SS_FRAMING_LITERAL: the exact_chunks copy as
-                                   written (processing.rs:110-120), which leaves every frame zero for > 2 frames. */
+                                   written (processing.rs:110-120), which leaves every frame zero for > 2 frames.
+                                   SS_FRAMING_CENTER: librosa center=True -- frame t covers
+                                   x[t*step - flen/2 : t*step + flen/2), 1 + n/step frames, edges per pad_mode */
     int32_t  spectrum_exponent; /* 1: |X|/N as written (processing.rs:168,180); 2: |X|^2/N (speechpy) */
     int32_t  dct_norm;          /* SS_DCT_REFERENCE: scaling as written (feature.rs:126-131); SS_DCT_ORTHO */
     float    dct2_gain;         /* SS_DCT2_GAIN */
@@ -78,6 +84,14 @@ typedef struct ss_params {
     float    preemph_coef;      /* fused pre-emphasis y[n] = x[n] - c*x[(n-shift) mod L] (processing.rs:31-53);
                                    0 = off (reference mfcc() applies none) */
     int32_t  preemph_shift;     /* >= 1 */
+    /* ---- librosa-compatible variants (all 0 in reference mode) ---- */
+    int32_t  mel_scale;         /* SS_MEL_REFERENCE: feature.rs:36-90 as written (HTK formula, integer bin mapping
+                                   floor((F+1) hz / sr)).  SS_MEL_SLANEY / SS_MEL_HTK: librosa.filters.mel -- triangles
+                                   in Hz evaluated at the FFT bin frequencies, mel points on the Slaney (htk=False) or
+                                   HTK scale */
+    int32_t  mel_norm;          /* SS_MEL_NORM_SLANEY: each filter scaled by 2 / (f[m+2] - f[m]) (librosa norm="slaney");
+                                   needs a non-reference mel_scale */
+    int32_t  pad_mode;          /* SS_FRAMING_CENTER only: how samples outside the clip are read (np.pad reflect / zeros) */
 } ss_params;
 
 typedef struct ss_config ss_config; /* opaque; replaces speechsauce::config::SpeechConfig (config.rs:99-131) */

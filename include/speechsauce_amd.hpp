@@ -51,6 +51,9 @@ class SpeechConfigBuilder {
 public:
     explicit SpeechConfigBuilder(std::size_t sample_rate) { check(ss_params_default(&p_, static_cast<uint32_t>(sample_rate))); }
     SpeechConfigBuilder &high_freq(float v) { p_.high_frequency = v; return *this; }
+    // librosa-compatible variants (ss_params switches): SS_FRAMING_CENTER + SS_PAD_*, SS_MEL_SLANEY / SS_MEL_HTK, SS_MEL_NORM_SLANEY
+    SpeechConfigBuilder &framing(int v, int pad_mode = SS_PAD_REFLECT) { p_.framing = v; p_.pad_mode = pad_mode; return *this; }
+    SpeechConfigBuilder &mel_scale(int scale, int norm = SS_MEL_NORM_NONE) { p_.mel_scale = scale; p_.mel_norm = norm; return *this; }
     SpeechConfigBuilder &low_freq(float v) { p_.low_frequency = v; return *this; }
     SpeechConfigBuilder &dc_elimination(bool v) { p_.dc_elimination = v; return *this; }
     SpeechConfigBuilder &num_cepstral(std::size_t v) { p_.num_cepstral = static_cast<uint32_t>(v); return *this; }

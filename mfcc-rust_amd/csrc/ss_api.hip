@@ -119,7 +119,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     a.n_frames = static_cast<uint32_t>(T);
     // processing.rs:110-120 as written: nothing is copied for > 2 frames, x[0..flen] into every row otherwise
     if (h.params.framing == SS_FRAMING_LITERAL) a.frame_mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
+    else if (h.params.framing == SS_FRAMING_CENTER) a.frame_mode = ss::FRAME_CENTER;  // librosa center=True (generic kernel only)
     else a.frame_mode = ss::FRAME_NORMAL;
+    a.pad_reflect = h.params.pad_mode == SS_PAD_REFLECT;
     a.preemph = h.params.preemph_coef;
     a.preemph_shift = static_cast<uint32_t>(h.params.preemph_shift > 0 ? h.params.preemph_shift : 1);
     a.window = cfg->d_window_mfcc;

@@ -15,7 +15,7 @@ enum OutKind : int32_t {
     OUT_STFT = 4    // [clips x R x F x 2]                        functions.rs:86-123
 };
 
-enum FrameMode : int32_t { FRAME_NORMAL = 0, FRAME_ZERO = 1, FRAME_FIRST = 2 };
+enum FrameMode : int32_t { FRAME_NORMAL = 0, FRAME_ZERO = 1, FRAME_FIRST = 2, FRAME_CENTER = 3 };
 
 struct FrontArgs {
     // input: `batch` clips of `n_samples`, row stride `ld` elements
@@ -26,6 +26,7 @@ struct FrontArgs {
     // MFCC framing (processing.rs:65-129)
     uint32_t flen, step, n_frames;
     int32_t frame_mode;
+    int32_t pad_reflect;  // FRAME_CENTER: 1 = np.pad 'reflect' outside the clip, 0 = zeros
     float preemph;
     uint32_t preemph_shift;
     // STFT framing (functions.rs:86-170)

@@ -68,8 +68,12 @@ int validate(const ss_params &p)
         return fail(SS_ERR_BAD_CONFIG, "High frequency cannot be greater than half of the sampling frequency!");
     if (!(p.low_frequency >= 0.0f))  // feature.rs:51
         return fail(SS_ERR_BAD_CONFIG, "low frequency cannot be less than zero!");
-    if (p.framing != SS_FRAMING_CONTRACT && p.framing != SS_FRAMING_LITERAL)
-        return fail(SS_ERR_BAD_CONFIG, "framing switch");
+    if (p.framing < SS_FRAMING_CONTRACT || p.framing > SS_FRAMING_CENTER) return fail(SS_ERR_BAD_CONFIG, "framing switch");
+    if (p.mel_scale < SS_MEL_REFERENCE || p.mel_scale > SS_MEL_HTK) return fail(SS_ERR_BAD_CONFIG, "mel_scale switch");
+    if (p.mel_norm != SS_MEL_NORM_NONE && p.mel_norm != SS_MEL_NORM_SLANEY) return fail(SS_ERR_BAD_CONFIG, "mel_norm switch");
+    if (p.mel_norm == SS_MEL_NORM_SLANEY && p.mel_scale == SS_MEL_REFERENCE)
+        return fail(SS_ERR_BAD_CONFIG, "mel_norm = slaney needs mel_scale = slaney or htk");
+    if (p.pad_mode != SS_PAD_REFLECT && p.pad_mode != SS_PAD_CONSTANT) return fail(SS_ERR_BAD_CONFIG, "pad_mode switch");
     if (p.spectrum_exponent != 1 && p.spectrum_exponent != 2)
         return fail(SS_ERR_BAD_CONFIG, "spectrum_exponent must be 1 or 2");
     if (p.dct_norm != SS_DCT_REFERENCE && p.dct_norm != SS_DCT_ORTHO) return fail(SS_ERR_BAD_CONFIG, "dct_norm switch");
@@ -92,6 +96,14 @@ int num_frames(const ss_params &p, size_t n, size_t &t)
     Derived d;
     int rc = derive(p, d);
     if (rc) return rc;
+    if (p.framing == SS_FRAMING_CENTER) {
+        // librosa center=True: the clip is padded by flen/2 on both sides -> 1 + n / step frames; np.pad 'reflect' needs
+        // more than flen/2 samples to mirror
+        if (n == 0 || (p.pad_mode == SS_PAD_REFLECT && n <= d.flen / 2))
+            return fail(SS_ERR_SHORT_SIGNAL, "signal too short for centred frames");
+        t = 1 + n / d.step;
+        return SS_OK;
+    }
     // processing.rs:101: ((len - flen) as f32 / step as f32).floor() as usize; len < flen underflows.
     if (n < d.flen) return fail(SS_ERR_SHORT_SIGNAL, "signal shorter than one frame");
     const float q = floorf(static_cast<float>(n - d.flen) / static_cast<float>(d.step));
@@ -132,10 +144,48 @@ void hann_window(size_t n, float *w)
         w[i] = static_cast<float>(0.5 * (1.0 - std::cos(2.0 * pi * static_cast<double>(i) / static_cast<double>(n))));
 }
 
+// librosa.filters.mel (htk = mel_scale == SS_MEL_HTK, norm = "slaney" | None): f64 arithmetic, f32 result
+static void build_filterbank_librosa(const ss_params &p, std::vector<float> &fb)
+{
+    const size_t M = p.num_filters, F = p.fft_points / 2 + 1;
+    const double sr = p.sample_rate, fmin = p.low_frequency, fmax = p.high_frequency;
+    const bool htk = p.mel_scale == SS_MEL_HTK;
+    constexpr double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) {
+        if (htk) return 2595.0 * std::log10(1.0 + f / 700.0);
+        return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+    };
+    auto mel_to_hz = [&](double m) {
+        if (htk) return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+        return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+    };
+    std::vector<double> mel_f(M + 2);
+    const double mlo = hz_to_mel(fmin), mhi = hz_to_mel(fmax);
+    for (size_t i = 0; i < M + 2; ++i) mel_f[i] = mel_to_hz(mlo + (mhi - mlo) * static_cast<double>(i) / static_cast<double>(M + 1));
+    fb.assign(M * F, 0.0f);
+    for (size_t m = 0; m < M; ++m) {
+        const double fd0 = mel_f[m + 1] - mel_f[m], fd1 = mel_f[m + 2] - mel_f[m + 1];
+        const double enorm = p.mel_norm == SS_MEL_NORM_SLANEY ? 2.0 / (mel_f[m + 2] - mel_f[m]) : 1.0;
+        for (size_t k = 0; k < F; ++k) {
+            const double f = static_cast<double>(k) * sr / static_cast<double>(p.fft_points);  // np.fft.rfftfreq
+            const double lower = (f - mel_f[m]) / fd0, upper = (mel_f[m + 2] - f) / fd1;
+            const double w = std::max(0.0, std::min(lower, upper));
+            fb[m * F + k] = static_cast<float>(w * enorm);
+        }
+    }
+}
+
 int build_filterbank(const ss_params &p, std::vector<float> &fb, std::vector<int32_t> &idx)
 {
     const size_t M = p.num_filters, F = p.fft_points / 2 + 1;
     const float sr = static_cast<float>(p.sample_rate);
+    if (p.mel_scale != SS_MEL_REFERENCE) {
+        if (!(p.high_frequency > p.low_frequency)) return fail(SS_ERR_BAD_CONFIG, "high_frequency must exceed low_frequency");
+        idx.assign(M + 2, 0);  // the integer bin edges exist in reference mode only
+        build_filterbank_librosa(p, fb);
+        return SS_OK;
+    }
     auto mel = [](float f) { return 1127.0f * logf(1.0f + f / 700.0f); };     // functions.rs:19-21
     auto hz = [](float m) { return 700.0f * (expf(m / 1127.0f) - 1.0f); };     // functions.rs:36-41
     const float lo = mel(p.low_frequency), hi = mel(p.high_frequency);
@@ -516,6 +566,9 @@ int ss_params_default(ss_params *p, uint32_t sample_rate)
     p->mfcc_window = SS_WINDOW_RECT;
     p->preemph_coef = 0.0f;
     p->preemph_shift = 1;
+    p->mel_scale = SS_MEL_REFERENCE;
+    p->mel_norm = SS_MEL_NORM_NONE;
+    p->pad_mode = SS_PAD_REFLECT;
     return SS_OK;
 }
 

@@ -212,12 +212,26 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                     const unsigned i = 2 * n + h;
                     float val = 0.0f;
                     if (active && i < lim) {
-                        const unsigned idx = base + i;
+                        unsigned idx = base + i;
+                        bool inside = true;
+                        if (a.frame_mode == FRAME_CENTER) {
+                            // librosa center=True: the frame is centred on t*step; outside the clip np.pad 'reflect'
+                            // (mirror without repeating the edge sample) or zeros
+                            long long pos = static_cast<long long>(t) * a.step + i - a.flen / 2;
+                            const long long ns = a.n_samples;
+                            if (pos < 0 || pos >= ns) {
+                                if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+                                else inside = false;
+                            }
+                            idx = static_cast<unsigned>(pos);
+                        }
+                        if (inside) {
                         val = xc[idx];
                         if (a.preemph != 0.0f) {  // processing.rs:31-53 fused
                             const unsigned sh = a.preemph_shift % a.n_samples;
                             const unsigned jdx = idx >= sh ? idx - sh : idx + a.n_samples - sh;
                             val -= a.preemph * xc[jdx];
+                        }
                         }
                         if (a.window) val *= a.window[i];
                     }

@@ -38,6 +38,10 @@ pub struct SsParams {
     pub mfcc_window: i32,
     pub preemph_coef: f32,
     pub preemph_shift: i32,
+    /// librosa-compatible variants (0 = reference mode): SS_MEL_*, SS_MEL_NORM_*, SS_PAD_*
+    pub mel_scale: i32,
+    pub mel_norm: i32,
+    pub pad_mode: i32,
 }
 
 #[repr(C)]

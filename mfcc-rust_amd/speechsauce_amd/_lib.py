@@ -15,7 +15,10 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
 
 SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED = range(6)
-FRAMING = {"contract": 0, "literal": 1}
+FRAMING = {"contract": 0, "literal": 1, "center": 2}
+MEL_SCALE = {"reference": 0, "slaney": 1, "htk": 2}
+MEL_NORM = {"none": 0, "slaney": 1}
+PAD_MODE = {"reflect": 0, "constant": 1}
 DCT_NORM = {"reference": 0, "ortho": 1}
 WINDOW = {"rect": 0, "hann": 1, "vorbis": 2}
 DCT2_GAIN = 2.0
@@ -42,6 +45,9 @@ class SsParams(C.Structure):
         ("mfcc_window", C.c_int32),
         ("preemph_coef", C.c_float),
         ("preemph_shift", C.c_int32),
+        ("mel_scale", C.c_int32),
+        ("mel_norm", C.c_int32),
+        ("pad_mode", C.c_int32),
     ]
 
 
@@ -123,7 +129,7 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.ss_abi_version() != 2:
+    if handle.ss_abi_version() != 3:
         raise ImportError("libspeechsauce_amd.so ABI version mismatch")
     _lib = handle
     return _lib
@@ -138,7 +144,8 @@ def check(status: int) -> None:
 def make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stride=0.01, num_cepstral=13,
                 num_filters=40, low_frequency=0.0, high_frequency=None, dc_elimination=True,
                 framing="contract", spectrum_exponent=1, dct_norm="reference", dct2_gain=DCT2_GAIN,
-                mfcc_window="rect", preemph_coef=0.0, preemph_shift=1) -> SsParams:
+                mfcc_window="rect", preemph_coef=0.0, preemph_shift=1, mel_scale="reference", mel_norm="none",
+                pad_mode="reflect") -> SsParams:
     p = SsParams()
     check(lib().ss_params_default(C.byref(p), int(sample_rate)))
     p.fft_points = int(fft_points)
@@ -157,4 +164,7 @@ def make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stri
     p.mfcc_window = WINDOW[mfcc_window] if isinstance(mfcc_window, str) else int(mfcc_window)
     p.preemph_coef = float(preemph_coef)
     p.preemph_shift = int(preemph_shift)
+    p.mel_scale = MEL_SCALE[mel_scale] if isinstance(mel_scale, str) else int(mel_scale)
+    p.mel_norm = MEL_NORM[mel_norm] if isinstance(mel_norm, str) else int(mel_norm)
+    p.pad_mode = PAD_MODE[pad_mode] if isinstance(pad_mode, str) else int(pad_mode)
     return p

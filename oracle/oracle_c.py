@@ -14,7 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libss_oracle.so")
 
 ORC_OK, ORC_ERR_SHORT_SIGNAL, ORC_ERR_BAD_CONFIG, ORC_ERR_ARG = 0, 1, 2, 3
-FRAMING = {"contract": 0, "literal": 1}
+FRAMING = {"contract": 0, "literal": 1, "center": 2}
+MEL_SCALE = {"reference": 0, "slaney": 1, "htk": 2}
+MEL_NORM = {"none": 0, "slaney": 1}
+PAD_MODE = {"reflect": 0, "constant": 1}
 DCT_NORM = {"reference": 0, "ortho": 1}
 WINDOW = {"rect": 0, "hann": 1, "vorbis": 2}
 
@@ -38,6 +41,9 @@ class OrcParams(C.Structure):
         ("mfcc_window", C.c_int32),
         ("preemph_coef", C.c_float),
         ("preemph_shift", C.c_int32),
+        ("mel_scale", C.c_int32),
+        ("mel_norm", C.c_int32),
+        ("pad_mode", C.c_int32),
     ]
 
 
@@ -67,7 +73,8 @@ def lib():
 def make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stride=0.01, num_cepstral=13,
                 num_filters=40, low_frequency=0.0, high_frequency=None, dc_elimination=True,
                 framing="contract", spectrum_exponent=1, dct_norm="reference", dct2_gain=2.0,
-                mfcc_window="rect", preemph_coef=0.0, preemph_shift=1) -> OrcParams:
+                mfcc_window="rect", preemph_coef=0.0, preemph_shift=1, mel_scale="reference", mel_norm="none",
+                pad_mode="reflect") -> OrcParams:
     p = OrcParams()
     lib().orc_params_default(C.byref(p), C.c_uint32(sample_rate))
     p.fft_points = fft_points
@@ -85,6 +92,9 @@ def make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stri
     p.mfcc_window = WINDOW[mfcc_window]
     p.preemph_coef = preemph_coef
     p.preemph_shift = preemph_shift
+    p.mel_scale = MEL_SCALE[mel_scale]
+    p.mel_norm = MEL_NORM[mel_norm]
+    p.pad_mode = PAD_MODE[pad_mode]
     return p
 
 

@@ -50,6 +50,10 @@ class Params:
     mfcc_window: str = "rect"  # "hann" | "vorbis"
     preemph_coef: float = 0.0
     preemph_shift: int = 1
+    # librosa-compatible variants; the defaults are reference mode
+    mel_scale: str = "reference"  # "slaney" | "htk": librosa.filters.mel, triangles in Hz at the rfft bin frequencies
+    mel_norm: str = "none"  # "slaney": area normalisation 2 / (f[m+2] - f[m])
+    pad_mode: str = "reflect"  # framing == "center": np.pad mode of the flen/2 samples on either side ("constant" = zeros)
 
     def high(self) -> float:
         return float(self.sample_rate) / 2.0 if self.high_frequency is None else float(self.high_frequency)
@@ -69,6 +73,10 @@ def frame_sizes(p: Params) -> tuple[int, int]:
 def num_frames(p: Params, n: int) -> int:
     """processing.rs:101 (zero_padding=false); f32 division then floor."""
     flen, step = frame_sizes(p)
+    if p.framing == "center":  # librosa center=True
+        if n == 0 or (p.pad_mode == "reflect" and n <= flen // 2):
+            raise ValueError("signal too short for centred frames")
+        return 1 + n // step
     if n < flen:
         raise ValueError("signal shorter than one frame")
     t = int(math.floor(float(f32(n - flen) / f32(step))))
@@ -99,6 +107,8 @@ def hann_window(n: int) -> np.ndarray:
 def filterbank(p: Params) -> tuple[np.ndarray, np.ndarray]:
     """feature.rs:36-90 + functions.rs:19-21,36-60, f32 with glibc logf/expf."""
     M, F = p.num_filters, p.fft_points // 2 + 1
+    if p.mel_scale != "reference":
+        return _filterbank_librosa(p), np.zeros(M + 2, dtype=np.int64)
     sr = f32(p.sample_rate)
 
     def mel(f):
@@ -128,6 +138,37 @@ def filterbank(p: Params) -> tuple[np.ndarray, np.ndarray]:
     return fb, idx
 
 
+def _filterbank_librosa(p: Params) -> np.ndarray:
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk, norm) written the way librosa writes it (vectorised
+    ramps / np.subtract.outer), float64 arithmetic, float32 result."""
+    M, n_fft = p.num_filters, p.fft_points
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        if p.mel_scale == "htk":
+            return 2595.0 * np.log10(1.0 + f / 700.0)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        if p.mel_scale == "htk":
+            return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.fft.rfftfreq(n_fft, 1.0 / p.sample_rate)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(p.low_frequency), hz_to_mel(p.high()), M + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    weights = np.maximum(0, np.minimum(lower, upper))
+    if p.mel_norm == "slaney":
+        weights *= (2.0 / (mel_f[2 : M + 2] - mel_f[:M]))[:, None]
+    return weights.astype(np.float32)
+
+
 def preemphasis(x: np.ndarray, shift: int = 1, cof: float = 0.98) -> np.ndarray:
     """processing.rs:31-53: np.roll semantics."""
     x = np.asarray(x, dtype=np.float64)
@@ -151,6 +192,10 @@ def power_spectrum(p: Params, x: np.ndarray) -> np.ndarray:
     if p.framing == "literal":
         if T <= 2:
             frames[:, : flen & ~1] = xs[: flen & ~1]
+    elif p.framing == "center":  # librosa center=True: np.pad then plain framing
+        xp = np.pad(xs, flen // 2, mode="reflect" if p.pad_mode == "reflect" else "constant")
+        for t in range(T):
+            frames[t, :flen] = xp[t * step : t * step + flen]
     else:
         for t in range(T):
             frames[t, :flen] = xs[t * step : t * step + flen]

@@ -48,6 +48,9 @@ void orc_params_default(orc_params *p, uint32_t sample_rate)
     p->mfcc_window = ORC_WINDOW_RECT;
     p->preemph_coef = 0.0f;
     p->preemph_shift = 1;
+    p->mel_scale = ORC_MEL_REFERENCE;
+    p->mel_norm = ORC_MEL_NORM_NONE;
+    p->pad_mode = ORC_PAD_REFLECT;
 }
 
 /* processing.rs:77-78: (sample_rate as f32 * seconds).round() as usize  (round half away from 0) */
@@ -69,6 +72,12 @@ int orc_num_frames(const orc_params *p, size_t n, size_t *n_frames)
     size_t flen, step;
     int rc = orc_frame_sizes(p, &flen, &step);
     if (rc) return rc;
+    if (p->framing == ORC_FRAMING_CENTER) {
+        /* librosa center=True: y padded by flen/2 on both sides -> 1 + n / hop frames */
+        if (n == 0 || (p->pad_mode == ORC_PAD_REFLECT && n <= flen / 2)) return ORC_ERR_SHORT_SIGNAL;
+        *n_frames = 1 + n / step;
+        return ORC_OK;
+    }
     if (n < flen) return ORC_ERR_SHORT_SIGNAL;
     float q = floorf((float)(n - flen) / (float)step);
     size_t t = (size_t)q;
@@ -155,6 +164,40 @@ int orc_filterbank(const orc_params *p, float *fb, int32_t *idx_out)
     if (M == 0) return ORC_ERR_BAD_CONFIG;
     if (p->high_frequency > sr / 2.0f) return ORC_ERR_BAD_CONFIG; /* feature.rs:47-50 assert */
     if (p->low_frequency < 0.0f) return ORC_ERR_BAD_CONFIG;       /* feature.rs:51 assert */
+    if (p->mel_norm == ORC_MEL_NORM_SLANEY && p->mel_scale == ORC_MEL_REFERENCE) return ORC_ERR_BAD_CONFIG;
+    if (p->mel_scale != ORC_MEL_REFERENCE) {
+        /* librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk, norm): triangles in Hz evaluated at the rfft bin
+         * frequencies; mel points on the Slaney scale (linear below 1 kHz, log above: 27 steps per factor 6.4) or HTK */
+        if (!(p->high_frequency > p->low_frequency)) return ORC_ERR_BAD_CONFIG;
+        const int htk = p->mel_scale == ORC_MEL_HTK;
+        const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+        double *mel_f = (double *)malloc((M + 2) * sizeof(double));
+        if (!mel_f) return ORC_ERR_ARG;
+        double lo = p->low_frequency, hi = p->high_frequency, mlo, mhi;
+        if (htk) { mlo = 2595.0 * log10(1.0 + lo / 700.0); mhi = 2595.0 * log10(1.0 + hi / 700.0); }
+        else {
+            mlo = lo >= min_log_hz ? min_log_mel + log(lo / min_log_hz) / logstep : lo / f_sp;
+            mhi = hi >= min_log_hz ? min_log_mel + log(hi / min_log_hz) / logstep : hi / f_sp;
+        }
+        for (size_t i = 0; i < M + 2; ++i) {
+            double m = mlo + (mhi - mlo) * (double)i / (double)(M + 1);
+            if (htk) mel_f[i] = 700.0 * (pow(10.0, m / 2595.0) - 1.0);
+            else mel_f[i] = m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+            if (idx_out) idx_out[i] = 0;
+        }
+        for (size_t m = 0; m < M; ++m) {
+            double enorm = p->mel_norm == ORC_MEL_NORM_SLANEY ? 2.0 / (mel_f[m + 2] - mel_f[m]) : 1.0;
+            for (size_t k = 0; k < F; ++k) {
+                double f = (double)k * (double)p->sample_rate / (double)p->fft_points;
+                double lower = (f - mel_f[m]) / (mel_f[m + 1] - mel_f[m]);
+                double upper = (mel_f[m + 2] - f) / (mel_f[m + 2] - mel_f[m + 1]);
+                double w = lower < upper ? lower : upper;
+                fb[m * F + k] = (float)((w > 0.0 ? w : 0.0) * enorm);
+            }
+        }
+        free(mel_f);
+        return ORC_OK;
+    }
 
     /* ndarray linspace: start + step*i with step = (end-start)/(n-1), all f32 (feature.rs:57-61) */
     const float m_lo = hz_to_mel(p->low_frequency);
@@ -421,6 +464,16 @@ int orc_power_spectrum(const orc_params *p, const float *x, size_t n, double *P)
              * numframes <= 2 copies x[0..flen] into every row (flen even). */
             if (T <= 2)
                 for (size_t i = 0; i < (flen & ~(size_t)1); ++i) buf[i] = sample_at(p, x, n, i);
+        } else if (p->framing == ORC_FRAMING_CENTER) {
+            /* frame centred on t*step; np.pad(y, flen/2, mode) semantics outside the clip */
+            for (size_t i = 0; i < flen; ++i) {
+                long long pos = (long long)(t * step + i) - (long long)(flen / 2);
+                if (pos < 0 || pos >= (long long)n) {
+                    if (p->pad_mode != ORC_PAD_REFLECT) continue; /* zeros */
+                    pos = pos < 0 ? -pos : 2 * ((long long)n - 1) - pos;
+                }
+                buf[i] = sample_at(p, x, n, (size_t)pos);
+            }
         } else {
             for (size_t i = 0; i < flen; ++i) buf[i] = sample_at(p, x, n, t * step + i);
         }

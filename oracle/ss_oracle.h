@@ -45,7 +45,10 @@ extern "C" {
 #define ORC_DCT2_GAIN 2.0f
 
 enum { ORC_OK = 0, ORC_ERR_SHORT_SIGNAL = 1, ORC_ERR_BAD_CONFIG = 2, ORC_ERR_ARG = 3 };
-enum { ORC_FRAMING_CONTRACT = 0, ORC_FRAMING_LITERAL = 1 };
+enum { ORC_FRAMING_CONTRACT = 0, ORC_FRAMING_LITERAL = 1, ORC_FRAMING_CENTER = 2 };
+enum { ORC_MEL_REFERENCE = 0, ORC_MEL_SLANEY = 1, ORC_MEL_HTK = 2 };   /* librosa-compatible variants, SURVEY 8f-4 */
+enum { ORC_MEL_NORM_NONE = 0, ORC_MEL_NORM_SLANEY = 1 };
+enum { ORC_PAD_REFLECT = 0, ORC_PAD_CONSTANT = 1 };
 enum { ORC_DCT_REFERENCE = 0, ORC_DCT_ORTHO = 1 };
 enum { ORC_WINDOW_RECT = 0, ORC_WINDOW_HANN = 1, ORC_WINDOW_VORBIS = 2 };
 
@@ -69,6 +72,11 @@ typedef struct orc_params {
     int32_t  mfcc_window;
     float    preemph_coef;      /* 0 = off (reference mfcc() applies none) */
     int32_t  preemph_shift;
+    /* librosa-compatible variants (0 = reference mode): restated from librosa's documented algorithms (filters.mel,
+     * stft center/pad_mode); librosa is not installed here, so these are "parity unpinned" against it as well */
+    int32_t  mel_scale;
+    int32_t  mel_norm;
+    int32_t  pad_mode;
 } orc_params;
 
 void orc_params_default(orc_params *p, uint32_t sample_rate);

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(sslib):
     for n in names:
         assert hasattr(sslib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in the Python front"
-    assert sslib.ss_abi_version() == 2
+    assert sslib.ss_abi_version() == 3
 
 
 def test_params_struct_matches_header(sslib):
@@ -45,13 +45,14 @@ def test_params_struct_matches_header(sslib):
 
     p = SsParams()
     assert sslib.ss_params_default(C.byref(p), 16000) == 0
-    assert p.struct_size == C.sizeof(SsParams) == 68
+    assert p.struct_size == C.sizeof(SsParams) == 80
     # SpeechConfigBuilder::new defaults, config.rs:35-47
     assert (p.sample_rate, p.fft_points, p.num_cepstral, p.num_filters, p.dc_elimination) == (16000, 512, 13, 40, 1)
     assert p.frame_length == pytest.approx(0.02) and p.frame_stride == pytest.approx(0.01)
     assert p.low_frequency == 0.0 and p.high_frequency == 8000.0
     # reference-mode switches
     assert (p.framing, p.spectrum_exponent, p.dct_norm, p.mfcc_window, p.preemph_shift) == (0, 1, 0, 0, 1)
+    assert (p.mel_scale, p.mel_norm, p.pad_mode) == (0, 0, 0)
     assert p.dct2_gain == 2.0 and p.preemph_coef == 0.0
     p.struct_size = 4
     assert sslib.ss_params_validate(C.byref(p)) == 3  # SS_ERR_ARG: ABI guard
