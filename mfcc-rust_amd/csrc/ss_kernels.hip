@@ -37,6 +37,20 @@ __device__ __forceinline__ float fast_ln(float x)
     return (l - (tiny ? 32.f : 0.f)) * 0.69314718055994530942f;
 }
 
+// Hand-off between the threads of ONE frame.  A frame has C/16 threads; up to 64 of them sit in one wave, whose LDS
+// operations execute in order, so only the compiler has to be kept from reordering (as in the dedicated kernels).  Frames
+// that span waves (fft_points 4096) need the workgroup barrier.
+template <int LOG2C>
+__device__ __forceinline__ void frame_sync()
+{
+    if constexpr ((1 << LOG2C) / 16 <= 64) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 // One Stockham pass of radix R with sub-transform length NS already done, on a frame of C points
 // held 16 per thread.  `j` is the thread index within the frame (TPF = C/16 threads).
 // Loads happen before the barrier-separated stores, so the pass works in place.
@@ -48,7 +62,7 @@ __device__ __forceinline__ void stockham_pass(float2 *zbuf, int j, const float2 
     constexpr int NB = 16 / R;  // butterflies per thread
     constexpr int STRIDE = C / R;
     if (kLoad) {
-        __syncthreads();
+        frame_sync<LOG2C>();
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int b = j + TPF * q;
@@ -67,7 +81,7 @@ __device__ __forceinline__ void stockham_pass(float2 *zbuf, int j, const float2 
         }
         fft_reg<R>(&v[q * R]);
     }
-    __syncthreads();
+    frame_sync<LOG2C>();
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int b = j + TPF * q;
@@ -91,7 +105,7 @@ __device__ __forceinline__ void frame_fft(float2 *zbuf, int j, const float2 *__r
     } else if constexpr (LOG2C > 4) {
         stockham_pass<LOG2C, C / 16, 16, true>(zbuf, j, tw_c, v);
     }
-    __syncthreads();
+    frame_sync<LOG2C>();
 }
 
 template <int LOG2C>
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
             frame_fft<LOG2C>(zbuf, j, a.tw_c, v);
             const float part = untangle_row<LOG2C>(zbuf, prow, nullptr, j, a, false, active);
             red[j] = part;
-            __syncthreads();
+            frame_sync<LOG2C>();  // zbuf / prow / frow / red are private to the frame's slot
 
             if (a.out_kind == OUT_POWER) {
                 if (active) {
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                 if (a.out_kind == OUT_MFE) {
                     if (active && j == 0) a.out1[gf] = energy;
                 } else {
-                    __syncthreads();
+                    frame_sync<LOG2C>();  // zbuf / prow / frow / red are private to the frame's slot
                     // feature.rs:120-146: DCT-II (first n_ceps outputs), scaling, column-0 replacement
                     const int Cc = static_cast<int>(a.n_ceps);
                     const int parts = G::TPF / Cc;  // threads per coefficient (uniform)
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                             for (int m = part * ms; m < m1; ++m) s = fmaf(frow[m], row[m], s);
                             red[j] = s;
                         }
-                        __syncthreads();
+                        frame_sync<LOG2C>();  // zbuf / prow / frow / red are private to the frame's slot
                         if (j < Cc) {
                             float tot = 0.0f;
                             for (int p = 0; p < parts; ++p) tot += red[p * Cc + j];
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                     }
                 }
             }
-            __syncthreads();
+            frame_sync<LOG2C>();  // zbuf / prow / frow / red are private to the frame's slot
         }
     } else {
         // ---------------- STFT / mel-spectrogram path: one clip (channel) per workgroup visit -------
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                     if (a.out_kind == OUT_STFT)
                         stft_row = reinterpret_cast<float2 *>(a.out0) + (static_cast<unsigned long long>(clip) * R + r) * G::F;
                     untangle_row<LOG2C>(zbuf, prow, stft_row, j, a, true, active);
-                    __syncthreads();
+                    frame_sync<LOG2C>();  // prow is private to the frame; the shared tile has its own barriers below
                     if (a.out_kind == OUT_MEL && rl < rt) {
                         // feature.rs:173: out[n,m,t] = sum_f P[n,t,f] fb[m,f]; rows >= real_rows stay zero
                         for (int m = j; m < M; m += G::TPF) tile[m * (TILE + 1) + rl] = active ? mel_dot(prow, a, m) : 0.0f;
