@@ -153,17 +153,18 @@ __device__ __forceinline__ float mel_slot_fixed(const float4 *w4, const float *p
     return acc;
 }
 
-// Same with a run-time tap count (configurations other than the default bank shape).
+// Same with a run-time tap count (configurations other than the default bank shape): chunks of 4, 2 and 1 float4 of
+// weights, so that a slot costs a few LDS round trips instead of one per four taps.
 __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p, int q4)
 {
     float acc = 0.f;
-    for (int i = 0; i < q4; ++i) {
-        const float4 w = w4[i];
-        acc = fmaf(w.x, p[4 * i], acc);
-        acc = fmaf(w.y, p[4 * i + 1], acc);
-        acc = fmaf(w.z, p[4 * i + 2], acc);
-        acc = fmaf(w.w, p[4 * i + 3], acc);
+    int i = 0;
+    for (; i + 4 <= q4; i += 4) acc += mel_slot_fixed<4>(w4 + i, p + 4 * i);
+    if (i + 2 <= q4) {
+        acc += mel_slot_fixed<2>(w4 + i, p + 4 * i);
+        i += 2;
     }
+    if (i < q4) acc += mel_slot_fixed<1>(w4 + i, p + 4 * i);
     return acc;
 }
 
