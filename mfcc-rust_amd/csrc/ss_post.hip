@@ -3,14 +3,16 @@
 // feature.rs:253-269 (extract_derivative_feature); the pads are np.pad 'edge' / 'symmetric' as util.rs:108-124 quotes.
 //
 // The data is the [clips x rows x cols] feature block the hot path just wrote (5 MB for 1024 one-second clips), so these
-// are plain HBM/L2-bound element kernels: one thread per output element (or per column for the global statistics),
-// neighbouring threads on neighbouring addresses, f64 accumulators for the statistics (full rate on gfx950; it keeps the
-// result within an ulp of the f64 oracle for 6 000-row matrices too).  No LDS, no cross-workgroup state.
+// are small HBM/L2-bound kernels with neighbouring threads on neighbouring addresses (columns fastest) and f64 accumulators
+// for the statistics (full rate on gfx950; it keeps the result within an ulp of the f64 oracle for 6 000-row matrices too):
+// cmvn sums chunks of rows per thread and normalises per element (two launches, no atomics: bit-reproducible); cmvnw slides
+// its window sums over a chunk of rows per thread (O(rows + win) loads per column chunk instead of O(rows * win)).
 #include "ss_internal.h"
 #include "speechsauce_amd.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 
 namespace ss {
@@ -19,79 +21,143 @@ namespace {
 
 constexpr double kEps30 = 9.313225746154785e-10;  // 2f32.powf(-30.), processing.rs:266, :324
 
-// np.pad(..., 'symmetric') index along an axis of length n (reflection that repeats the edge sample, period 2n)
-__device__ __forceinline__ unsigned sym_index(long long p, unsigned n)
-{
-    const long long period = 2ll * n;
-    long long m = p % period;
-    if (m < 0) m += period;
-    return static_cast<unsigned>(m < n ? m : period - 1 - m);
-}
+// Walker over np.pad(..., 'symmetric') of an axis of length n (reflection that repeats the edge sample, period 2n):
+// position p of the padded axis maps to idx; step() moves to p + 1 without a division.
+struct SymWalk {
+    unsigned idx;
+    int dir;
+    unsigned n;
+    __device__ SymWalk(long long p, unsigned n_) : n(n_)
+    {
+        const long long period = 2ll * n_;
+        long long m = p % period;
+        if (m < 0) m += period;
+        dir = m < n_ ? 1 : -1;
+        idx = static_cast<unsigned>(m < n_ ? m : period - 1 - m);
+    }
+    __device__ void step()
+    {
+        if (dir > 0) {
+            if (idx + 1 == n) dir = -1;  // the edge sample repeats
+            else ++idx;
+        } else {
+            if (idx == 0) dir = 1;
+            else --idx;
+        }
+    }
+};
 
-// cmvn: thread = (clip, column); three passes over the column (mean, centred second moment, write)
-__global__ __launch_bounds__(256) void ss_cmvn_kernel(const float *__restrict__ x, float *__restrict__ out, unsigned long long n_cols_total,
-                                                      unsigned rows, unsigned cols, int variance)
+// ---- cmvn: column statistics in two kernels, no atomics (bit-reproducible) ----
+// partial sums of x and x^2 over a chunk of rows; thread = (clip, chunk, column), columns fastest
+__global__ __launch_bounds__(256) void ss_cmvn_partial_kernel(const float *__restrict__ x, double *__restrict__ part, unsigned long long total,
+                                                             unsigned rows, unsigned cols, unsigned chunks, unsigned rpc)
 {
     const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (g >= n_cols_total) return;
-    const unsigned long long clip = g / cols;
-    const unsigned c = static_cast<unsigned>(g - clip * cols);
+    if (g >= total) return;
+    const unsigned c = static_cast<unsigned>(g % cols);
+    const unsigned long long cc = g / cols;
+    const unsigned chunk = static_cast<unsigned>(cc % chunks);
+    const unsigned long long clip = cc / chunks;
+    const unsigned r0 = chunk * rpc, r1 = min(rows, r0 + rpc);
     const float *src = x + clip * rows * cols + c;
-    float *dst = out + clip * rows * cols + c;
-    double s = 0.0;
-    for (unsigned r = 0; r < rows; ++r) s += static_cast<double>(src[static_cast<size_t>(r) * cols]);
-    const double mean = s / rows;
+    double s1 = 0.0, s2 = 0.0;
+    for (unsigned r = r0; r < r1; ++r) {
+        const double v = static_cast<double>(src[static_cast<size_t>(r) * cols]);
+        s1 += v;
+        s2 += v * v;
+    }
+    part[2 * g] = s1;
+    part[2 * g + 1] = s2;
+}
+
+// thread = output element: mean (and population std) of its column from the chunk partials, then (x - mean) / (std + 2^-30)
+__global__ __launch_bounds__(256) void ss_cmvn_apply_kernel(const float *__restrict__ x, const double *__restrict__ part, float *__restrict__ out,
+                                                           unsigned long long total, unsigned rows, unsigned cols, unsigned chunks, int variance)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const unsigned long long per_clip = static_cast<unsigned long long>(rows) * cols;
+    const unsigned long long clip = g / per_clip;
+    const unsigned c = static_cast<unsigned>((g - clip * per_clip) % cols);
+    const double *pp = part + 2 * (clip * chunks * cols + c);
+    double s1 = 0.0, s2 = 0.0;
+    for (unsigned k = 0; k < chunks; ++k) {
+        s1 += pp[2 * static_cast<size_t>(k) * cols];
+        s2 += pp[2 * static_cast<size_t>(k) * cols + 1];
+    }
+    const double mean = s1 / rows;
     double inv = 1.0;
     if (variance) {
-        // std_axis(Axis(0), 0.) of the mean-subtracted column (processing.rs:283)
-        double v = 0.0;
-        for (unsigned r = 0; r < rows; ++r) {
-            const double d = static_cast<double>(src[static_cast<size_t>(r) * cols]) - mean;
-            v += d * d;
-        }
-        inv = 1.0 / (sqrt(v / rows) + kEps30);
+        const double var = fmax(s2 / rows - mean * mean, 0.0);  // std_axis(Axis(0), 0.) of the mean-subtracted column (processing.rs:283)
+        inv = 1.0 / (sqrt(var) + kEps30);
     }
-    for (unsigned r = 0; r < rows; ++r)
-        dst[static_cast<size_t>(r) * cols] = static_cast<float>((static_cast<double>(src[static_cast<size_t>(r) * cols]) - mean) * inv);
+    out[g] = static_cast<float>((static_cast<double>(x[g]) - mean) * inv);
 }
 
-// cmvnw pass 1: thread = (clip, row, column): x - mean over the win_size rows of the symmetric-padded clip centred on row
+// ---- cmvnw: sliding window sums over the symmetric-padded rows; thread = (clip, chunk of rows, column) ----
+// pass 1: ms[i] = x[i] - mean of the win rows centred on i
 __global__ __launch_bounds__(256) void ss_cmvnw_mean_kernel(const float *__restrict__ x, float *__restrict__ ms, unsigned long long total,
-                                                            unsigned rows, unsigned cols, unsigned win)
+                                                            unsigned rows, unsigned cols, unsigned win, unsigned chunks, unsigned rpc)
 {
     const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= total) return;
-    const unsigned long long per_clip = static_cast<unsigned long long>(rows) * cols;
-    const unsigned long long clip = g / per_clip;
-    const unsigned rc = static_cast<unsigned>(g - clip * per_clip);
-    const unsigned i = rc / cols, c = rc - i * cols;
-    const float *src = x + clip * per_clip + c;
+    const unsigned c = static_cast<unsigned>(g % cols);
+    const unsigned long long cc = g / cols;
+    const unsigned chunk = static_cast<unsigned>(cc % chunks);
+    const unsigned long long clip = cc / chunks;
+    const unsigned i0 = chunk * rpc, i1 = min(rows, i0 + rpc);
+    const float *src = x + clip * rows * cols + c;
+    float *dst = ms + clip * rows * cols + c;
     const long long pad = (win - 1) / 2;
+    SymWalk head(static_cast<long long>(i0) - pad, rows), tail = head;  // tail: oldest row of the window, head: next row to enter
     double s = 0.0;
-    for (unsigned w = 0; w < win; ++w) s += static_cast<double>(src[static_cast<size_t>(sym_index(static_cast<long long>(i) + w - pad, rows)) * cols]);
-    ms[g] = static_cast<float>(static_cast<double>(src[static_cast<size_t>(i) * cols]) - s / win);
+#pragma unroll 4
+    for (unsigned w = 0; w < win; ++w) {
+        s += static_cast<double>(src[static_cast<size_t>(head.idx) * cols]);
+        head.step();
+    }
+    for (unsigned i = i0; i < i1; ++i) {
+        dst[static_cast<size_t>(i) * cols] = static_cast<float>(static_cast<double>(src[static_cast<size_t>(i) * cols]) - s / win);
+        s += static_cast<double>(src[static_cast<size_t>(head.idx) * cols]) - static_cast<double>(src[static_cast<size_t>(tail.idx) * cols]);
+        head.step();
+        tail.step();
+    }
 }
 
-// cmvnw pass 2 (variance_normalization): ms / (population std of ms over the same symmetric window + 2^-30)
+// pass 2 (variance_normalization): ms / (population std of ms over the same symmetric window + 2^-30)
 __global__ __launch_bounds__(256) void ss_cmvnw_var_kernel(const float *__restrict__ ms, float *__restrict__ out, unsigned long long total,
-                                                           unsigned rows, unsigned cols, unsigned win)
+                                                           unsigned rows, unsigned cols, unsigned win, unsigned chunks, unsigned rpc)
 {
     const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= total) return;
-    const unsigned long long per_clip = static_cast<unsigned long long>(rows) * cols;
-    const unsigned long long clip = g / per_clip;
-    const unsigned rc = static_cast<unsigned>(g - clip * per_clip);
-    const unsigned i = rc / cols, c = rc - i * cols;
-    const float *src = ms + clip * per_clip + c;
+    const unsigned c = static_cast<unsigned>(g % cols);
+    const unsigned long long cc = g / cols;
+    const unsigned chunk = static_cast<unsigned>(cc % chunks);
+    const unsigned long long clip = cc / chunks;
+    const unsigned i0 = chunk * rpc, i1 = min(rows, i0 + rpc);
+    const float *src = ms + clip * rows * cols + c;
+    float *dst = out + clip * rows * cols + c;
     const long long pad = (win - 1) / 2;
-    double s = 0.0, q = 0.0;
-    for (unsigned w = 0; w < win; ++w) s += static_cast<double>(src[static_cast<size_t>(sym_index(static_cast<long long>(i) + w - pad, rows)) * cols]);
-    const double m = s / win;
+    SymWalk head(static_cast<long long>(i0) - pad, rows), tail = head;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
     for (unsigned w = 0; w < win; ++w) {
-        const double d = static_cast<double>(src[static_cast<size_t>(sym_index(static_cast<long long>(i) + w - pad, rows)) * cols]) - m;
-        q += d * d;
+        const double v = static_cast<double>(src[static_cast<size_t>(head.idx) * cols]);
+        s1 += v;
+        s2 += v * v;
+        head.step();
     }
-    out[g] = static_cast<float>(static_cast<double>(src[static_cast<size_t>(i) * cols]) / (sqrt(q / win) + kEps30));
+    for (unsigned i = i0; i < i1; ++i) {
+        const double m = s1 / win;
+        const double var = fmax(s2 / win - m * m, 0.0);
+        dst[static_cast<size_t>(i) * cols] = static_cast<float>(static_cast<double>(src[static_cast<size_t>(i) * cols]) / (sqrt(var) + kEps30));
+        const double vin = static_cast<double>(src[static_cast<size_t>(head.idx) * cols]);
+        const double vout = static_cast<double>(src[static_cast<size_t>(tail.idx) * cols]);
+        s1 += vin - vout;
+        s2 += vin * vin - vout * vout;
+        head.step();
+        tail.step();
+    }
 }
 
 // derivative along the FEATURE axis with edge clamping, literal reference arithmetic: sum_R (R f[c+R] - f[c-R]) / sum_R 2R^2
@@ -182,11 +248,23 @@ int ss_cmvn_batch_device(const float *d_vec, size_t batch, size_t rows, size_t c
     int rc = ss::check_shape(d_vec, d_out, batch, rows, cols);
     if (rc) return rc;
     if (batch == 0) return SS_OK;
-    const unsigned long long n = static_cast<unsigned long long>(batch) * cols;
-    hipLaunchKernelGGL(ss::ss_cmvn_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_vec, d_out, n,
-                       static_cast<unsigned>(rows), static_cast<unsigned>(cols), variance_normalization);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_cmvn_kernel");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // rows are summed in chunks (one thread per clip, chunk and column), then every element is normalised
+    const unsigned chunks = static_cast<unsigned>(std::min<size_t>(64, (rows + 31) / 32));
+    const unsigned rpc = static_cast<unsigned>((rows + chunks - 1) / chunks);
+    const unsigned long long np = static_cast<unsigned long long>(batch) * chunks * cols;
+    const unsigned long long n = static_cast<unsigned long long>(batch) * rows * cols;
+    double *d_part = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&d_part), np * 2 * sizeof(double), s);
+    if (e != hipSuccess) return ss::hip_err(e, "hipMallocAsync");
+    hipLaunchKernelGGL(ss::ss_cmvn_partial_kernel, dim3(ss::blocks_for(np)), dim3(256), 0, s, d_vec, d_part, np, static_cast<unsigned>(rows),
+                       static_cast<unsigned>(cols), chunks, rpc);
+    hipLaunchKernelGGL(ss::ss_cmvn_apply_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_vec, d_part, d_out, n, static_cast<unsigned>(rows),
+                       static_cast<unsigned>(cols), chunks, variance_normalization);
+    e = hipFreeAsync(d_part, s);
+    if (e != hipSuccess) return ss::hip_err(e, "hipFreeAsync");
+    e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_cmvn kernels");
 }
 
 int ss_cmvnw_batch_device(const float *d_vec, size_t batch, size_t rows, size_t cols, size_t win_size, int variance_normalization,
@@ -198,17 +276,21 @@ int ss_cmvnw_batch_device(const float *d_vec, size_t batch, size_t rows, size_t 
     if (win_size >= (1ull << 31)) return ss::fail(SS_ERR_ARG, "window too large");
     if (batch == 0) return SS_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned long long n = static_cast<unsigned long long>(batch) * rows * cols;
     const unsigned r = static_cast<unsigned>(rows), c = static_cast<unsigned>(cols), w = static_cast<unsigned>(win_size);
+    // a thread slides the window over a chunk of rows: chunks long enough to amortise the first window sum
+    const unsigned rpc = static_cast<unsigned>(std::min<size_t>(256, std::max<size_t>(8, (win_size + 15) / 16)));
+    const unsigned chunks = (r + rpc - 1) / rpc;
+    const unsigned long long nt = static_cast<unsigned long long>(batch) * chunks * cols;
+    const unsigned long long n = static_cast<unsigned long long>(batch) * rows * cols;
     if (!variance_normalization) {
-        hipLaunchKernelGGL(ss::ss_cmvnw_mean_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_vec, d_out, n, r, c, w);
+        hipLaunchKernelGGL(ss::ss_cmvnw_mean_kernel, dim3(ss::blocks_for(nt)), dim3(256), 0, s, d_vec, d_out, nt, r, c, w, chunks, rpc);
     } else {
         // the second pass reads its neighbours' mean-subtracted values: they go through a stream-ordered scratch block
         float *d_ms = nullptr;
         hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&d_ms), n * sizeof(float), s);
         if (e != hipSuccess) return ss::hip_err(e, "hipMallocAsync");
-        hipLaunchKernelGGL(ss::ss_cmvnw_mean_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_vec, d_ms, n, r, c, w);
-        hipLaunchKernelGGL(ss::ss_cmvnw_var_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, s, d_ms, d_out, n, r, c, w);
+        hipLaunchKernelGGL(ss::ss_cmvnw_mean_kernel, dim3(ss::blocks_for(nt)), dim3(256), 0, s, d_vec, d_ms, nt, r, c, w, chunks, rpc);
+        hipLaunchKernelGGL(ss::ss_cmvnw_var_kernel, dim3(ss::blocks_for(nt)), dim3(256), 0, s, d_ms, d_out, nt, r, c, w, chunks, rpc);
         e = hipFreeAsync(d_ms, s);
         if (e != hipSuccess) return ss::hip_err(e, "hipFreeAsync");
     }
