@@ -1,0 +1,78 @@
+"""Seeded sweep over the configuration space: every case goes through the public Python front (hence through whichever
+kernel build the dispatcher picks: default-bank / generic-bank / windowed / pre-emphasised builds of the 512-point kernel,
+the 2048- and 4096-point kernels, the generic kernel) and is compared with the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _rel(got, want):
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        sr = int(rng.choice([8000, 16000, 22050, 44100]))
+        n_fft = int(rng.choice([256, 512, 512, 512, 1024, 2048, 4096]))
+        flen = int(rng.integers(n_fft // 4, n_fft + 1))
+        if rng.random() < 0.7:
+            flen &= ~1  # even frame lengths reach the dedicated kernels
+        step = int(rng.integers(max(8, flen // 8), flen + 1))
+        if rng.random() < 0.7:
+            step &= ~1
+        M = int(rng.choice([20, 26, 40, 40, 48, 64, 128, 256]))
+        C = int(rng.integers(1, min(M, 40) + 1))
+        kw = dict(sample_rate=sr, fft_points=n_fft, frame_length=(flen + 0.25) / sr, frame_stride=(step + 0.25) / sr,
+                  num_cepstral=C, num_filters=M, low_frequency=float(rng.choice([0.0, 50.0, 300.0])),
+                  high_frequency=float(sr / 2 * rng.choice([1.0, 1.0, 0.8])), dc_elimination=bool(rng.random() < 0.7))
+        sw = {}
+        if rng.random() < 0.3:
+            sw["mfcc_window"] = str(rng.choice(["hann", "vorbis"]))
+        if rng.random() < 0.25:
+            sw["preemph_coef"] = 0.97
+            sw["preemph_shift"] = int(rng.choice([1, 1, 2, 5]))
+        if rng.random() < 0.25:
+            sw["spectrum_exponent"] = 2
+        if rng.random() < 0.25:
+            sw["dct_norm"] = "ortho"
+        if rng.random() < 0.15:
+            sw.update(framing="center", pad_mode=str(rng.choice(["reflect", "constant"])))
+        if rng.random() < 0.2:
+            sw.update(mel_scale=str(rng.choice(["slaney", "htk"])), mel_norm=str(rng.choice(["none", "slaney"])))
+        batch = int(rng.choice([1, 3, 9]))
+        n_samples = int(flen + step * rng.integers(1, 40) + rng.integers(0, step))
+        out.append((kw, sw, batch, n_samples))
+    return out
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_configurations(ss, oracle, sslib, block):
+    import torch
+
+    kernels = set()
+    for i, (kw, sw, batch, n) in enumerate(_cases(24, 1000 + block)):
+        try:
+            p = oracle.make_params(**kw, **sw)
+            oracle.filterbank(p)
+            T = oracle.num_frames(p, n)
+        except oracle.OracleError:
+            continue  # a combination the reference itself rejects (filter edges outside the spectrum, no frames, ...)
+        x = (np.random.default_rng(7 * i + block).standard_normal((batch, n)) * 0.1).astype(np.float32)
+        args = dict(frame_length=kw["frame_length"], frame_stride=kw["frame_stride"], num_cepstral=kw["num_cepstral"],
+                    num_filters=kw["num_filters"], fft_length=kw["fft_points"], low_frequency=kw["low_frequency"],
+                    high_frequency=kw["high_frequency"], dc_elimination=kw["dc_elimination"])
+        got = ss.mfcc_batch(torch.from_numpy(x).cuda(), kw["sample_rate"], **args, **sw).cpu().numpy()
+        kernels.add(sslib.ss_last_kernel_name().decode().split("<")[0])
+        assert got.shape == (batch, T, kw["num_cepstral"]), (kw, sw)
+        for b in {0, batch - 1}:
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (kw, sw, b)
+        margs = {k: v for k, v in args.items() if k not in ("num_cepstral", "dc_elimination")}
+        feat, en = ss.mfe_batch(torch.from_numpy(x).cuda(), kw["sample_rate"], **margs, **sw)
+        wf, we = oracle.mfe(p, x[batch - 1])
+        assert _rel(feat[batch - 1].cpu().numpy(), wf) <= RTOL and _rel(en[batch - 1].cpu().numpy(), we) <= RTOL, (kw, sw)
+    assert kernels  # at least one case ran
