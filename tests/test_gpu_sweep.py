@@ -76,3 +76,38 @@ def test_random_configurations(ss, oracle, sslib, block):
         wf, we = oracle.mfe(p, x[batch - 1])
         assert _rel(feat[batch - 1].cpu().numpy(), wf) <= RTOL and _rel(en[batch - 1].cpu().numpy(), we) <= RTOL, (kw, sw)
     assert kernels  # at least one case ran
+
+
+def test_random_mel_spectrogram_configurations(ss, oracle, sslib):
+    """STFT branch (feature.rs:151-174): random fft sizes / hops / filter counts / channel counts, 1-D and 2-D inputs."""
+    rng = np.random.default_rng(4242)
+    ran = 0
+    for i in range(40):
+        sr = int(rng.choice([8000, 16000, 44100]))
+        n_fft = int(rng.choice([256, 512, 1024, 2048, 2048, 4096]))
+        hop = int(rng.integers(n_fft // 16, n_fft // 2 + 1))
+        if rng.random() < 0.6:
+            hop &= ~1
+        M = int(rng.choice([20, 40, 64, 128]))
+        kw = dict(sample_rate=sr, fft_points=n_fft, frame_length=(hop + 0.5) / sr, frame_stride=(hop + 0.5) / sr, num_cepstral=13,
+                  num_filters=M, low_frequency=0.0, high_frequency=float(sr / 2 * rng.choice([1.0, 0.9])))
+        ch = int(rng.choice([1, 1, 2, 5]))
+        n = int(rng.integers(hop * 3, hop * 40))
+        if rng.random() < 0.5:
+            n &= ~1
+        try:
+            p = oracle.make_params(**kw)
+            oracle.filterbank(p)
+            oracle.stft_rows(p, n)
+        except oracle.OracleError:
+            continue
+        x = (np.random.default_rng(100 + i).standard_normal((ch, n)) * 0.1).astype(np.float32)
+        args = dict(frame_length=kw["frame_length"], frame_stride=kw["frame_stride"], num_filters=M, fft_length=n_fft,
+                    high_frequency=kw["high_frequency"])
+        sig = x[0] if ch == 1 and rng.random() < 0.5 else x
+        got = ss.mel_spectrogram(sig, sr, **args)
+        want = oracle.mel_spectrogram(p, sig)
+        assert got.shape == want.shape, (kw, ch, n)
+        assert _rel(got, want) <= RTOL, (kw, ch, n)
+        ran += 1
+    assert ran >= 20
