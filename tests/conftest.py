@@ -23,8 +23,15 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def sslib():
-    """The built C-ABI library (fails loudly if it is missing: there is no CPU fallback)."""
+    """The built C-ABI library (fails loudly if it is missing: there is no CPU fallback).  A clean checkout has no
+    binaries (they are git-ignored), so the library is built here the way `__graft_entry__.build()` does when it is absent;
+    hipcc cross-compiles for gfx950 without a GPU."""
+    import subprocess
+
     from speechsauce_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc")], check=True)
 
     return _lib.lib()
 
