@@ -554,6 +554,10 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
         return pow2 ? go(ss_mfcc_c256<10, false, true, WAVES, false, 12>, "ss_mfcc_c256<10,pow2>")
                     : go(ss_mfcc_c256<10, false, false, WAVES, false, 12>, "ss_mfcc_c256<10>");
     }
+    if (a.flen <= 416) {  // 25 ms at 16 kHz (400 samples): 13 of the 16 first-pass inputs
+        return pow2 ? go(ss_mfcc_c256<13, false, true, WAVES, false, 12>, "ss_mfcc_c256<13,pow2>")
+                    : go(ss_mfcc_c256<13, false, false, WAVES, false, 12>, "ss_mfcc_c256<13>");
+    }
     return pow2 ? go(ss_mfcc_c256<16, false, true, WAVES, false, 12>, "ss_mfcc_c256<16,pow2>")
                 : go(ss_mfcc_c256<16, false, false, WAVES, false, 12>, "ss_mfcc_c256<16>");
 }
