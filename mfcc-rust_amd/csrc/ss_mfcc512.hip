@@ -479,6 +479,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     }
 }
 
+constexpr int NE13RES = 4;  // resident-table set of the 13-input default-bank build (symmetric DCT; the twiddles would spill)
+
 template <int WAVES>
 hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
@@ -555,6 +557,9 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
                     : go(ss_mfcc_c256<10, false, false, WAVES, false, 12>, "ss_mfcc_c256<10>");
     }
     if (a.flen <= 416) {  // 25 ms at 16 kHz (400 samples): 13 of the 16 first-pass inputs
+        // the bank does not depend on the frame length: the default bank keeps its fixed tap counts and symmetric DCT
+        if (!pow2 && b421 && a.n_filters == 40 && WAVES <= 12 && !a.out_mfe && a.win_floats == 0 && a.preemph == 0.0f)
+            return go(ss_mfcc_c256<13, false, false, WAVES, true, 10, NE13RES>, "ss_mfcc_c256<13,bank421,sym>");
         return pow2 ? go(ss_mfcc_c256<13, false, true, WAVES, false, 12>, "ss_mfcc_c256<13,pow2>")
                     : go(ss_mfcc_c256<13, false, false, WAVES, false, 12>, "ss_mfcc_c256<13>");
     }

@@ -226,6 +226,22 @@ def test_front_end_fast_path(ss, oracle, sslib):
         assert _rel(feat[20].cpu().numpy(), wf) <= RTOL and _rel(en[20].cpu().numpy(), we) <= RTOL
 
 
+def test_25ms_frames(ss, oracle, sslib):
+    """The classic 25 ms / 10 ms speech front end (400-sample frames in a 512-point FFT): 13-input build of the kernel."""
+    import torch
+
+    x = _signal(15, (33, 16000))
+    got = ss.mfcc_batch(torch.from_numpy(x).cuda(), 16000, frame_length=0.025).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256<13")
+    p = oracle.make_params(**dict(CFG1, frame_length=0.025))
+    assert got.shape == (33, oracle.num_frames(p, 16000), 13)
+    for b in (0, 16, 32):
+        assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL
+    got26 = ss.mfcc_batch(torch.from_numpy(x).cuda(), 16000, frame_length=0.025, num_filters=26).cpu().numpy()
+    p26 = oracle.make_params(**dict(CFG1, frame_length=0.025, num_filters=26))
+    assert _rel(got26[5], oracle.mfcc(p26, x[5])) <= RTOL
+
+
 def test_literal_framing_known_answer(ss, oracle):
     """processing.rs:110-120 as written copies nothing for > 2 frames: output is signal-independent."""
     x = _signal(10, 16000)
