@@ -149,9 +149,14 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool mfe_shape = a.flen == 320 && a.spectrum_exponent != 2 && cfg->fast.q4[0] == 4 && cfg->fast.q4[1] == 2 &&
                            cfg->fast.q4[2] == 1 && a.n_filters <= 40;
     const bool front = a.preemph != 0.0f || a.window != nullptr;  // optional window / fused pre-emphasis: default-bank build only
+    // librosa-compatible variants: centred frames (flen % 4 == 0) and banks over the whole spectrum have MFCC builds of their
+    // own (optional window, no fused pre-emphasis)
+    const bool centre = a.frame_mode == ss::FRAME_CENTER;
+    const bool lib_variant = centre || cfg->fast.fullp;
+    const bool lib_ok = out_kind == ss::OUT_MFCC && a.preemph == 0.0f && (!centre || a.flen % 4 == 0);
     const bool fast_ok = !force_generic && cfg->fast.ok &&
                          (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape) || (out_kind == ss::OUT_POWER && mfe_shape && !front)) &&
-                         (!front || mfe_shape) && a.frame_mode == ss::FRAME_NORMAL &&
+                         (lib_variant ? lib_ok : (!front || mfe_shape)) && (a.frame_mode == ss::FRAME_NORMAL || centre) &&
                          (a.flen % 2 == 0) && (a.step % 2 == 0) &&
                          (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
     // SS_MFCC512_VARIANT=mfma selects the block-sparse f32-MFMA mel+DCT build (ss_mfcc512_mfma.hip) for A/B runs
@@ -160,7 +165,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool fits32 = static_cast<unsigned long long>(batch) * T < 0xffffffffull;
     static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only: per-wave realtime stamps of ONE launch
     static bool dbg_done = false;
-    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC && !front) {
+    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC && !front && !lib_variant) {
         ss::Fast512MArgs f{};
         f.x = d_x;
         f.ld = ld;
@@ -215,6 +220,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.win_floats = a.window ? cfg->fast.win_floats : 0;
         f.preemph = a.preemph;
         f.preemph_shift = a.preemph_shift;
+        f.center = centre;
+        f.pad_reflect = a.pad_reflect;
+        f.fullp = cfg->fast.fullp;
         if (dbg_path && !dbg_done && !f.out_mfe) {
             dbg_done = true;
             const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;

@@ -93,6 +93,10 @@ struct Fast512Args {
     int32_t win_floats;     // > 0: frame window [flen] behind the mel rows of the table block
     float preemph;          // != 0: y[n] = x[n] - preemph * x[(n - preemph_shift) mod n_samples] (processing.rs:31-53) on load
     uint32_t preemph_shift;
+    // librosa-compatible variants (ss_params.framing = SS_FRAMING_CENTER, banks that cover the whole spectrum)
+    int32_t center;         // frame t covers x[t*step - flen/2 : t*step + flen/2); flen % 4 == 0
+    int32_t pad_reflect;    // center: np.pad 'reflect' outside the clip (else zeros)
+    int32_t fullp;          // the table block was built for P rows of all 257 bins
     unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
     // filled by launch_mfcc_c256: floor(x / n_frames) = umulhi(x, nf_magic) >> nf_shift for x < 2^31 (nf_magic = 0: divide)
     uint32_t nf_magic, nf_shift;

@@ -295,8 +295,11 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     f = Fast512Tables{};
     const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
     if (t.d.n_fft != 512 || M > 48 || Cc > 16) return;
-    if (t.bank.last_bin > 129) return;  // the kernel keeps P bins 0..128 (the bank ends at (F+1)/2 when high = sr/2)
-    constexpr int32_t kRow = 132;       // P bins a tap may touch: 0..128 plus three zero pad bins
+    // reference banks end at (F+1)/2 (feature.rs:69-70): the kernel then keeps P bins 0..128 only; a bank that reaches
+    // higher (mel_scale = slaney / htk) gets the builds with the whole row of 257 bins
+    if (t.bank.last_bin > 257) return;
+    f.fullp = t.bank.last_bin > 129;
+    const int32_t kRow = f.fullp ? 260 : 132;  // P bins a tap may touch, including three zero pad bins
     // order filters by tap count (longest first) and deal them 16 per slot
     std::vector<int32_t> order(M);
     for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);

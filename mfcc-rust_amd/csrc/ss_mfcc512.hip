@@ -92,7 +92,7 @@ __device__ __forceinline__ float ln_scaled(float xs)
 }
 
 // Issues the loads of one quad; returns this lane's frame index within its clip.
-template <int NE, bool EXACT, bool PRE>
+template <int NE, bool EXACT, bool PRE, bool CENTER = false>
 __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, float2 (&vin)[NE],
                                               float2 (&pin)[PRE ? NE : 1])
 {
@@ -110,6 +110,41 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
         const unsigned gf = q4 + fl;
         clip = gf / a.n_frames;
         t = gf - clip * a.n_frames;
+    }
+    if (CENTER) {
+        // librosa center=True: frame t is centred on sample t*step.  Frames inside the clip load like contract frames from
+        // their (even) start; the few at the clip edges mirror (np.pad 'reflect') or zero their out-of-range samples.
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+        const int s0 = static_cast<int>(t * a.step) - static_cast<int>(a.flen / 2), ns = static_cast<int>(a.n_samples);
+        const bool inside = s0 >= 0 && s0 + static_cast<int>(a.flen) <= ns;
+        if (__all(inside)) {
+            const float2 *srcc = reinterpret_cast<const float2 *>(xc + s0);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int n = j + 16 * e;
+                vin[e] = 2 * n < static_cast<int>(a.flen) ? srcc[n] : make_float2(0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int n = j + 16 * e;
+                float sv[2] = {0.f, 0.f};
+                if (2 * n < static_cast<int>(a.flen)) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        int pos = s0 + 2 * n + h;
+                        bool ok = true;
+                        if (pos < 0 || pos >= ns) {
+                            if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+                            else ok = false;
+                        }
+                        if (ok) sv[h] = xc[pos];
+                    }
+                }
+                vin[e] = make_float2(sv[0], sv[1]);
+            }
+        }
+        return t;
     }
     // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
     const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
@@ -168,7 +203,8 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, int OUTK = 0, int FRONT = 0>
+template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, int OUTK = 0, int FRONT = 0, bool FULLP = false,
+          bool CENTER = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
     constexpr bool PREFETCH = WAVES <= 12;
@@ -185,8 +221,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     // ---- LDS carve: per-wave regions, then the shared read-only table block, then the quad counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloats;
     float2 *zh = reinterpret_cast<float2 *>(wbase) + f * kZStride;        // this frame's exchange slot
-    float *prow = wbase + kPOff + f * kPRow;                              // P[0..128] + zero pad bins 129..131
-    float *frow = wbase + f * 48;                                         // ln(mel) in (slot, lane) order (after the exchange)
+    // P row: bins 0..128 + zero pad bins behind the exchange slots; FULLP: all 257 bins (+ pad) inside the frame's own
+    // exchange slot, with the ln(mel) row behind it
+    float *prow = FULLP ? wbase + f * (2 * kZStride) : wbase + kPOff + f * kPRow;
+    float *frow = FULLP ? prow + 264 : wbase + f * 48;  // ln(mel) in (slot, lane) order (after the exchange)
     float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloats;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
@@ -207,14 +245,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         const int n4 = (L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0)) / 4;
         for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) *s_next = q_lo + WAVES;
-        if (j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
+        if (!FULLP && j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
     }
     // first quad of this wave; its loads are in flight across the barrier
     unsigned quad = q_lo + wave;
     float2 vin[NE];
     float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
-    if (quad < q_hi) t_next = load_quad<NE, EXACT, PRE>(a, quad, total, f, j, vin, pin);
+    if (quad < q_hi) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
 
     const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
@@ -224,9 +262,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     __syncthreads();
     // first P bin of this lane's three filters, as float indices into LDS; opaque so that the full address stays in a
     // register (the compiler otherwise re-adds the P-row offset in front of every ds_read2)
-    int st0 = wave * kWaveFloats + kPOff + f * kPRow + s_start[j];
-    int st1 = wave * kWaveFloats + kPOff + f * kPRow + s_start[16 + j];
-    int st2 = wave * kWaveFloats + kPOff + f * kPRow + s_start[32 + j];
+    const int pbase = wave * kWaveFloats + (FULLP ? f * (2 * kZStride) : kPOff + f * kPRow);
+    int st0 = pbase + s_start[j];
+    int st1 = pbase + s_start[16 + j];
+    int st2 = pbase + s_start[32 + j];
     asm volatile("" : "+v"(st0), "+v"(st1), "+v"(st2));
     const float *smem_f = reinterpret_cast<const float *>(smem);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
@@ -269,7 +308,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         next = __builtin_amdgcn_readfirstlane(next);
         ++n_done;
 
-        if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE>(a, quad, total, f, j, vin, pin);
+        if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
         const unsigned t_cur = t_next;
         float2 v[16];
 #pragma unroll
@@ -290,7 +329,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         wave_order();
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
-        if (PREFETCH && next < q_hi) t_next = load_quad<NE, EXACT, PRE>(a, next, total, f, j, vin, pin);
+        if (PREFETCH && next < q_hi) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -343,7 +382,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 }
                 continue;
             }
-            prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70)
+            prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70) ...
+            if (FULLP) prow[256 - j - 16 * r] = pb;  // ... unless the bank covers the whole spectrum
             esum += pa + pb;
         }
         if (j == 0) {
@@ -358,6 +398,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 esum += p128;
             }
         }
+        if (FULLP && j < 3) prow[257 + j] = 0.f;  // pad bins (the slot was overwritten by the exchange)
         if (PWR) {
             wave_order();
             quad = next;
@@ -521,6 +562,31 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
     };
     const bool pow2 = a.spectrum_exponent == 2;
     const bool b421 = a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1;
+    if (a.fullp || a.center) {
+        // librosa-compatible variants: P rows of all 257 bins (banks that cover the whole spectrum) and / or centred frames;
+        // MFCC output, optional frame window, no fused pre-emphasis
+        if constexpr (WAVES != 12) {
+            return hipErrorInvalidValue;
+        } else {
+            if (a.out_mfe || a.preemph != 0.0f || (a.center && a.flen % 4 != 0)) return hipErrorInvalidValue;
+            const bool win = a.win_floats > 0;
+#define SS_LV(P2, FR, FP, CE, NAME) return go(ss_mfcc_c256<16, false, P2, WAVES, false, 12, 0, 0, FR, FP, CE>, NAME)
+            if (a.fullp && !a.center) {
+                if (pow2) { if (win) SS_LV(true, 1, true, false, "ss_mfcc_c256<16,pow2,win,fullp>"); SS_LV(true, 0, true, false, "ss_mfcc_c256<16,pow2,fullp>"); }
+                if (win) SS_LV(false, 1, true, false, "ss_mfcc_c256<16,win,fullp>");
+                SS_LV(false, 0, true, false, "ss_mfcc_c256<16,fullp>");
+            }
+            if (!a.fullp) {
+                if (pow2) { if (win) SS_LV(true, 1, false, true, "ss_mfcc_c256<16,pow2,win,center>"); SS_LV(true, 0, false, true, "ss_mfcc_c256<16,pow2,center>"); }
+                if (win) SS_LV(false, 1, false, true, "ss_mfcc_c256<16,win,center>");
+                SS_LV(false, 0, false, true, "ss_mfcc_c256<16,center>");
+            }
+            if (pow2) { if (win) SS_LV(true, 1, true, true, "ss_mfcc_c256<16,pow2,win,fullp,center>"); SS_LV(true, 0, true, true, "ss_mfcc_c256<16,pow2,fullp,center>"); }
+            if (win) SS_LV(false, 1, true, true, "ss_mfcc_c256<16,win,fullp,center>");
+            SS_LV(false, 0, true, true, "ss_mfcc_c256<16,fullp,center>");
+#undef SS_LV
+        }
+    }
     static const char *res_env = std::getenv("SS_RES");  // A/B knob: register-resident tables (bit 0 cosines, bit 1 twiddles)
     int res = res_env ? std::atoi(res_env) : 6;  // 2: twiddles resident (140 VGPRs, 0.7 us faster than 0; 3 spills); 6: + symmetric DCT (165 VGPRs, another 1.2 %)
     if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
@@ -576,11 +642,11 @@ bool mfcc_c256_has_mfe(const Fast512Args &a)
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    // mfe output, frame window and pre-emphasis exist for the default-bank build only
-    if ((a.out_mfe || a.win_floats > 0 || a.preemph != 0.0f) && !mfcc_c256_has_mfe(a)) return hipErrorInvalidValue;
+    // mfe output, frame window and pre-emphasis exist for the default-bank build only (the librosa-style builds take a window)
+    if (!(a.fullp || a.center) && (a.out_mfe || a.win_floats > 0 || a.preemph != 0.0f) && !mfcc_c256_has_mfe(a)) return hipErrorInvalidValue;
     // 12 waves per CU (3 per SIMD, <= 168 VGPRs, 138 KB of LDS): measured equal to 14 and 16 and 8 % faster than 8
     static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
-    if (w && std::atoi(w) == 8) return launch_w<8>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 8 && !a.fullp && !a.center) return launch_w<8>(a, stream, num_cus, info);
     return launch_w<12>(a, stream, num_cus, info);
 }
 

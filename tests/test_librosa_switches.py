@@ -121,7 +121,7 @@ def test_host_tables_follow_the_switches(sslib, oracle):
 # ------------------------------------------------------------------------------------------------------------------ GPU
 
 @pytest.mark.gpu
-def test_librosa_like_front_end_gpu(ss, oracle):
+def test_librosa_like_front_end_gpu(ss, oracle, sslib):
     import torch
 
     x = _signal(62, (9, 16000))
@@ -134,6 +134,12 @@ def test_librosa_like_front_end_gpu(ss, oracle):
                                                        "num_cepstral", "num_filters")}
         args = dict(frame_length=kw.get("frame_length", 0.02), frame_stride=kw.get("frame_stride", 0.01))
         got = ss.mfcc_batch(xd, 16000, **args, **sw).cpu().numpy()
+        name = sslib.ss_last_kernel_name().decode()
+        if kw.get("preemph_coef"):
+            assert name.startswith("ss_front_generic")  # fused pre-emphasis stays on the generic kernel in these modes
+        else:  # builds of the 512-point kernel with centred frames and / or P rows over the whole spectrum
+            assert name.startswith("ss_mfcc_c256<16") and ("center" in name) == (kw.get("framing") == "center") \
+                and ("fullp" in name) == (kw.get("mel_scale", "reference") != "reference"), name
         assert got.shape[1] == oracle.num_frames(p, 16000)
         for b in (0, 4, 8):
             assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (kw, b)
