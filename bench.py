@@ -173,7 +173,14 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver)
+        try:
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL
+        except Exception as e:  # the control plane (barrier, max over ranks) also works over gloo; --gather needs RCCL
+            if args.gather:
+                raise
+            print(f"[bench] rank {rank}: RCCL init failed ({e}); using gloo for the barriers", file=sys.stderr, flush=True)
+            dist.init_process_group(backend="gloo")
 
     desc, pkw, n_samples, clips, kind = WORKLOADS[args.workload]
     if args.params:
@@ -268,7 +275,7 @@ def main():
     dev_ms = e0.elapsed_time(e1)  # HIP events on the launch stream over the timed region
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
