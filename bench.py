@@ -169,6 +169,8 @@ def main():
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if os.environ.get("SS_BENCH_ONE_DEVICE"):  # test aid: several ranks on one GPU (exercises the multi-rank control flow)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
