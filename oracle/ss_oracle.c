@@ -393,7 +393,7 @@ int orc_derivative_extraction(const double *feat, size_t rows, size_t cols, size
 int orc_extract_derivative_feature(const float *feat, size_t rows, size_t cols, double *cube)
 {
     if (rows == 0 || cols == 0) return ORC_ERR_ARG;
-    double *f0 = (double *)malloc(3 * rows * cols * sizeof(double));
+    double *f0 = (double *)calloc(3 * rows * cols, sizeof(double));
     if (!f0) return ORC_ERR_ARG;
     double *d1 = f0 + rows * cols, *d2 = d1 + rows * cols;
     for (size_t i = 0; i < rows * cols; ++i) f0[i] = (double)feat[i];
