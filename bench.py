@@ -256,12 +256,19 @@ def main():
     torch.cuda.synchronize()
 
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ten intermediate events on the launch stream: median / spread of the per-launch time over tenths of the timed region
+    seg_every = max(1, args.steps // 10)
+    seg_events = []
     t0 = time.perf_counter()
     e0.record(stream)
     for i in range(args.steps):
         o = step(i)
         if gather_bufs is not None:
             gather(i, o)
+        if args.streams == 1 and (i + 1) % seg_every == 0 and i + 1 < args.steps:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            seg_events.append((i + 1, ev))
     for st in extra_streams:  # the end event on the launch stream waits for the other streams' work
         ev = torch.cuda.Event()
         ev.record(st)
@@ -287,6 +294,8 @@ def main():
         value = total_frames / elapsed
         avg_launch_s = dev_ms * 1e-3 / args.steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
+        marks = [(0, e0)] + seg_events + [(args.steps, e1)]
+        segs = sorted(a_ev.elapsed_time(b_ev) * 1e3 / (b_i - a_i) for (a_i, a_ev), (b_i, b_ev) in zip(marks[:-1], marks[1:]) if b_i > a_i)
         res = {
             "metric": "mfcc_frames_per_sec" if kind == "mfcc" else "mel_rows_per_sec",
             "value": value,
@@ -320,6 +329,7 @@ def main():
                 "traffic": load_traffic(kernel, args.workload),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": avg_launch_s * 1e6,
+                "launch_us_median_min_max_over_tenths": [segs[len(segs) // 2], segs[0], segs[-1]],
                 "frames_per_sec_kernel_only": frames_per_launch / avg_launch_s,
             },
         }
