@@ -163,7 +163,9 @@ struct Mfcc4096Args {
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
-    float *out;
+    float *out;          // MFCC [frames x n_ceps], or (out_mfe) mel energies [frames x n_filters]
+    float *out_energy;   // out_mfe: frame energies [frames]
+    int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)
     float *dbg;  // diagnostic (SS_DEBUG_ROWS): frame 0's P row [1028] + ln(mel) row [256], or null
 };
 

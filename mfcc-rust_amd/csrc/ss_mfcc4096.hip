@@ -100,7 +100,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <bool EXACT, bool POW2, int WAVES>
+template <bool EXACT, bool POW2, int WAVES, bool MFE = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -289,9 +289,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int s = 0; s < 4; ++s) {
                 float m = hscale32 * mel_slot_h(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 m = m == 0.f ? kEpsH * kTwo32H : m;
-                frow[fi[s]] = ln_scaled_h(m);
+                if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32H);  // exact: power of two
+                else frow[fi[s]] = ln_scaled_h(m);
                 off += a.mel_q4[s];
             }
+        }
+        if (MFE) {  // mfe (feature.rs:200-233): mel energies (written above) and the frame energy
+            if (lane == 0) a.out_energy[frame] = energy * (1.0f / kTwo32H);
+            wave_order_h();
+            frame = next;
+            continue;
         }
         wave_order_h();
         if (a.dbg && frame == 0) {
@@ -365,6 +372,10 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096;
+    if (a.out_mfe) {
+        if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES, true>, "ss_mfcc_c2048<exact,pow2,mfe>") : go(ss_mfcc_c2048<true, false, WAVES, true>, "ss_mfcc_c2048<exact,mfe>");
+        return pow2 ? go(ss_mfcc_c2048<false, true, WAVES, true>, "ss_mfcc_c2048<pow2,mfe>") : go(ss_mfcc_c2048<false, false, WAVES, true>, "ss_mfcc_c2048<mfe>");
+    }
     if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
     return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
 }

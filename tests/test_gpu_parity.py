@@ -486,6 +486,22 @@ def test_cpp_mirror_parity(tmp_path, oracle):
     assert _rel(n, oracle.cmvn(m, True)) <= RTOL
 
 
+def test_cfg5_mfe(ss, oracle, sslib):
+    """mfe at the high-resolution configuration: the mfe build of the 4096-point kernel (256 filters, 19 of them empty)."""
+    import torch
+
+    x = _signal(24, (5, 44100))
+    kw = dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_filters=256, fft_length=4096)
+    feat, en = ss.mfe_batch(torch.from_numpy(x).cuda(), 44100, **kw)
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c2048<") and b"mfe" in sslib.ss_last_kernel_name()
+    assert feat.shape == (5, 39, 256) and en.shape == (5, 39)
+    p = oracle.make_params(**CFG5)
+    for b in (0, 4):
+        wf, we = oracle.mfe(p, x[b])
+        assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL
+    assert (feat.cpu().numpy() == np.float32(1.1920929e-7)).sum() >= 5 * 39 * 19  # the empty filters: exactly EPS
+
+
 def test_kernel_variants_agree(ss):
     """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
     the variant is chosen once per process from the environment)."""
