@@ -254,7 +254,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     }
     // fft_points = 4096 MFCC (256 filters): the one-frame-per-wave kernel under the same layout assumptions
     if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL &&
-        a.preemph == 0.0f && a.window == nullptr && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
+        a.preemph == 0.0f && (a.window == nullptr || a.spectrum_exponent != 2) && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mfcc4096Args f{};
         f.x = d_x;
@@ -278,6 +278,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out = out0;
         f.out_energy = out1;
         f.out_mfe = out_kind == ss::OUT_MFE;
+        f.window = a.window;
         static const char *rows_path = std::getenv("SS_DEBUG_ROWS");  // diagnostic only: frame 0's P row and ln(mel) row
         if (rows_path) (void)hipMalloc(reinterpret_cast<void **>(&f.dbg), (1028 + 256 + 4 * 4096) * sizeof(float));
         hipError_t e4 = ss::launch_mfcc_c2048(f, stream, cfg->num_cus, &info);

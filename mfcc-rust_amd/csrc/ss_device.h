@@ -166,6 +166,7 @@ struct Mfcc4096Args {
     float *out;          // MFCC [frames x n_ceps], or (out_mfe) mel energies [frames x n_filters]
     float *out_energy;   // out_mfe: frame energies [frames]
     int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)
+    const float *window; // optional frame window [flen] in device memory (mfcc_window switch), or null
     float *dbg;  // diagnostic (SS_DEBUG_ROWS): frame 0's P row [1028] + ln(mel) row [256], or null
 };
 

@@ -100,7 +100,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <bool EXACT, bool POW2, int WAVES, bool MFE = false>
+template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -163,6 +163,17 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         for (int e = 0; e < 32; ++e) {
             if (EXACT) v[e] = src[64 * e];
             else v[e] = 2 * (lane + 64 * e) < static_cast<int>(a.flen) ? src[64 * e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
+        }
+        if (WIN) {
+            // optional frame window (mfcc_window switch): sample pairs from the 16 KB table in device memory (L2-resident)
+            const float2 *w2 = reinterpret_cast<const float2 *>(a.window) + lane;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                if (EXACT || 2 * (lane + 64 * e) < static_cast<int>(a.flen)) {
+                    const float2 w = w2[64 * e];
+                    v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
+                }
+            }
         }
         // ---- pass 1: radix-32 over n2 ----
         fft_reg<32>(v);
@@ -372,6 +383,11 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096;
+    if (a.window) {  // windowed builds: MFCC and mfe, magnitude spectrum
+        if (pow2 || (a.flen & 1)) return hipErrorInvalidValue;
+        if (a.out_mfe) return exact ? go(ss_mfcc_c2048<true, false, WAVES, true, true>, "ss_mfcc_c2048<exact,mfe,win>") : go(ss_mfcc_c2048<false, false, WAVES, true, true>, "ss_mfcc_c2048<mfe,win>");
+        return exact ? go(ss_mfcc_c2048<true, false, WAVES, false, true>, "ss_mfcc_c2048<exact,win>") : go(ss_mfcc_c2048<false, false, WAVES, false, true>, "ss_mfcc_c2048<win>");
+    }
     if (a.out_mfe) {
         if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES, true>, "ss_mfcc_c2048<exact,pow2,mfe>") : go(ss_mfcc_c2048<true, false, WAVES, true>, "ss_mfcc_c2048<exact,mfe>");
         return pow2 ? go(ss_mfcc_c2048<false, true, WAVES, true>, "ss_mfcc_c2048<pow2,mfe>") : go(ss_mfcc_c2048<false, false, WAVES, true>, "ss_mfcc_c2048<mfe>");

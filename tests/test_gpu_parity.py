@@ -502,6 +502,26 @@ def test_cfg5_mfe(ss, oracle, sslib):
     assert (feat.cpu().numpy() == np.float32(1.1920929e-7)).sum() >= 5 * 39 * 19  # the empty filters: exactly EPS
 
 
+def test_cfg5_windowed(ss, oracle, sslib):
+    """Frame window at the high-resolution configuration: windowed builds of the 4096-point kernel (mfcc and mfe),
+    full frames and frames shorter than the FFT."""
+    import torch
+
+    x = _signal(25, (4, 44100))
+    xd = torch.from_numpy(x).cuda()
+    for flen in (4096, 3000):
+        kw = dict(frame_length=flen / 44100, frame_stride=1024 / 44100, num_filters=256, fft_length=4096)
+        p = oracle.make_params(**dict(CFG5, frame_length=flen / 44100, mfcc_window="hann"))
+        got = ss.mfcc_batch(xd, 44100, num_cepstral=40, mfcc_window="hann", **kw).cpu().numpy()
+        name = sslib.ss_last_kernel_name()
+        assert name.startswith(b"ss_mfcc_c2048<") and b"win" in name, name
+        assert _rel(got[3], oracle.mfcc(p, x[3])) <= RTOL
+        feat, en = ss.mfe_batch(xd, 44100, mfcc_window="hann", **kw)
+        assert b"mfe,win" in sslib.ss_last_kernel_name()
+        wf, we = oracle.mfe(p, x[0])
+        assert _rel(feat[0].cpu().numpy(), wf) <= RTOL and _rel(en[0].cpu().numpy(), we) <= RTOL
+
+
 def test_kernel_variants_agree(ss):
     """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
     the variant is chosen once per process from the environment)."""
