@@ -124,7 +124,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const int Cc = static_cast<int>(a.n_ceps);
     const int melw0 = L::kCos + Cc * L::kCosPitch;
     const float *s_melw = s_tab + melw0;
-    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + melw0 + 64 * a.mel_wpitch);
+    // WIN: the frame window (4096 floats, zero beyond flen) sits behind the table block
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + melw0 + 64 * a.mel_wpitch);
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + melw0 + 64 * a.mel_wpitch + (WIN ? 4096 : 0));
 
     const unsigned total = a.batch * a.n_frames;
     const unsigned f_lo = static_cast<unsigned>(static_cast<unsigned long long>(total) * blockIdx.x / gridDim.x);
@@ -132,6 +134,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     {
         const int n4 = (melw0 + 64 * a.mel_wpitch) / 4;
         for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (WIN) {
+            float *wdst = s_tab + melw0 + 64 * a.mel_wpitch;
+            for (int i = tid; i < 4096; i += WAVES * 64) wdst[i] = i < static_cast<int>(a.flen) ? a.window[i] : 0.f;
+        }
         if (tid == 0) *s_next = f_lo + WAVES;
     }
     __syncthreads();
@@ -165,14 +171,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             else v[e] = 2 * (lane + 64 * e) < static_cast<int>(a.flen) ? src[64 * e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
         }
         if (WIN) {
-            // optional frame window (mfcc_window switch): sample pairs from the 16 KB table in device memory (L2-resident)
-            const float2 *w2 = reinterpret_cast<const float2 *>(a.window) + lane;
+            // optional frame window (mfcc_window switch): sample pairs from the copy in LDS
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
-                if (EXACT || 2 * (lane + 64 * e) < static_cast<int>(a.flen)) {
-                    const float2 w = w2[64 * e];
-                    v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
-                }
+                const float2 w = s_win[lane + 64 * e];
+                v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
             }
         }
         // ---- pass 1: radix-32 over n2 ----
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 template <int WAVES>
 hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + L::kCos + static_cast<size_t>(a.n_ceps) * L::kCosPitch +
+    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.n_ceps) * L::kCosPitch +
                         64 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
