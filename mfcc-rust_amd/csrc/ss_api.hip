@@ -37,6 +37,9 @@ struct ss_config {
     // fft_points = 4096 MFCC kernel tables (ss_mfcc4096.hip)
     ss::Mfcc4096Tables mfcc4096;
     float *d_mfcc4096_tab = nullptr;
+    // fft_points = 2048 MFCC kernel tables (ss_mfcc2048.hip)
+    ss::Mfcc2048Tables mfcc2048;
+    float *d_mfcc2048_tab = nullptr;
 };
 
 namespace {
@@ -252,6 +255,38 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
+    // fft_points = 2048 MFCC / mfe: two frames per wave (ss_mfcc2048.hip), same layout assumptions, optional frame window
+    if (!force_generic && cfg->mfcc2048.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
+        a.frame_mode == ss::FRAME_NORMAL && a.preemph == 0.0f && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
+        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        ss::Mfcc2048Args f{};
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tab = cfg->d_mfcc2048_tab;
+        f.mel_wpitch = cfg->mfcc2048.wpitch;
+        for (int s = 0; s < 4; ++s) f.mel_q4[s] = cfg->mfcc2048.q4[s];
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        f.windowed = cfg->mfcc2048.windowed;
+        f.out_mfe = out_kind == ss::OUT_MFE;
+        f.out = out0;
+        f.out_energy = out1;
+        hipError_t e2 = ss::launch_mfcc_c1024(f, stream, cfg->num_cus, &info);
+        if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c1024");
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
     // fft_points = 4096 MFCC (256 filters): the one-frame-per-wave kernel under the same layout assumptions
     if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL &&
         a.preemph == 0.0f && (a.window == nullptr || a.spectrum_exponent != 2) && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
@@ -429,6 +464,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     }
     ss::build_mfcc4096(h, c->mfcc4096);
     if (c->mfcc4096.ok) SS_UP(d_mfcc4096_tab, c->mfcc4096.tab);
+    ss::build_mfcc2048(h, c->mfcc2048);
+    if (c->mfcc2048.ok) SS_UP(d_mfcc2048_tab, c->mfcc2048.tab);
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
@@ -445,7 +482,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

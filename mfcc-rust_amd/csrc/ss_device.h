@@ -150,6 +150,27 @@ struct Mel2048Args {
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
+// Arguments of the fft_points = 2048 MFCC / mfe kernel (ss_mfcc2048.hip).
+struct Mfcc2048Args {
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples, batch, flen, step, n_frames;
+    float scale;  // 1/N (processing.rs:180)
+    int32_t spectrum_exponent;
+    const float *tab;    // table block (layout: ss::mfcc2048_layout in ss_internal.h), copied verbatim into LDS
+    int32_t mel_wpitch;  // floats per lane weight row
+    int32_t mel_q4[4];   // taps / 4 per slot
+    uint32_t n_filters, n_ceps;
+    float dct_scale_k, dct_scale_0, dct_scale_00;
+    int32_t dc_elimination;
+    int32_t windowed;    // the table block carries a frame window (mfcc_window switch)
+    int32_t out_mfe;     // 1: write mfe's (features, energy) instead of the cepstra
+    float *out;
+    float *out_energy;
+};
+
+hipError_t launch_mfcc_c1024(const Mfcc2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 // Arguments of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip).
 struct Mfcc4096Args {
     const float *x;

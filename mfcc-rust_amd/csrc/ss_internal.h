@@ -118,6 +118,27 @@ struct Mel2048Tables {
 };
 void build_mel2048(const HostTables &t, Mel2048Tables &f);
 
+// Table block of the fft_points = 2048 MFCC / mfe kernel (ss_mfcc2048.hip), float offsets; global layout == LDS layout.
+namespace mfcc2048_layout {
+constexpr int kTw2 = 0;                  // [16][32] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 1024)
+constexpr int kTwn = kTw2 + 16 * 128;    // [16][32] float2: exp(-2 pi i (j + 32 r) / 2048)
+constexpr int kWin = kTwn + 16 * 64;     // [1024] float2: frame window pairs (zero beyond flen); unused without a window
+constexpr int kStart = kWin + 2048;      // [4][32] int32: first P bin (multiple of 4) of the filter owned by (slot, lane)
+constexpr int kFilt = kStart + 128;      // [4][32] int32: filter index of (slot, lane), -1 if none
+constexpr int kCos = kFilt + 128;        // [32][68]: row c: cos(pi c (2m+1) / 2M), m < M/2 (the other half by symmetry), zero padded
+constexpr int kCosPitch = 68;
+constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
+}  // namespace mfcc2048_layout
+
+struct Mfcc2048Tables {
+    bool ok = false;
+    bool windowed = false;
+    std::vector<float> tab;
+    int32_t q4[4] = {0, 0, 0, 0};
+    int32_t wpitch = 0;
+};
+void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f);
+
 // Table block of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip), float offsets.  Reader lane L' = k1 + 32 a.
 namespace mfcc4096_layout {
 constexpr int kT1 = 0;                    // [16][32] float4: (W^(k1(2p+1)), W^(k1(2p+2))), W = exp(-2 pi i / 1024)

@@ -1,0 +1,332 @@
+// ss_mfcc_c1024: fused MFCC / mfe for fft_points = 2048 (C = 1024 packed complex points) on gfx950 -- the frame path
+// (feature.rs:99-148, :200-233; processing.rs:65-181) one size up from ss_mfcc512.hip and one down from ss_mfcc4096.hip.
+//
+//   * 32 lanes own a frame, 32 complex points per lane; a wave carries two consecutive frames of the flat frame list.  One
+//     persistent 8-wave workgroup per CU; waves pull frame pairs from an LDS counter.
+//   * FFT exactly as in ss_mel2048.hip: radix-32, ONE transposing exchange through wave-private LDS in two register halves
+//     (ds_write_b64 scatter to 34*(n1>>1) + 2*k1' + (n1&1), ds_read_b128 back), twiddle, radix-32.  No workgroup barrier
+//     in the main loop.
+//   * untangle with ds_bpermute_b32 (partner = lane 32-j, register 31-r): bins 0..512 go to the P row (the mel bank ends at
+//     (F+1)/2, feature.rs:69-70), all 1025 feed the frame energy (feature.rs:216-219), summed over the half-wave.
+//   * banded mel (4 filters per lane, aligned float4 taps), zero handling, ln -> row in filter order; DCT-II with the
+//     m <-> M-1-m symmetry of the cosine (sum / difference rows, half the table), reference scaling, column-0 replacement.
+//   * optional frame window (mfcc_window switch) from the table block; mfe build stops after the mel stage.
+// Reference semantics as in ss_mfcc512.hip; tables: ss::mfcc2048_layout (ss_internal.h).
+#include "ss_device.h"
+#include "ss_fft_reg.h"
+#include "ss_internal.h"
+
+namespace ss {
+
+namespace {
+
+namespace L = mfcc2048_layout;
+constexpr float kEpsG = 1.1920929e-7f;      // f32::EPSILON, functions.rs:70
+constexpr float kTwo32G = 4294967296.f;
+constexpr int kExSlotsG = 2 * 16 * 34;      // float2 in the wave's exchange region: two frames x half the columns (8704 B)
+constexpr int kWaveFloatsG = kExSlotsG * 2;
+constexpr int kHalfFloats = kWaveFloatsG / 2;  // per frame after the exchange: P row [520] | ln(mel) row [128] | s [64] | d [64]
+
+__device__ __forceinline__ void wave_order_g()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float bperm_g(int addr, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// ln(x) for a value handed over as x * 2^32 (see ss_mfcc512.hip)
+__device__ __forceinline__ float ln_scaled_g(float xs)
+{
+    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
+}
+
+__device__ __forceinline__ float mel_slot_g(const float4 *w4, const float4 *p4, int q4)
+{
+    float acc = 0.f;
+    int i = 0;
+    for (; i + 4 <= q4; i += 4) {
+        float4 w[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = w4[i + u];
+            t[u] = p4[i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = fmaf(w[u].x, t[u].x, acc);
+            acc = fmaf(w[u].y, t[u].y, acc);
+            acc = fmaf(w[u].z, t[u].z, acc);
+            acc = fmaf(w[u].w, t[u].w, acc);
+        }
+    }
+    for (; i < q4; ++i) {
+        const float4 w = w4[i], t = p4[i];
+        acc = fmaf(w.x, t.x, acc);
+        acc = fmaf(w.y, t.y, acc);
+        acc = fmaf(w.z, t.z, acc);
+        acc = fmaf(w.w, t.w, acc);
+    }
+    return acc;
+}
+
+// sum over the 32 lanes of a half-wave; every lane of the half ends with the same bits
+__device__ __forceinline__ float half_sum(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <bool POW2, bool MFE, bool WIN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int half = lane >> 5;  // frame within the wave
+    const int j = lane & 31;     // lane within the frame
+
+    float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsG;
+    float2 *ex = reinterpret_cast<float2 *>(wbase);
+    float *hb = wbase + half * kHalfFloats;  // this frame's rows after the exchange
+    float *prow = hb, *frow = hb + 520, *srow = hb + 648, *drow = hb + 712;
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloatsG;
+    const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const float *s_cos = s_tab + L::kCos;
+    const float *s_melw = s_tab + L::kMelW;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+
+    const unsigned total = a.batch * a.n_frames;
+    const unsigned units = (total + 1) / 2;
+    const unsigned u_lo = static_cast<unsigned>(static_cast<unsigned long long>(units) * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(static_cast<unsigned long long>(units) * (blockIdx.x + 1) / gridDim.x);
+    {
+        const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
+        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = u_lo + WAVES;
+    }
+    __syncthreads();
+    int st[4], fi[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st[s] = s_start[s * 32 + j];
+        fi[s] = s_filt[s * 32 + j];
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
+    const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32G;
+    const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2;
+    // valid sample pairs of this lane: n = j + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
+    const int e_hi = min(32, max(0, (static_cast<int>(a.flen) / 2 - j + 31) >> 5));
+
+    unsigned unit = u_lo + wave;
+    while (unit < u_hi) {
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+
+        const unsigned gf_raw = 2 * unit + half;
+        const bool live = gf_raw < total;
+        const unsigned gf = live ? gf_raw : total - 1;
+        const unsigned clip = gf / a.n_frames;
+        const unsigned t = gf - clip * a.n_frames;
+        // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
+        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step) + j;
+        float2 v[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            float2 s = make_float2(0.f, 0.f);
+            if (e < e_hi) s = src[32 * e];
+            v[e] = s;
+        }
+        if (WIN) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const float2 w = s_win[j + 32 * e];
+                v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
+            }
+        }
+        // ---- 1024-point complex FFT: radix-32, transpose through LDS (two register halves), twiddle, radix-32 ----
+        fft_reg<32>(v);
+        float2 u[32];
+        float2 *exf = ex + half * (16 * 34);
+        const int wbh = 34 * (j >> 1) + (j & 1);
+        const int jl = j & 15;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[k];
+        wave_order_g();
+        if (j < 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&exf[34 * p + 2 * jl]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order_g();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[16 + k];
+        wave_order_g();
+        if (j >= 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&exf[34 * p + 2 * jl]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order_g();
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float4 w2 = s_tw2[p * 32 + j];
+            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+            if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        }
+        fft_reg<32>(u);  // u[r] = Z[j + 32 r]
+
+        // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
+        float esum = 0.f;
+#pragma unroll
+        for (int hb2 = 0; hb2 < 2; ++hb2) {
+            float2 zcs[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm_g(paddr, u[31 - (8 * hb2 + q)].x), bperm_g(paddr, u[31 - (8 * hb2 + q)].y));
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const int q = 8 * hb2 + qq;
+                const float2 zk = u[q];
+                // lane 0 pairs with itself: Z[1024 - 32 q] = own register (32 - q) & 31
+                const float2 zc = j == 0 ? u[(32 - q) & 31] : zcs[qq];
+                const float2 w = s_twn[q * 32 + j];
+                const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+                const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
+                // 2 X[k] = s - i w d, 2 conj X[1024-k] = 2 s - 2 X[k]
+                const float xa_r = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
+                const float xa_i = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
+                const float xb_r = fmaf(2.f, s.x, -xa_r), xb_i = fmaf(2.f, s.y, -xa_i);
+                const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
+                const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);
+                const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+                prow[j + 32 * q] = pa;  // bins 0..511 (the bank ends at (F+1)/2, feature.rs:69-70); 512 below
+                esum += pa + pb;        // X[0] and X[1024] come from lane 0's self pair (q = 0)
+            }
+        }
+        if (j == 0) {
+            const float2 z = u[16];  // X[512] = conj Z[512]
+            const float n = 4.f * (z.x * z.x + z.y * z.y);
+            const float p512 = POW2 ? n : __builtin_amdgcn_sqrtf(n);
+            prow[512] = p512;
+            esum += p512;
+        }
+        if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        float energy = hscale32 * half_sum(esum);              // E * 2^32
+        energy = energy == 0.f ? kEpsG * kTwo32G : energy;     // zero_handling, feature.rs:219
+        wave_order_g();
+
+        // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
+        {
+            int off = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float m = hscale32 * mel_slot_g(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                m = m == 0.f ? kEpsG * kTwo32G : m;
+                if (fi[s] >= 0) {
+                    if (MFE) {
+                        if (live) a.out[static_cast<unsigned long long>(gf) * M + fi[s]] = m * (1.0f / kTwo32G);  // exact: power of two
+                    } else {
+                        frow[fi[s]] = ln_scaled_g(m);
+                    }
+                }
+                off += a.mel_q4[s];
+            }
+        }
+        if (MFE) {
+            if (j == 0 && live) a.out_energy[gf] = energy * (1.0f / kTwo32G);
+            wave_order_g();
+            unit = next;
+            continue;
+        }
+        wave_order_g();
+        // ---- DCT-II (feature.rs:120-123), cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M even: sum and
+        // difference rows once per frame, then a M/2-term product per coefficient ----
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int m = j + 32 * h2;
+            if (m < Mh) {
+                const float lo = frow[m], hi = frow[M - 1 - m];
+                srow[m] = lo + hi;
+                drow[m] = lo - hi;
+            } else if (m < ((Mh + 3) & ~3)) {  // the product below runs over whole float4s
+                srow[m] = 0.f;
+                drow[m] = 0.f;
+            }
+        }
+        wave_order_g();
+        if (j < Cc) {
+            const float4 *r4 = reinterpret_cast<const float4 *>((j & 1) ? drow : srow);
+            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * L::kCosPitch);
+            float acc = 0.f;
+            const int nq = (Mh + 3) / 4;  // the rows are zero-padded to a multiple of 4 by the host table / the loop below
+            for (int i = 0; i < nq; ++i) {
+                const float4 r = r4[i], c = c4[i];
+                acc = fmaf(r.x, c.x, acc);
+                acc = fmaf(r.y, c.y, acc);
+                acc = fmaf(r.z, c.z, acc);
+                acc = fmaf(r.w, c.w, acc);
+            }
+            // scaling + column-0 replacement (feature.rs:126-146)
+            float o = acc * a.dct_scale_k;
+            if (j == 0) o = a.dc_elimination ? ln_scaled_g(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (live) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
+        }
+        wave_order_g();
+        unit = next;
+    }
+}
+
+template <int WAVES>
+hipError_t launch_g(const Mfcc2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloatsG + L::kMelW + 32 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
+    if (total == 0) return hipSuccess;
+    if (total >= 0xffffffffull) return hipErrorInvalidValue;
+    const unsigned long long units = (total + 1) / 2;
+    unsigned long long blocks = (units + WAVES - 1) / WAVES;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    if (blocks > cap) blocks = cap;
+    const unsigned grid = static_cast<unsigned>(blocks);
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    const bool pow2 = a.spectrum_exponent == 2, win = a.windowed != 0;
+    if (a.out_mfe) {
+        if (pow2) return win ? go(ss_mfcc_c1024<true, true, true, WAVES>, "ss_mfcc_c1024<pow2,mfe,win>") : go(ss_mfcc_c1024<true, true, false, WAVES>, "ss_mfcc_c1024<pow2,mfe>");
+        return win ? go(ss_mfcc_c1024<false, true, true, WAVES>, "ss_mfcc_c1024<mfe,win>") : go(ss_mfcc_c1024<false, true, false, WAVES>, "ss_mfcc_c1024<mfe>");
+    }
+    if (pow2) return win ? go(ss_mfcc_c1024<true, false, true, WAVES>, "ss_mfcc_c1024<pow2,win>") : go(ss_mfcc_c1024<true, false, false, WAVES>, "ss_mfcc_c1024<pow2>");
+    return win ? go(ss_mfcc_c1024<false, false, true, WAVES>, "ss_mfcc_c1024<win>") : go(ss_mfcc_c1024<false, false, false, WAVES>, "ss_mfcc_c1024");
+}
+
+}  // namespace
+
+hipError_t launch_mfcc_c1024(const Mfcc2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    return launch_g<8>(a, stream, num_cus, info);
+}
+
+}  // namespace ss

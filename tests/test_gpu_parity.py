@@ -522,6 +522,37 @@ def test_cfg5_windowed(ss, oracle, sslib):
         assert _rel(feat[0].cpu().numpy(), wf) <= RTOL and _rel(en[0].cpu().numpy(), we) <= RTOL
 
 
+def test_mfcc_2048_kernel(ss, oracle, sslib):
+    """MFCC / mfe at fft_points = 2048 (e.g. 22.05 kHz, 2048-sample frames, hop 512, 128 mels, 20 cepstra): the
+    two-frames-per-wave kernel, with and without a frame window, odd frame counts, frames shorter than the FFT."""
+    import torch
+
+    sr = 22050
+    x = _signal(26, (7, sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, sw in ((2048, {}), (2048, dict(mfcc_window="hann")), (1764, dict(spectrum_exponent=2)), (1500, dict(mfcc_window="vorbis", dct_norm="ortho"))):
+        kw = dict(frame_length=flen / sr, frame_stride=512 / sr, num_cepstral=20, num_filters=128, fft_length=2048)
+        p = oracle.make_params(sample_rate=sr, fft_points=2048, frame_length=flen / sr, frame_stride=512 / sr, num_cepstral=20,
+                               num_filters=128, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c1024"), sslib.ss_last_kernel_name()
+        assert got.shape == (7, oracle.num_frames(p, sr), 20)
+        for b in (0, 3, 6):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **sw)
+        assert b"mfe" in sslib.ss_last_kernel_name()
+        wf, we = oracle.mfe(p, x[6])
+        assert _rel(feat[6].cpu().numpy(), wf) <= RTOL and _rel(en[6].cpu().numpy(), we) <= RTOL
+    # 26 filters (13 sum/difference terms: the product runs over whole float4s), 13 cepstra, no dc elimination
+    kw = dict(frame_length=2048 / sr, frame_stride=441 * 2 / sr, num_cepstral=13, num_filters=26, fft_length=2048, dc_elimination=False)
+    p = oracle.make_params(sample_rate=sr, fft_points=2048, frame_length=2048 / sr, frame_stride=882 / sr, num_cepstral=13,
+                           num_filters=26, dc_elimination=False)
+    got = ss.mfcc_batch(xd, sr, **kw).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c1024")
+    assert _rel(got[2], oracle.mfcc(p, x[2])) <= RTOL
+
+
 def test_kernel_variants_agree(ss):
     """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
     the variant is chosen once per process from the environment)."""
