@@ -40,6 +40,9 @@ struct ss_config {
     // fft_points = 2048 MFCC kernel tables (ss_mfcc2048.hip)
     ss::Mfcc2048Tables mfcc2048;
     float *d_mfcc2048_tab = nullptr;
+    // fft_points = 1024 MFCC kernel tables (ss_mfcc1024.hip)
+    ss::Mfcc1024Tables mfcc1024;
+    float *d_mfcc1024_tab = nullptr;
 };
 
 namespace {
@@ -255,8 +258,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    // fft_points = 2048 MFCC / mfe: two frames per wave (ss_mfcc2048.hip), same layout assumptions, optional frame window
-    if (!force_generic && cfg->mfcc2048.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
+    // fft_points = 2048 / 1024 MFCC / mfe: two frames per wave (ss_mfcc2048.hip, ss_mfcc1024.hip), same layout assumptions,
+    // optional frame window
+    if (!force_generic && (cfg->mfcc2048.ok || cfg->mfcc1024.ok) && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
         a.frame_mode == ss::FRAME_NORMAL && a.preemph == 0.0f && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mfcc2048Args f{};
@@ -269,21 +273,22 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.n_frames = a.n_frames;
         f.scale = a.scale;
         f.spectrum_exponent = a.spectrum_exponent;
-        f.tab = cfg->d_mfcc2048_tab;
-        f.mel_wpitch = cfg->mfcc2048.wpitch;
-        for (int s = 0; s < 4; ++s) f.mel_q4[s] = cfg->mfcc2048.q4[s];
+        const bool k2048 = cfg->mfcc2048.ok;
+        f.tab = k2048 ? cfg->d_mfcc2048_tab : cfg->d_mfcc1024_tab;
+        f.mel_wpitch = k2048 ? cfg->mfcc2048.wpitch : cfg->mfcc1024.wpitch;
+        for (int s = 0; s < 4; ++s) f.mel_q4[s] = k2048 ? cfg->mfcc2048.q4[s] : cfg->mfcc1024.q4[s];
         f.n_filters = a.n_filters;
         f.n_ceps = a.n_ceps;
         f.dct_scale_k = a.dct_scale_k;
         f.dct_scale_0 = a.dct_scale_0;
         f.dct_scale_00 = a.dct_scale_00;
         f.dc_elimination = a.dc_elimination;
-        f.windowed = cfg->mfcc2048.windowed;
+        f.windowed = k2048 ? cfg->mfcc2048.windowed : cfg->mfcc1024.windowed;
         f.out_mfe = out_kind == ss::OUT_MFE;
         f.out = out0;
         f.out_energy = out1;
-        hipError_t e2 = ss::launch_mfcc_c1024(f, stream, cfg->num_cus, &info);
-        if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c1024");
+        hipError_t e2 = k2048 ? ss::launch_mfcc_c1024(f, stream, cfg->num_cus, &info) : ss::launch_mfcc_c512(f, stream, cfg->num_cus, &info);
+        if (e2 != hipSuccess) return hip_fail(e2, k2048 ? "launch_mfcc_c1024" : "launch_mfcc_c512");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
@@ -466,6 +471,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mfcc4096.ok) SS_UP(d_mfcc4096_tab, c->mfcc4096.tab);
     ss::build_mfcc2048(h, c->mfcc2048);
     if (c->mfcc2048.ok) SS_UP(d_mfcc2048_tab, c->mfcc2048.tab);
+    ss::build_mfcc1024(h, c->mfcc1024);
+    if (c->mfcc1024.ok) SS_UP(d_mfcc1024_tab, c->mfcc1024.tab);
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
@@ -482,7 +489,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

@@ -171,6 +171,10 @@ struct Mfcc2048Args {
 
 hipError_t launch_mfcc_c1024(const Mfcc2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
+// fft_points = 1024 MFCC / mfe kernel (ss_mfcc1024.hip): same argument block, table layout ss::mfcc1024_layout
+using Mfcc1024Args = Mfcc2048Args;
+hipError_t launch_mfcc_c512(const Mfcc1024Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 // Arguments of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip).
 struct Mfcc4096Args {
     const float *x;

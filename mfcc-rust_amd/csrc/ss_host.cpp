@@ -474,6 +474,77 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
 }
 
 
+void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f)
+{
+    namespace L = mfcc1024_layout;
+    f = Mfcc1024Tables{};
+    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
+    if (t.d.n_fft != 1024 || M > 128 || (M & 1) || Cc > 32) return;  // the symmetric DCT is written for an even filter count
+    if (t.bank.last_bin > 257) return;  // the kernel keeps P bins 0..256 (reference banks end at (F+1)/2)
+    constexpr int32_t kRow = 260;
+    std::vector<int32_t> order(M);
+    for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
+    auto alen = [&](int32_t m) { return t.bank.len[m] ? (t.bank.start[m] & 3) + t.bank.len[m] : 0; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return alen(a) > alen(b); });
+    int32_t maxlen[4] = {0, 0, 0, 0};
+    for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], alen(order[q]));
+    for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
+    if (f.wpitch == 0) f.wpitch = 4;
+    if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: conflict-free ds_read_b128 of the lanes' rows
+    if (f.wpitch > 256) return;
+    f.tab.assign(static_cast<size_t>(L::kMelW) + 32 * static_cast<size_t>(f.wpitch), 0.0f);
+    const double pi = 3.14159265358979323846;
+    auto cis = [&](double num, double den, float *dst) {
+        const double ang = -2.0 * pi * num / den;
+        dst[0] = static_cast<float>(std::cos(ang));
+        dst[1] = static_cast<float>(std::sin(ang));
+    };
+    for (int r = 1; r < 16; ++r)
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const int p = (r - 1) / 2, half = (r - 1) % 2;
+            cis(static_cast<double>(k1 * r), 256.0, &f.tab[L::kT1 + (p * 16 + k1) * 4 + 2 * half]);
+        }
+    for (int i = 0; i < 8; ++i)
+        for (int jj = 0; jj < 32; ++jj) {
+            const int k1 = jj & 15, hh = jj >> 4;
+            cis(static_cast<double>(k1 + 16 * (i + 8 * hh)), 512.0, &f.tab[L::kT2 + (i * 32 + jj) * 2]);
+            cis(static_cast<double>(k1 + 16 * i + 128 * hh), 1024.0, &f.tab[L::kTwn + (i * 32 + jj) * 2]);
+        }
+    if (!t.window_mfcc.empty()) {
+        f.windowed = true;
+        for (size_t i = 0; i < t.window_mfcc.size() && i < 1024; ++i) f.tab[L::kWin + i] = t.window_mfcc[i];
+    }
+    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
+    int32_t off = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int32_t span = 4 * f.q4[s];
+        for (int j = 0; j < 32; ++j) {
+            const size_t q = static_cast<size_t>(s) * 32 + j;
+            start[q] = 0;
+            filt[q] = -1;
+            if (q >= M) continue;
+            const int32_t m = order[q];
+            filt[q] = m;
+            const int32_t len = t.bank.len[m];
+            int32_t shift = len ? (t.bank.start[m] & 3) : 0;
+            int32_t st = len ? t.bank.start[m] - shift : 0;
+            if (st + span > kRow) {
+                shift += st + span - kRow;
+                st = kRow - span;
+            }
+            start[q] = st;
+            for (int32_t i = 0; i < len; ++i)
+                f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
+        }
+        off += span;
+    }
+    for (size_t c = 0; c < Cc; ++c)
+        for (size_t m = 0; m < M / 2; ++m) f.tab[L::kCos + c * L::kCosPitch + m] = t.dct[c * M + m];
+    f.ok = true;
+}
+
 void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
 {
     namespace L = mfcc2048_layout;

@@ -118,6 +118,28 @@ struct Mel2048Tables {
 };
 void build_mel2048(const HostTables &t, Mel2048Tables &f);
 
+// Table block of the fft_points = 1024 MFCC / mfe kernel (ss_mfcc1024.hip), float offsets.  Reader lane jj = k1 + 16 h.
+namespace mfcc1024_layout {
+constexpr int kT1 = 0;                   // [8][16] float4: (W^(k1(2p+1)), W^(k1(2p+2))), W = exp(-2 pi i / 256)
+constexpr int kT2 = kT1 + 8 * 64;        // [8][32] float2: exp(-2 pi i (k1 + 16 (i + 8 h)) / 512)
+constexpr int kTwn = kT2 + 8 * 64;       // [8][32] float2: exp(-2 pi i (k1 + 16 i + 128 h) / 1024)
+constexpr int kWin = kTwn + 8 * 64;      // [512] float2: frame window pairs (zero beyond flen); unused without a window
+constexpr int kStart = kWin + 1024;      // [4][32] int32: first P bin (multiple of 4) of the filter owned by (slot, lane)
+constexpr int kFilt = kStart + 128;      // [4][32] int32: filter index of (slot, lane), -1 if none
+constexpr int kCos = kFilt + 128;        // [32][68]: row c: cos(pi c (2m+1) / 2M), m < M/2, zero padded
+constexpr int kCosPitch = 68;
+constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
+}  // namespace mfcc1024_layout
+
+struct Mfcc1024Tables {
+    bool ok = false;
+    bool windowed = false;
+    std::vector<float> tab;
+    int32_t q4[4] = {0, 0, 0, 0};
+    int32_t wpitch = 0;
+};
+void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f);
+
 // Table block of the fft_points = 2048 MFCC / mfe kernel (ss_mfcc2048.hip), float offsets; global layout == LDS layout.
 namespace mfcc2048_layout {
 constexpr int kTw2 = 0;                  // [16][32] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 1024)

@@ -1,0 +1,341 @@
+// ss_mfcc_c512: fused MFCC / mfe for fft_points = 1024 (C = 512 packed complex points) on gfx950 -- the structure of the
+// 4096-point kernel (ss_mfcc4096.hip) at a quarter of the size, two frames per wave.
+//
+//   * 32 lanes own a frame, 16 complex points per lane.  512-point FFT = 16 x 32: a radix-16 register butterfly over n2
+//     (n = n1 + 32 n2, n1 = lane), ONE transposing exchange through wave-private LDS, then the 32-point transform over n1
+//     split as n1 = a + 2b: lane (k1, a) does a radix-16 butterfly over b, and the last radix-2 over a pairs lanes L and
+//     L + 16 with v_permlane16_swap (odd DPP rows of one register trade places with even rows of another: one swap of
+//     registers (i, 8 + i) gives the even-row lane both halves' column i and the odd-row lane both halves' column 8 + i):
+//       Z[k1 + 16 c + 256 d] = G0[c] + (-1)^d W512^(k1 + 16 c) G1[c],  Ga[c] = FFT16_b(A[a+2b][k1] W256^(b k1))[c].
+//     The exchange is two independent 16 x 16 transposes (even / odd n1), ds_write_b64 scatter to
+//     34*(b>>1) + 2*k1 + (b&1) per class, ds_read_b128 back; conflict-free on both sides.
+//   * real-FFT untangle: lane (k1, h) register r0[i] holds bin k = k1 + 16 i + 128 h (< 256); its partner 512 - k is
+//     r1[7 - i] of lane (16 - k1, 1 - h) (r1[8 - i] for the k1 = 0 lanes), fetched with ds_bpermute_b32.
+//   * |X|/N: bins 0..256 go to the P row (the mel bank ends at (F+1)/2, feature.rs:69-70), all 513 feed the frame energy.
+//   * banded mel (4 filters per lane, aligned float4 taps), zero handling, ln, symmetric DCT-II (sum / difference rows),
+//     reference scaling, column-0 replacement; optional frame window; mfe build.
+//   * 12 waves per CU, frame pairs from an LDS counter; no workgroup barrier in the main loop.
+// Reference semantics: feature.rs:99-148 (mfcc), :200-233 (mfe), processing.rs:65-181.  Tables: ss::mfcc1024_layout.
+#include "ss_device.h"
+#include "ss_fft_reg.h"
+#include "ss_internal.h"
+
+namespace ss {
+
+namespace {
+
+namespace L = mfcc1024_layout;
+constexpr float kEpsK = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
+constexpr float kTwo32K = 4294967296.f;
+constexpr int kClsK = 8 * 34 + 8;        // float2 per class slice (+8: the two classes of a write group sit 16 banks apart)
+constexpr int kFrameF2 = 560;            // float2 per frame region (4480 B = 128 mod 256: the two frames of a wave use different banks)
+constexpr int kFrameFloats = 2 * kFrameF2;  // after the exchange: P row [260] | ln(mel) row [128] | s [64] | d [64]
+constexpr int kWaveFloatsK = 2 * kFrameFloats;
+
+__device__ __forceinline__ void wave_order_k()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float bperm_k(int addr, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+
+// v_permlane16_swap: the odd DPP rows (lanes 16..31, 48..63) of `a` trade places with the even rows of `b`
+// (tools/ubench/permlane16.hip).  Inline assembly with its own hazard s_nop, as for v_permlane32_swap in ss_mfcc4096.hip.
+__device__ __forceinline__ void swap_rows(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+__device__ __forceinline__ float ln_scaled_k(float xs)
+{
+    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
+}
+
+__device__ __forceinline__ float mel_slot_k(const float4 *w4, const float4 *p4, int q4)
+{
+    float acc = 0.f;
+    int i = 0;
+    for (; i + 4 <= q4; i += 4) {
+        float4 w[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = w4[i + u];
+            t[u] = p4[i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = fmaf(w[u].x, t[u].x, acc);
+            acc = fmaf(w[u].y, t[u].y, acc);
+            acc = fmaf(w[u].z, t[u].z, acc);
+            acc = fmaf(w[u].w, t[u].w, acc);
+        }
+    }
+    for (; i < q4; ++i) {
+        const float4 w = w4[i], t = p4[i];
+        acc = fmaf(w.x, t.x, acc);
+        acc = fmaf(w.y, t.y, acc);
+        acc = fmaf(w.z, t.z, acc);
+        acc = fmaf(w.w, t.w, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float half_sum_k(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <bool POW2, bool MFE, bool WIN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int fr = lane >> 5;                 // frame within the wave
+    const int jj = lane & 31;                 // lane within the frame
+    const int k1 = jj & 15, h = jj >> 4;      // reader view: column k1, half a = h
+    const int cls = jj & 1, bw = jj >> 1;     // writer view: n1 = jj = cls + 2 bw
+
+    float *fbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsK + fr * kFrameFloats;
+    float2 *exf = reinterpret_cast<float2 *>(fbase);
+    float *prow = fbase, *frow = fbase + 260, *srow = fbase + 388, *drow = fbase + 452;
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloatsK;
+    const float4 *s_t1 = reinterpret_cast<const float4 *>(s_tab + L::kT1);
+    const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const float *s_cos = s_tab + L::kCos;
+    const float *s_melw = s_tab + L::kMelW;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+
+    const unsigned total = a.batch * a.n_frames;
+    const unsigned units = (total + 1) / 2;
+    const unsigned u_lo = static_cast<unsigned>(static_cast<unsigned long long>(units) * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(static_cast<unsigned long long>(units) * (blockIdx.x + 1) / gridDim.x);
+    {
+        const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
+        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = u_lo + WAVES;
+    }
+    __syncthreads();
+    int st[4], fi[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st[s] = s_start[s * 32 + jj];
+        fi[s] = s_filt[s * 32 + jj];
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + jj * a.mel_wpitch);
+    const int paddr = ((lane & 32) | ((16 - k1) & 15) | ((1 - h) << 4)) << 2;  // lane holding Z[512 - k]
+    float2 *exw = exf + cls * kClsK + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
+    const float2 *exr = exf + h * kClsK + 2 * k1;                  // reader base
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32K;
+    const bool k1z = k1 == 0;
+    const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2;
+    // valid sample pairs of this lane: n = jj + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
+    const int e_hi = min(16, max(0, (static_cast<int>(a.flen) / 2 - jj + 31) >> 5));
+
+    unsigned unit = u_lo + wave;
+    while (unit < u_hi) {
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+
+        const unsigned gf_raw = 2 * unit + fr;
+        const bool live = gf_raw < total;
+        const unsigned gf = live ? gf_raw : total - 1;
+        const unsigned clip = gf / a.n_frames;
+        const unsigned t = gf - clip * a.n_frames;
+        // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
+        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step) + jj;
+        float2 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float2 s = make_float2(0.f, 0.f);
+            if (e < e_hi) s = src[32 * e];
+            if (WIN) {
+                const float2 w = s_win[jj + 32 * e];
+                s = make_float2(s.x * w.x, s.y * w.y);
+            }
+            v[e] = s;
+        }
+        // ---- pass 1: radix-16 over n2; transpose (two 16 x 16 problems: even and odd n1) ----
+        fft_reg<16>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
+        wave_order_k();
+        float2 u[16];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(&exr[34 * p]);
+            u[2 * p] = make_float2(t4.x, t4.y);
+            u[2 * p + 1] = make_float2(t4.z, t4.w);
+        }
+        wave_order_k();
+        // ---- twiddle W256^(b k1), radix-16 over b ----
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float4 w2 = s_t1[p * 16 + k1];
+            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+            if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        }
+        fft_reg<16>(u);  // u[c] = G_a[c], a = h
+        // ---- radix-2 over a with one row swap per register pair: r0[i] (d = 0) and r1[i] (d = 1) hold
+        //      Z[k1 + 16 c + 256 d] = G0[c] + (-1)^d W512^(k1 + 16 c) G1[c],  c = i + 8 h ----
+        float2 r0[8], r1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float px = u[i].x, qx = u[8 + i].x, py = u[i].y, qy = u[8 + i].y;
+            swap_rows(px, qx);
+            swap_rows(py, qy);
+            const float2 wq = cmul(make_float2(qx, qy), s_t2[i * 32 + jj]);
+            r0[i] = make_float2(px + wq.x, py + wq.y);
+            r1[i] = make_float2(px - wq.x, py - wq.y);
+        }
+
+        // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
+        // k1 = 0 lanes pair with r1[8 - i] of the other k1 = 0 lane of the frame; their i = 0 pairs are in-lane: (k1, h) = (0, 0)
+        // has k = 0 (X[0] and X[512] come from Z[0] alone), (0, 1) has (128, 384) = (r0[0], r1[0]).  Z[256] = r1[0] of (0, 0).
+        float esum = 0.f;
+        float2 zcs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 sv = k1z ? r1[(8 - i) & 7] : r1[7 - i];
+            zcs[i] = make_float2(bperm_k(paddr, sv.x), bperm_k(paddr, sv.y));
+        }
+        float *pdst = prow + k1 + 128 * h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 zk = r0[i];
+            float2 zc = zcs[i];
+            if (i == 0) zc = k1z ? (h ? r1[0] : zk) : zc;
+            const float2 w = s_twn[i * 32 + jj];
+            const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+            const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+            // 2 X[k] = s - i w dd, 2 conj X[512-k] = 2 s - 2 X[k]
+            const float xa_r = fmaf(w.y, dd.x, fmaf(w.x, dd.y, s.x));
+            const float xa_i = fmaf(w.y, dd.y, fmaf(-w.x, dd.x, s.y));
+            const float xb_r = fmaf(2.f, s.x, -xa_r), xb_i = fmaf(2.f, s.y, -xa_i);
+            const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
+            const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);
+            const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+            pdst[16 * i] = pa;  // bins 0..255 (the bank ends at (F+1)/2, feature.rs:69-70); 256 below
+            esum += pa + pb;
+        }
+        if (jj == 0) {
+            const float2 z = r1[0];  // X[256] = conj Z[256]
+            const float n = 4.f * (z.x * z.x + z.y * z.y);
+            const float p256 = POW2 ? n : __builtin_amdgcn_sqrtf(n);
+            prow[256] = p256;
+            esum += p256;
+        }
+        if (jj < 3) prow[257 + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        float energy = hscale32 * half_sum_k(esum);            // E * 2^32
+        energy = energy == 0.f ? kEpsK * kTwo32K : energy;     // zero_handling, feature.rs:219
+        wave_order_k();
+
+        // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
+        {
+            int off = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float m = hscale32 * mel_slot_k(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                m = m == 0.f ? kEpsK * kTwo32K : m;
+                if (fi[s] >= 0) {
+                    if (MFE) {
+                        if (live) a.out[static_cast<unsigned long long>(gf) * M + fi[s]] = m * (1.0f / kTwo32K);  // exact: power of two
+                    } else {
+                        frow[fi[s]] = ln_scaled_k(m);
+                    }
+                }
+                off += a.mel_q4[s];
+            }
+        }
+        if (MFE) {
+            if (jj == 0 && live) a.out_energy[gf] = energy * (1.0f / kTwo32K);
+            wave_order_k();
+            unit = next;
+            continue;
+        }
+        wave_order_k();
+        // ---- DCT-II (feature.rs:120-123) with the m <-> M-1-m symmetry of the cosine (M even) ----
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int m = jj + 32 * h2;
+            if (m < Mh) {
+                const float lo = frow[m], hi = frow[M - 1 - m];
+                srow[m] = lo + hi;
+                drow[m] = lo - hi;
+            } else if (m < ((Mh + 3) & ~3)) {  // the product below runs over whole float4s
+                srow[m] = 0.f;
+                drow[m] = 0.f;
+            }
+        }
+        wave_order_k();
+        if (jj < Cc) {
+            const float4 *r4 = reinterpret_cast<const float4 *>((jj & 1) ? drow : srow);
+            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + jj * L::kCosPitch);
+            float acc = 0.f;
+            const int nq = (Mh + 3) / 4;
+            for (int i = 0; i < nq; ++i) {
+                const float4 r = r4[i], c = c4[i];
+                acc = fmaf(r.x, c.x, acc);
+                acc = fmaf(r.y, c.y, acc);
+                acc = fmaf(r.z, c.z, acc);
+                acc = fmaf(r.w, c.w, acc);
+            }
+            // scaling + column-0 replacement (feature.rs:126-146)
+            float o = acc * a.dct_scale_k;
+            if (jj == 0) o = a.dc_elimination ? ln_scaled_k(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (live) a.out[static_cast<unsigned long long>(gf) * Cc + jj] = o;
+        }
+        wave_order_k();
+        unit = next;
+    }
+}
+
+template <int WAVES>
+hipError_t launch_k(const Mfcc1024Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloatsK + L::kMelW + 32 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
+    if (total == 0) return hipSuccess;
+    if (total >= 0xffffffffull) return hipErrorInvalidValue;
+    const unsigned long long units = (total + 1) / 2;
+    unsigned long long blocks = (units + WAVES - 1) / WAVES;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    if (blocks > cap) blocks = cap;
+    const unsigned grid = static_cast<unsigned>(blocks);
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    const bool pow2 = a.spectrum_exponent == 2, win = a.windowed != 0;
+    if (a.out_mfe) {
+        if (pow2) return win ? go(ss_mfcc_c512<true, true, true, WAVES>, "ss_mfcc_c512<pow2,mfe,win>") : go(ss_mfcc_c512<true, true, false, WAVES>, "ss_mfcc_c512<pow2,mfe>");
+        return win ? go(ss_mfcc_c512<false, true, true, WAVES>, "ss_mfcc_c512<mfe,win>") : go(ss_mfcc_c512<false, true, false, WAVES>, "ss_mfcc_c512<mfe>");
+    }
+    if (pow2) return win ? go(ss_mfcc_c512<true, false, true, WAVES>, "ss_mfcc_c512<pow2,win>") : go(ss_mfcc_c512<true, false, false, WAVES>, "ss_mfcc_c512<pow2>");
+    return win ? go(ss_mfcc_c512<false, false, true, WAVES>, "ss_mfcc_c512<win>") : go(ss_mfcc_c512<false, false, false, WAVES>, "ss_mfcc_c512");
+}
+
+}  // namespace
+
+hipError_t launch_mfcc_c512(const Mfcc1024Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    return launch_k<12>(a, stream, num_cus, info);
+}
+
+}  // namespace ss

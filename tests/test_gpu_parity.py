@@ -553,6 +553,32 @@ def test_mfcc_2048_kernel(ss, oracle, sslib):
     assert _rel(got[2], oracle.mfcc(p, x[2])) <= RTOL
 
 
+def test_mfcc_1024_kernel(ss, oracle, sslib):
+    """MFCC / mfe at fft_points = 1024 (e.g. 22.05 kHz, 1024-sample frames, hop 256, 64 mels, 20 cepstra): the
+    permlane16 kernel, with and without a frame window, short frames, odd frame counts, power spectrum."""
+    import torch
+
+    sr = 22050
+    x = _signal(27, (9, sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, M, C, sw in ((1024, 64, 20, {}), (1024, 128, 32, dict(mfcc_window="hann")), (882, 40, 13, dict(spectrum_exponent=2)),
+                           (700, 26, 13, dict(mfcc_window="vorbis", dct_norm="ortho", dc_elimination=False))):
+        kw = dict(frame_length=flen / sr, frame_stride=256 / sr, num_cepstral=C, num_filters=M, fft_length=1024)
+        p = oracle.make_params(sample_rate=sr, fft_points=1024, frame_length=flen / sr, frame_stride=256 / sr, num_cepstral=C,
+                               num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c512"), sslib.ss_last_kernel_name()
+        assert got.shape == (9, oracle.num_frames(p, sr), C)
+        for b in (0, 4, 8):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, M, sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        msw = {k: v for k, v in sw.items() if k != "dc_elimination"}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
+        assert b"mfe" in sslib.ss_last_kernel_name()
+        wf, we = oracle.mfe(p, x[8])
+        assert _rel(feat[8].cpu().numpy(), wf) <= RTOL and _rel(en[8].cpu().numpy(), we) <= RTOL
+
+
 def test_kernel_variants_agree(ss):
     """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
     the variant is chosen once per process from the environment)."""
