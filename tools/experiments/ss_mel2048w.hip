@@ -1,3 +1,4 @@
+// RETIRED EXPERIMENT (not built): needs the mel2048w_layout / build_mel2048w host tables of commit history; see DESIGN.md 4.1 findings.
 // ss_mel_c1024w: fused mel spectrogram for fft_points = 2048 (C = 1024 packed complex points), "wide" mapping: ONE row
 // per 64 lanes with 16 complex points per lane (ss_mel2048.hip holds 32 per lane, two rows per wave).  Half the registers
 // per lane (<= 128 VGPRs) buys 3 waves per SIMD instead of 2, which is what the 2048-point kernel lacks: it is bound by
