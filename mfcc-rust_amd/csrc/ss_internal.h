@@ -155,6 +155,7 @@ constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
 struct Mfcc2048Tables {
     bool ok = false;
     bool windowed = false;
+    bool fullp = false;  // the bank reaches past bin 512 (librosa-style banks up to fs/2): LIB builds
     std::vector<float> tab;
     int32_t q4[4] = {0, 0, 0, 0};
     int32_t wpitch = 0;

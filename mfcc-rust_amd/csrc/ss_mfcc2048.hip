@@ -11,6 +11,8 @@
 //   * banded mel (4 filters per lane, aligned float4 taps), zero handling, ln -> row in filter order; DCT-II with the
 //     m <-> M-1-m symmetry of the cosine (sum / difference rows, half the table), reference scaling, column-0 replacement.
 //   * optional frame window (mfcc_window switch) from the table block; mfe build stops after the mel stage.
+//   * LIB builds (librosa-compatible switches): centred frames with reflect / zero padding at the clip edges, and P rows of
+//     all 1025 bins for banks over the whole spectrum; the rows then outgrow the exchange region (10304 B per wave).
 // Reference semantics as in ss_mfcc512.hip; tables: ss::mfcc2048_layout (ss_internal.h).
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -26,6 +28,8 @@ constexpr float kTwo32G = 4294967296.f;
 constexpr int kExSlotsG = 2 * 16 * 34;      // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsG = kExSlotsG * 2;
 constexpr int kHalfFloats = kWaveFloatsG / 2;  // per frame after the exchange: P row [520] | ln(mel) row [128] | s [64] | d [64]
+constexpr int kHalfFloatsLib = 1288;           // LIB: P row [1028] | ln(mel) row [128] | s [64] | d [64]
+template <bool LIB> constexpr int wave_floats() { return LIB ? 2 * kHalfFloatsLib : kWaveFloatsG; }
 
 __device__ __forceinline__ void wave_order_g()
 {
@@ -81,7 +85,7 @@ __device__ __forceinline__ float half_sum(float v)
     return v;
 }
 
-template <bool POW2, bool MFE, bool WIN, int WAVES>
+template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,11 +95,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
     const int half = lane >> 5;  // frame within the wave
     const int j = lane & 31;     // lane within the frame
 
-    float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsG;
+    constexpr int kWF = wave_floats<LIB>();
+    float *wbase = reinterpret_cast<float *>(smem) + wave * kWF;
     float2 *ex = reinterpret_cast<float2 *>(wbase);
-    float *hb = wbase + half * kHalfFloats;  // this frame's rows after the exchange
-    float *prow = hb, *frow = hb + 520, *srow = hb + 648, *drow = hb + 712;
-    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloatsG;
+    float *hb = wbase + half * (LIB ? kHalfFloatsLib : kHalfFloats);  // this frame's rows after the exchange
+    float *prow = hb, *frow = hb + (LIB ? 1028 : 520), *srow = frow + 128, *drow = srow + 64;
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWF;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
     const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
@@ -140,13 +145,38 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
         const unsigned clip = gf / a.n_frames;
         const unsigned t = gf - clip * a.n_frames;
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
-        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step) + j;
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
         float2 v[32];
+        // librosa center=True: frame t is centred on sample t*step; frames inside the clip load like contract frames from
+        // their (even) start, the few at the clip edges mirror (np.pad 'reflect') or zero their out-of-range samples
+        const int s0 = static_cast<int>(t * a.step) - (LIB && a.center ? static_cast<int>(a.flen / 2) : 0);
+        const int ns = static_cast<int>(a.n_samples);
+        if (!LIB || __all(s0 >= 0 && s0 + static_cast<int>(a.flen) <= ns)) {
+            const float2 *src = reinterpret_cast<const float2 *>(xc + s0) + j;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            float2 s = make_float2(0.f, 0.f);
-            if (e < e_hi) s = src[32 * e];
-            v[e] = s;
+            for (int e = 0; e < 32; ++e) {
+                float2 s = make_float2(0.f, 0.f);
+                if (e < e_hi) s = src[32 * e];
+                v[e] = s;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                float sv[2] = {0.f, 0.f};
+                if (e < e_hi) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        int pos = s0 + 2 * (j + 32 * e) + h;
+                        bool ok = true;
+                        if (pos < 0 || pos >= ns) {
+                            if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+                            else ok = false;
+                        }
+                        if (ok) sv[h] = xc[pos];
+                    }
+                }
+                v[e] = make_float2(sv[0], sv[1]);
+            }
         }
         if (WIN) {
 #pragma unroll
@@ -217,6 +247,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                 const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);
                 const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
                 prow[j + 32 * q] = pa;  // bins 0..511 (the bank ends at (F+1)/2, feature.rs:69-70); 512 below
+                if (LIB) prow[1024 - (j + 32 * q)] = pb;  // bins 513..1024 for banks over the whole spectrum
                 esum += pa + pb;        // X[0] and X[1024] come from lane 0's self pair (q = 0)
             }
         }
@@ -227,7 +258,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
             prow[512] = p512;
             esum += p512;
         }
-        if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        if (j < 3) prow[(LIB ? 1025 : 513) + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float energy = hscale32 * half_sum(esum);              // E * 2^32
         energy = energy == 0.f ? kEpsG * kTwo32G : energy;     // zero_handling, feature.rs:219
         wave_order_g();
@@ -296,7 +327,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
 template <int WAVES>
 hipError_t launch_g(const Mfcc2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloatsG + L::kMelW + 32 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
+    const bool lib = a.center != 0 || a.fullp != 0;
+    const size_t lds = (static_cast<size_t>(WAVES) * (lib ? wave_floats<true>() : wave_floats<false>()) + L::kMelW + 32 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
     if (total == 0) return hipSuccess;
@@ -314,12 +346,22 @@ hipError_t launch_g(const Mfcc2048Args &a, hipStream_t stream, int num_cus, Laun
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2, win = a.windowed != 0;
-    if (a.out_mfe) {
-        if (pow2) return win ? go(ss_mfcc_c1024<true, true, true, WAVES>, "ss_mfcc_c1024<pow2,mfe,win>") : go(ss_mfcc_c1024<true, true, false, WAVES>, "ss_mfcc_c1024<pow2,mfe>");
-        return win ? go(ss_mfcc_c1024<false, true, true, WAVES>, "ss_mfcc_c1024<mfe,win>") : go(ss_mfcc_c1024<false, true, false, WAVES>, "ss_mfcc_c1024<mfe>");
+#define SS_G(P, M, W, LB, NAME) go(ss_mfcc_c1024<P, M, W, WAVES, LB>, NAME)
+    if (lib) {
+        if (a.out_mfe) {
+            if (pow2) return win ? SS_G(true, true, true, true, "ss_mfcc_c1024<pow2,mfe,win,lib>") : SS_G(true, true, false, true, "ss_mfcc_c1024<pow2,mfe,lib>");
+            return win ? SS_G(false, true, true, true, "ss_mfcc_c1024<mfe,win,lib>") : SS_G(false, true, false, true, "ss_mfcc_c1024<mfe,lib>");
+        }
+        if (pow2) return win ? SS_G(true, false, true, true, "ss_mfcc_c1024<pow2,win,lib>") : SS_G(true, false, false, true, "ss_mfcc_c1024<pow2,lib>");
+        return win ? SS_G(false, false, true, true, "ss_mfcc_c1024<win,lib>") : SS_G(false, false, false, true, "ss_mfcc_c1024<lib>");
     }
-    if (pow2) return win ? go(ss_mfcc_c1024<true, false, true, WAVES>, "ss_mfcc_c1024<pow2,win>") : go(ss_mfcc_c1024<true, false, false, WAVES>, "ss_mfcc_c1024<pow2>");
-    return win ? go(ss_mfcc_c1024<false, false, true, WAVES>, "ss_mfcc_c1024<win>") : go(ss_mfcc_c1024<false, false, false, WAVES>, "ss_mfcc_c1024");
+    if (a.out_mfe) {
+        if (pow2) return win ? SS_G(true, true, true, false, "ss_mfcc_c1024<pow2,mfe,win>") : SS_G(true, true, false, false, "ss_mfcc_c1024<pow2,mfe>");
+        return win ? SS_G(false, true, true, false, "ss_mfcc_c1024<mfe,win>") : SS_G(false, true, false, false, "ss_mfcc_c1024<mfe>");
+    }
+    if (pow2) return win ? SS_G(true, false, true, false, "ss_mfcc_c1024<pow2,win>") : SS_G(true, false, false, false, "ss_mfcc_c1024<pow2>");
+    return win ? SS_G(false, false, true, false, "ss_mfcc_c1024<win>") : SS_G(false, false, false, false, "ss_mfcc_c1024");
+#undef SS_G
 }
 
 }  // namespace
