@@ -260,9 +260,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     }
     // fft_points = 2048 / 1024 MFCC / mfe: two frames per wave (ss_mfcc2048.hip, ss_mfcc1024.hip), same layout assumptions,
     // optional frame window
-    // (the 2048-point kernel also has librosa-compatible builds: centred frames with flen % 4 == 0, banks up to fs/2)
+    // (both have librosa-compatible builds: centred frames with flen % 4 == 0, banks up to fs/2)
     if (!force_generic && (cfg->mfcc2048.ok || cfg->mfcc1024.ok) && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
-        (a.frame_mode == ss::FRAME_NORMAL || (centre && cfg->mfcc2048.ok && a.flen % 4 == 0)) && a.preemph == 0.0f &&
+        (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) && a.preemph == 0.0f &&
         (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mfcc2048Args f{};
         f.x = d_x;
@@ -288,7 +288,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out_mfe = out_kind == ss::OUT_MFE;
         f.center = centre;
         f.pad_reflect = a.pad_reflect;
-        f.fullp = k2048 && cfg->mfcc2048.fullp;
+        f.fullp = k2048 ? cfg->mfcc2048.fullp : cfg->mfcc1024.fullp;
         f.out = out0;
         f.out_energy = out1;
         hipError_t e2 = k2048 ? ss::launch_mfcc_c1024(f, stream, cfg->num_cus, &info) : ss::launch_mfcc_c512(f, stream, cfg->num_cus, &info);

@@ -165,9 +165,9 @@ struct Mfcc2048Args {
     int32_t dc_elimination;
     int32_t windowed;    // the table block carries a frame window (mfcc_window switch)
     int32_t out_mfe;     // 1: write mfe's (features, energy) instead of the cepstra
-    int32_t center;      // librosa center=True framing (2048-point kernel only)
+    int32_t center;      // librosa center=True framing
     int32_t pad_reflect; // np.pad 'reflect' (else zeros) outside the clip for centred frames
-    int32_t fullp;       // the bank reaches past bin 512: P rows hold all 1025 bins (2048-point kernel only)
+    int32_t fullp;       // the bank reaches past the reference's (F+1)/2: P rows hold every bin up to fft_points/2
     float *out;
     float *out_energy;
 };

@@ -480,8 +480,9 @@ void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f)
     f = Mfcc1024Tables{};
     const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
     if (t.d.n_fft != 1024 || M > 128 || (M & 1) || Cc > 32) return;  // the symmetric DCT is written for an even filter count
-    if (t.bank.last_bin > 257) return;  // the kernel keeps P bins 0..256 (reference banks end at (F+1)/2)
-    constexpr int32_t kRow = 260;
+    if (t.bank.last_bin > 513) return;
+    f.fullp = t.bank.last_bin > 257;  // reference banks end at (F+1)/2 (P bins 0..256); librosa-style ones need all 513
+    const int32_t kRow = f.fullp ? 516 : 260;
     std::vector<int32_t> order(M);
     for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
     auto alen = [&](int32_t m) { return t.bank.len[m] ? (t.bank.start[m] & 3) + t.bank.len[m] : 0; };

@@ -134,6 +134,7 @@ constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
 struct Mfcc1024Tables {
     bool ok = false;
     bool windowed = false;
+    bool fullp = false;  // the bank reaches past bin 256: LIB builds
     std::vector<float> tab;
     int32_t q4[4] = {0, 0, 0, 0};
     int32_t wpitch = 0;

@@ -91,7 +91,7 @@ __device__ __forceinline__ float half_sum_k(float v)
     return v;
 }
 
-template <bool POW2, bool MFE, bool WIN, int WAVES>
+template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 
     float *fbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsK + fr * kFrameFloats;
     float2 *exf = reinterpret_cast<float2 *>(fbase);
-    float *prow = fbase, *frow = fbase + 260, *srow = fbase + 388, *drow = fbase + 452;
+    // LIB builds (librosa-compatible switches) keep all 513 bins of the P row: [516] | ln(mel) [128] | s [64] | d [64]
+    float *prow = fbase, *frow = fbase + (LIB ? 516 : 260), *srow = frow + 128, *drow = srow + 64;
     float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloatsK;
     const float4 *s_t1 = reinterpret_cast<const float4 *>(s_tab + L::kT1);
     const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
@@ -155,17 +156,45 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
         const unsigned clip = gf / a.n_frames;
         const unsigned t = gf - clip * a.n_frames;
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
-        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step) + jj;
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
         float2 v[16];
+        // librosa center=True (LIB builds): frame t is centred on sample t*step; frames inside the clip load like contract
+        // frames from their (even) start, the few at the clip edges mirror (np.pad 'reflect') or zero their missing samples
+        const int s0 = static_cast<int>(t * a.step) - (LIB && a.center ? static_cast<int>(a.flen / 2) : 0);
+        const int ns = static_cast<int>(a.n_samples);
+        if (!LIB || __all(s0 >= 0 && s0 + static_cast<int>(a.flen) <= ns)) {
+            const float2 *src = reinterpret_cast<const float2 *>(xc + s0) + jj;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float2 s = make_float2(0.f, 0.f);
-            if (e < e_hi) s = src[32 * e];
-            if (WIN) {
-                const float2 w = s_win[jj + 32 * e];
-                s = make_float2(s.x * w.x, s.y * w.y);
+            for (int e = 0; e < 16; ++e) {
+                float2 s = make_float2(0.f, 0.f);
+                if (e < e_hi) s = src[32 * e];
+                v[e] = s;
             }
-            v[e] = s;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float sv[2] = {0.f, 0.f};
+                if (e < e_hi) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        int pos = s0 + 2 * (jj + 32 * e) + hh;
+                        bool ok = true;
+                        if (pos < 0 || pos >= ns) {
+                            if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+                            else ok = false;
+                        }
+                        if (ok) sv[hh] = xc[pos];
+                    }
+                }
+                v[e] = make_float2(sv[0], sv[1]);
+            }
+        }
+        if (WIN) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float2 w = s_win[jj + 32 * e];
+                v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
+            }
         }
         // ---- pass 1: radix-16 over n2; transpose (two 16 x 16 problems: even and odd n1) ----
         fft_reg<16>(v);
@@ -228,6 +257,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);
             const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
             pdst[16 * i] = pa;  // bins 0..255 (the bank ends at (F+1)/2, feature.rs:69-70); 256 below
+            if (LIB) prow[512 - (k1 + 128 * h + 16 * i)] = pb;  // bins 257..512 for banks over the whole spectrum
             esum += pa + pb;
         }
         if (jj == 0) {
@@ -237,7 +267,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             prow[256] = p256;
             esum += p256;
         }
-        if (jj < 3) prow[257 + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        if (jj < 3) prow[(LIB ? 513 : 257) + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float energy = hscale32 * half_sum_k(esum);            // E * 2^32
         energy = energy == 0.f ? kEpsK * kTwo32K : energy;     // zero_handling, feature.rs:219
         wave_order_k();
@@ -322,13 +352,23 @@ hipError_t launch_k(const Mfcc1024Args &a, hipStream_t stream, int num_cus, Laun
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
         return hipGetLastError();
     };
-    const bool pow2 = a.spectrum_exponent == 2, win = a.windowed != 0;
-    if (a.out_mfe) {
-        if (pow2) return win ? go(ss_mfcc_c512<true, true, true, WAVES>, "ss_mfcc_c512<pow2,mfe,win>") : go(ss_mfcc_c512<true, true, false, WAVES>, "ss_mfcc_c512<pow2,mfe>");
-        return win ? go(ss_mfcc_c512<false, true, true, WAVES>, "ss_mfcc_c512<mfe,win>") : go(ss_mfcc_c512<false, true, false, WAVES>, "ss_mfcc_c512<mfe>");
+    const bool pow2 = a.spectrum_exponent == 2, win = a.windowed != 0, lib = a.center != 0 || a.fullp != 0;
+#define SS_K(P, M, W, LB, NAME) go(ss_mfcc_c512<P, M, W, WAVES, LB>, NAME)
+    if (lib) {
+        if (a.out_mfe) {
+            if (pow2) return win ? SS_K(true, true, true, true, "ss_mfcc_c512<pow2,mfe,win,lib>") : SS_K(true, true, false, true, "ss_mfcc_c512<pow2,mfe,lib>");
+            return win ? SS_K(false, true, true, true, "ss_mfcc_c512<mfe,win,lib>") : SS_K(false, true, false, true, "ss_mfcc_c512<mfe,lib>");
+        }
+        if (pow2) return win ? SS_K(true, false, true, true, "ss_mfcc_c512<pow2,win,lib>") : SS_K(true, false, false, true, "ss_mfcc_c512<pow2,lib>");
+        return win ? SS_K(false, false, true, true, "ss_mfcc_c512<win,lib>") : SS_K(false, false, false, true, "ss_mfcc_c512<lib>");
     }
-    if (pow2) return win ? go(ss_mfcc_c512<true, false, true, WAVES>, "ss_mfcc_c512<pow2,win>") : go(ss_mfcc_c512<true, false, false, WAVES>, "ss_mfcc_c512<pow2>");
-    return win ? go(ss_mfcc_c512<false, false, true, WAVES>, "ss_mfcc_c512<win>") : go(ss_mfcc_c512<false, false, false, WAVES>, "ss_mfcc_c512");
+    if (a.out_mfe) {
+        if (pow2) return win ? SS_K(true, true, true, false, "ss_mfcc_c512<pow2,mfe,win>") : SS_K(true, true, false, false, "ss_mfcc_c512<pow2,mfe>");
+        return win ? SS_K(false, true, true, false, "ss_mfcc_c512<mfe,win>") : SS_K(false, true, false, false, "ss_mfcc_c512<mfe>");
+    }
+    if (pow2) return win ? SS_K(true, false, true, false, "ss_mfcc_c512<pow2,win>") : SS_K(true, false, false, false, "ss_mfcc_c512<pow2>");
+    return win ? SS_K(false, false, true, false, "ss_mfcc_c512<win>") : SS_K(false, false, false, false, "ss_mfcc_c512");
+#undef SS_K
 }
 
 }  // namespace

@@ -156,26 +156,27 @@ def test_librosa_like_front_end_gpu(ss, oracle, sslib):
 
 
 @pytest.mark.gpu
-def test_librosa_like_2048_gpu(ss, oracle, sslib):
+@pytest.mark.parametrize("nfft,hop,mels,kernel", [(2048, 512, 128, "ss_mfcc_c1024<"), (1024, 256, 80, "ss_mfcc_c512<")])
+def test_librosa_like_large_fft_gpu(ss, oracle, sslib, nfft, hop, mels, kernel):
     """librosa.feature.melspectrogram's own defaults (22.05 kHz, n_fft = win_length = 2048, hop 512, 128 Slaney mels over
     0..fs/2, centred reflect-padded frames, Hann window, power 2) and the MFCCs on top, on the LIB builds of the 2048-point
-    frame kernel; each switch also on its own."""
+    frame kernel -- and the same at n_fft = 1024 / hop 256 / 80 mels on the 1024-point one; each switch also on its own."""
     import torch
 
     sr, n = 22050, 22050
-    base = dict(sample_rate=sr, fft_points=2048, frame_length=2048 / sr, frame_stride=512 / sr, num_cepstral=20, num_filters=128)
+    base = dict(sample_rate=sr, fft_points=nfft, frame_length=nfft / sr, frame_stride=hop / sr, num_cepstral=20, num_filters=mels)
     lib = dict(framing="center", pad_mode="reflect", mfcc_window="hann", spectrum_exponent=2, mel_scale="slaney",
                mel_norm="slaney", dct_norm="ortho")
     x = _signal(64, (7, n))
     xd = torch.from_numpy(x).cuda()
-    margs = dict(frame_length=base["frame_length"], frame_stride=base["frame_stride"], fft_length=2048, num_filters=128)
+    margs = dict(frame_length=base["frame_length"], frame_stride=base["frame_stride"], fft_length=nfft, num_filters=mels)
     args = dict(margs, num_cepstral=20)
     for sw in (lib, dict(lib, pad_mode="constant"), dict(framing="center"), dict(mel_scale="htk"),
                dict(mel_scale="slaney", mel_norm="slaney", spectrum_exponent=2)):
         p = oracle.make_params(**base, **sw)
         got = ss.mfcc_batch(xd, sr, **args, **sw).cpu().numpy()
         name = sslib.ss_last_kernel_name().decode()
-        assert name.startswith("ss_mfcc_c1024<") and "lib" in name and ("win" in name) == ("mfcc_window" in sw), name
+        assert name.startswith(kernel) and "lib" in name and ("win" in name) == ("mfcc_window" in sw), name
         assert got.shape[1] == oracle.num_frames(p, n)
         for b in (0, 3, 6):
             assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
@@ -183,8 +184,8 @@ def test_librosa_like_2048_gpu(ss, oracle, sslib):
         assert "mfe" in sslib.ss_last_kernel_name().decode() and "lib" in sslib.ss_last_kernel_name().decode()
         wf, we = oracle.mfe(p, x[6])
         assert _rel(feat[6].cpu().numpy(), wf) <= RTOL and _rel(en[6].cpu().numpy(), we) <= RTOL, sw
-    # a clip barely longer than half a frame: every frame touches both edges; odd clip count -> a dead half-wave
-    xs = _signal(65, 1200)
+    # a clip barely longer than half a frame: every frame touches both edges; odd frame count -> a dead half-wave
+    xs = _signal(65, nfft // 2 + 176)
     p = oracle.make_params(**base, **lib)
     got = ss.mfcc(xs, sr, **args, **lib)
     assert _rel(got, oracle.mfcc(p, xs)) <= RTOL
