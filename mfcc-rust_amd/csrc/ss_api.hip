@@ -43,6 +43,9 @@ struct ss_config {
     // fft_points = 1024 MFCC kernel tables (ss_mfcc1024.hip)
     ss::Mfcc1024Tables mfcc1024;
     float *d_mfcc1024_tab = nullptr;
+    // fft_points = 256 MFCC kernel tables (ss_mfcc256.hip)
+    ss::Mfcc256Tables mfcc256;
+    float *d_mfcc256_tab = nullptr;
 };
 
 namespace {
@@ -255,6 +258,38 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         }
         hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256");
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
+    // fft_points = 256 MFCC / mfe: two frames per complex transform (ss_mfcc256.hip); scalar sample loads, so no alignment
+    // assumptions; optional frame window, no fused pre-emphasis
+    if (!force_generic && cfg->mfcc256.ok && static_cast<unsigned long long>(batch) * T + 8 < 0x7fffffffull &&
+        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL && a.preemph == 0.0f && a.flen <= 256) {
+        ss::Mfcc256Args f{};
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tab = cfg->d_mfcc256_tab;
+        f.mel_wpitch = cfg->mfcc256.wpitch;
+        for (int s = 0; s < 3; ++s) f.mel_q4[s] = cfg->mfcc256.q4[s];
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        f.windowed = cfg->mfcc256.windowed;
+        f.out_mfe = out_kind == ss::OUT_MFE;
+        f.out = out0;
+        f.out_energy = out1;
+        hipError_t e3 = ss::launch_mfcc_c256x2(f, stream, cfg->num_cus, &info);
+        if (e3 != hipSuccess) return hip_fail(e3, "launch_mfcc_c256x2");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
@@ -477,6 +512,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mfcc2048.ok) SS_UP(d_mfcc2048_tab, c->mfcc2048.tab);
     ss::build_mfcc1024(h, c->mfcc1024);
     if (c->mfcc1024.ok) SS_UP(d_mfcc1024_tab, c->mfcc1024.tab);
+    ss::build_mfcc256(h, c->mfcc256);
+    if (c->mfcc256.ok) SS_UP(d_mfcc256_tab, c->mfcc256.tab);
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
@@ -493,7 +530,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

@@ -178,6 +178,28 @@ hipError_t launch_mfcc_c1024(const Mfcc2048Args &a, hipStream_t stream, int num_
 using Mfcc1024Args = Mfcc2048Args;
 hipError_t launch_mfcc_c512(const Mfcc1024Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
+// Arguments of the fft_points = 256 MFCC / mfe kernel (ss_mfcc256.hip): two frames per 256-point complex transform.
+struct Mfcc256Args {
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples, batch, flen, step, n_frames;
+    float scale;  // 1/N (processing.rs:180)
+    int32_t spectrum_exponent;
+    const float *tab;    // table block (layout: ss::mfcc256_layout in ss_internal.h), copied verbatim into LDS
+    int32_t mel_wpitch;  // floats per lane weight row
+    int32_t mel_q4[3];   // taps / 4 per slot
+    uint32_t n_filters, n_ceps;
+    float dct_scale_k, dct_scale_0, dct_scale_00;
+    int32_t dc_elimination;
+    int32_t windowed;    // the table block carries a frame window (mfcc_window switch)
+    int32_t out_mfe;     // 1: write mfe's (features, energy) instead of the cepstra
+    uint32_t nf_magic, nf_shift;  // set by the launcher: frame -> (clip, t) by multiply-high
+    float *out;
+    float *out_energy;
+};
+
+hipError_t launch_mfcc_c256x2(const Mfcc256Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 // Arguments of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip).
 struct Mfcc4096Args {
     const float *x;

@@ -359,6 +359,67 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     f.ok = true;
 }
 
+void build_mfcc256(const HostTables &t, Mfcc256Tables &f)
+{
+    namespace L = mfcc256_layout;
+    f = Mfcc256Tables{};
+    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
+    if (t.d.n_fft != 256 || M > 48 || Cc > 16) return;
+    if (t.bank.last_bin > 129) return;
+    constexpr int32_t kRow = 132;  // P bins a tap may touch: 0..128 plus three zero pad bins
+    // order filters by tap count (longest first) and deal them 16 per slot
+    std::vector<int32_t> order(M);
+    for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
+    int32_t maxlen[3] = {0, 0, 0};
+    for (size_t q = 0; q < M; ++q) maxlen[q / 16] = std::max(maxlen[q / 16], t.bank.len[order[q]]);
+    for (int s = 0; s < 3; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2]);
+    if (f.wpitch == 0) f.wpitch = 4;
+    if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the 16 lanes' ds_read_b128 rows spread over the banks
+    if (f.wpitch > 160) return;
+    f.tab.assign(static_cast<size_t>(L::kMelW) + 16 * static_cast<size_t>(f.wpitch), 0.0f);
+    const double pi = 3.14159265358979323846;
+    for (int r = 1; r < 16; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256); two twiddles per 16-byte slot
+            const int p = (r - 1) / 2, half = (r - 1) % 2;
+            const double ang = -2.0 * pi * static_cast<double>(j * r) / 256.0;
+            f.tab[L::kTw2 + (p * 16 + j) * 4 + 2 * half] = static_cast<float>(std::cos(ang));
+            f.tab[L::kTw2 + (p * 16 + j) * 4 + 2 * half + 1] = static_cast<float>(std::sin(ang));
+        }
+    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
+    int32_t off = 0;
+    for (int s = 0; s < 3; ++s) {
+        const int32_t span = 4 * f.q4[s];
+        for (int j = 0; j < 16; ++j) {
+            const size_t q = static_cast<size_t>(s) * 16 + j;
+            start[q] = 0;
+            filt[q] = -1;
+            if (q >= M) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
+            const int32_t m = order[q];
+            filt[q] = m;
+            int32_t st = t.bank.start[m];
+            const int32_t len = t.bank.len[m];
+            int32_t shift = 0;  // the lock-step loop reads `span` taps: keep st + span inside the row
+            if (st + span > kRow) shift = st + span - kRow;
+            st -= shift;
+            start[q] = st;
+            for (int32_t i = 0; i < len; ++i)
+                f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
+            for (size_t c = 0; c < Cc; ++c) f.tab[L::kCos + c * 52 + q] = t.dct[c * M + m];
+        }
+        off += span;
+    }
+    if (!t.window_mfcc.empty()) {  // optional frame window (mfcc_window switch)
+        f.windowed = true;
+        const size_t base = f.tab.size();
+        f.tab.resize(base + 256, 0.0f);
+        for (size_t i = 0; i < t.window_mfcc.size() && i < 256; ++i) f.tab[base + i] = t.window_mfcc[i];
+    }
+    f.ok = true;
+}
+
 void build_fast512m(const HostTables &t, Fast512MTables &f)
 {
     namespace L = fast512m_layout;

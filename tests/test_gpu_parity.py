@@ -579,6 +579,45 @@ def test_mfcc_1024_kernel(ss, oracle, sslib):
         assert _rel(feat[8].cpu().numpy(), wf) <= RTOL and _rel(en[8].cpu().numpy(), we) <= RTOL
 
 
+def test_mfcc_256_kernel(ss, oracle, sslib):
+    """MFCC / mfe at fft_points = 256 (8 kHz telephony front ends): two frames per complex transform.  20 ms and 25 ms frames,
+    odd hops (scalar loads: no alignment assumptions), window, power spectrum, filter counts up to 48, batches whose frame count
+    is not a multiple of 8, clips with fewer than 8 frames (the per-lane division path), a single clip."""
+    import torch
+
+    sr = 8000
+    x = _signal(31, (11, 2 * sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, step, M, C, sw in ((160, 80, 40, 13, {}), (200, 80, 26, 13, dict(mfcc_window="vorbis")), (256, 81, 48, 16, dict(spectrum_exponent=2)),
+                                 (161, 77, 23, 12, dict(mfcc_window="hann", dct_norm="ortho", dc_elimination=False)),
+                                 (160, 80, 40, 13, dict(mel_scale="slaney", mel_norm="slaney"))):
+        kw = dict(frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, fft_length=256)
+        p = oracle.make_params(sample_rate=sr, fft_points=256, frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C,
+                               num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256x2<"), sslib.ss_last_kernel_name()
+        assert got.shape == (11, oracle.num_frames(p, 2 * sr), C)
+        for b in (0, 5, 10):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, step, M, sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        msw = {k: v for k, v in sw.items() if k != "dc_elimination"}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
+        assert b"mfe" in sslib.ss_last_kernel_name() and sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256x2<")
+        for b in (0, 10):
+            wf, we = oracle.mfe(p, x[b])
+            assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL
+    # fewer than 8 frames per clip, odd clip count; one clip through the 1-D entry point (views at odd offsets: unaligned starts)
+    p = oracle.make_params(sample_rate=sr, fft_points=256)
+    xs = _signal(32, (5, 160 + 80 * 5 + 3))
+    got = ss.mfcc_batch(torch.from_numpy(xs).cuda(), sr, fft_length=256).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256x2<")
+    assert got.shape[1] == oracle.num_frames(p, xs.shape[1]) and got.shape[1] < 8
+    for b in range(5):
+        assert _rel(got[b], oracle.mfcc(p, xs[b])) <= RTOL, b
+    x1 = _signal(33, 4001)
+    assert _rel(ss.mfcc(x1[1:], sr, fft_length=256), oracle.mfcc(p, x1[1:])) <= RTOL
+
+
 def test_kernel_variants_agree(ss):
     """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
     the variant is chosen once per process from the environment)."""
