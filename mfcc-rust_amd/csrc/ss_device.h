@@ -150,6 +150,23 @@ struct Mel2048Args {
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
+// Arguments of the fft_points = 512 mel-spectrogram kernel (ss_mel512.hip).
+struct Mel512Args {
+    const float *x;
+    unsigned long long ld;
+    uint32_t n_samples, batch;
+    uint32_t hop, n_pad, rows, real_rows;
+    float scale;  // wnorm (config.rs:178)
+    const float *tab;    // table block (layout: ss::mel512_layout in ss_internal.h), copied verbatim into LDS
+    int32_t mel_wpitch;  // floats per lane weight row
+    int32_t mel_q4[5];   // taps / 4 per slot
+    int32_t fullp;       // the bank reaches past bin 128: P rows hold all 257 bins
+    uint32_t n_filters;
+    float *out;          // [batch][n_filters][rows]
+};
+
+hipError_t launch_mel_c256(const Mel512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
 // Arguments of the fft_points = 2048 MFCC / mfe kernel (ss_mfcc2048.hip).
 struct Mfcc2048Args {
     const float *x;

@@ -118,6 +118,25 @@ struct Mel2048Tables {
 };
 void build_mel2048(const HostTables &t, Mel2048Tables &f);
 
+// Table block of the fft_points = 512 mel-spectrogram kernel (ss_mel512.hip), float offsets; global layout == LDS layout.
+namespace mel512_layout {
+constexpr int kTw2 = 0;                  // [8][16] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 256); last .zw unused
+constexpr int kTwn = kTw2 + 8 * 64;      // [8][16] float2: exp(-2 pi i (j + 16 r) / 512)
+constexpr int kWin = kTwn + 8 * 32;      // [256] float2: Vorbis window pairs (w[2n], w[2n+1])
+constexpr int kStart = kWin + 512;       // [5][16] int32: first P bin of the filter owned by (slot, lane)
+constexpr int kFilt = kStart + 80;       // [5][16] int32: filter index of (slot, lane), -1 if none
+constexpr int kMelW = kFilt + 80;        // [16][pitch]
+}  // namespace mel512_layout
+
+struct Mel512Tables {
+    bool ok = false;
+    bool fullp = false;
+    std::vector<float> tab;
+    int32_t q4[5] = {0, 0, 0, 0, 0};
+    int32_t wpitch = 0;
+};
+void build_mel512(const HostTables &t, Mel512Tables &f);
+
 // Table block of the fft_points = 256 MFCC / mfe kernel (ss_mfcc256.hip), float offsets; global layout == LDS layout.
 namespace mfcc256_layout {
 constexpr int kTw2 = 0;                  // [8][16] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 256); last .zw unused

@@ -141,6 +141,26 @@ def test_cfg3_mel_spectrogram(ss, oracle):
     np.testing.assert_array_equal(one, got[0])
 
 
+def test_mel_spectrogram_512_kernel(ss, oracle, sslib):
+    """mel_spectrogram at fft_points = 512 (16 kHz, 16 ms / 8 ms chunks, 40 / 64 / 80 mels, reference and Slaney banks): the
+    four-rows-per-wave kernel; clip lengths that leave partial last chunks, row counts that are not multiples of 4."""
+    import torch
+
+    for n, frame, M, sw in ((16000, 0.016, 40, {}), (15872, 0.008, 64, {}), (16000, 0.016, 80, dict(mel_scale="slaney", mel_norm="slaney")),
+                            (4100, 0.010, 23, dict(high_frequency=3800.0)), (700, 0.016, 40, {})):
+        x = _signal(41, (7, n))
+        kw = dict(frame_length=frame, frame_stride=frame, num_filters=M, fft_length=512)
+        got = ss.mel_spectrogram(torch.from_numpy(x).cuda(), 16000, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name() == b"ss_mel_c256", (sslib.ss_last_kernel_name(), n, frame, M)
+        p = oracle.make_params(sample_rate=16000, fft_points=512, frame_length=frame, frame_stride=frame, num_filters=M, **sw)
+        want = oracle.mel_spectrogram(p, x)
+        assert got.shape == want.shape
+        for b in range(7):
+            assert _rel(got[b], want[b]) <= RTOL, (n, frame, M, sw, b)
+        one = ss.mel_spectrogram(x[3], 16000, **kw, **sw)
+        np.testing.assert_array_equal(one, got[3])
+
+
 def test_cfg5_highres(ss, oracle):
     import torch
 
