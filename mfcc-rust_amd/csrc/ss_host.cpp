@@ -597,12 +597,16 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
 }
 
 
-void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f)
+// mel = false: the frame-path kernel (ss_mfcc_c512); mel = true: the mel-spectrogram kernel (ss_mel_c512) -- same FFT tables
+// and bank layout, the Vorbis STFT window in kWin, no cosine rows
+static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
 {
     namespace L = mfcc1024_layout;
     f = Mfcc1024Tables{};
-    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
-    if (t.d.n_fft != 1024 || M > 128 || (M & 1) || Cc > 32) return;  // the symmetric DCT is written for an even filter count
+    const size_t M = t.params.num_filters, Cc = mel ? 0 : t.params.num_cepstral;
+    if (t.d.n_fft != 1024 || M > 128 || Cc > 32) return;
+    if (!mel && (M & 1)) return;  // the symmetric DCT is written for an even filter count
+    if (mel && (!t.d.stft_ok || t.window_stft.size() != 1024)) return;
     if (t.bank.last_bin > 513) return;
     f.fullp = t.bank.last_bin > 257;  // reference banks end at (F+1)/2 (P bins 0..256); librosa-style ones need all 513
     const int32_t kRow = f.fullp ? 516 : 260;
@@ -635,7 +639,10 @@ void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f)
             cis(static_cast<double>(k1 + 16 * (i + 8 * hh)), 512.0, &f.tab[L::kT2 + (i * 32 + jj) * 2]);
             cis(static_cast<double>(k1 + 16 * i + 128 * hh), 1024.0, &f.tab[L::kTwn + (i * 32 + jj) * 2]);
         }
-    if (!t.window_mfcc.empty()) {
+    if (mel) {
+        f.windowed = true;
+        for (size_t i = 0; i < 1024; ++i) f.tab[L::kWin + i] = t.window_stft[i];
+    } else if (!t.window_mfcc.empty()) {
         f.windowed = true;
         for (size_t i = 0; i < t.window_mfcc.size() && i < 1024; ++i) f.tab[L::kWin + i] = t.window_mfcc[i];
     }
@@ -668,6 +675,9 @@ void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f)
         for (size_t m = 0; m < M / 2; ++m) f.tab[L::kCos + c * L::kCosPitch + m] = t.dct[c * M + m];
     f.ok = true;
 }
+
+void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f) { build_1024(t, f, false); }
+void build_mel1024(const HostTables &t, Mfcc1024Tables &f) { build_1024(t, f, true); }
 
 void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
 {

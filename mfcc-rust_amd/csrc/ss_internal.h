@@ -177,6 +177,7 @@ struct Mfcc1024Tables {
     int32_t wpitch = 0;
 };
 void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f);
+void build_mel1024(const HostTables &t, Mfcc1024Tables &f);  // the mel-spectrogram kernel's block: Vorbis window, no cosines
 
 // Table block of the fft_points = 2048 MFCC / mfe kernel (ss_mfcc2048.hip), float offsets; global layout == LDS layout.
 namespace mfcc2048_layout {

@@ -332,6 +332,175 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
     }
 }
 
+// ss_mel_c512: the mel-spectrogram path (frame_analysis + |X wnorm|^2 + mel einsum, functions.rs:125-170, feature.rs:151-174)
+// at fft_points = 1024 on the same FFT mapping: 32 lanes own a 1024-sample window, a wave carries two consecutive rows of
+// one clip, the work unit is a (clip, row pair).  Row r covers the 1024 samples that end at chunk r + n_pad: zero initial
+// state, zero tail, rows past the real ones all zero (D3); windows inside the clip load at constant offsets, clip edges
+// through one masked range per lane.  The table block is mfcc1024_layout with the Vorbis window in kWin (kCos unused).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int fr = lane >> 5;                 // row within the pair
+    const int jj = lane & 31;                 // lane within the row
+    const int k1 = jj & 15, h = jj >> 4;      // reader view: column k1, half a = h
+    const int cls = jj & 1, bw = jj >> 1;     // writer view: n1 = jj = cls + 2 bw
+
+    float *fbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsK + fr * kFrameFloats;
+    float2 *exf = reinterpret_cast<float2 *>(fbase);
+    float *prow = fbase;  // [516] after the exchange
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloatsK;
+    const float4 *s_t1 = reinterpret_cast<const float4 *>(s_tab + L::kT1);
+    const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const float *s_melw = s_tab + L::kMelW;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+
+    const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows), M = static_cast<int>(a.n_filters);
+    const unsigned pairs = (a.rows + 1) / 2;
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    {
+        const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
+        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = u_lo + WAVES;
+    }
+    __syncthreads();
+    int st[4], fi[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st[s] = s_start[s * 32 + jj];
+        fi[s] = s_filt[s * 32 + jj];
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + jj * a.mel_wpitch);
+    const int paddr = ((lane & 32) | ((16 - k1) & 15) | ((1 - h) << 4)) << 2;  // lane holding Z[512 - k]
+    float2 *exw = exf + cls * kClsK + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
+    const float2 *exr = exf + h * kClsK + 2 * k1;                  // reader base
+    const float hs = 0.25f * a.scale * a.scale;                    // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
+    const bool k1z = k1 == 0;
+
+    unsigned unit = u_lo + wave;
+    while (unit < u_hi) {
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+
+        const unsigned clip = unit / pairs;
+        const int r = static_cast<int>(unit - clip * pairs) * 2 + fr;
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+        const bool active = r < Rreal;
+        // functions.rs:137-151: the window covers the last 1024 samples ending at chunk r + n_pad
+        const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 1024;
+        const bool inside = active && start >= 0 && start + 1024 <= static_cast<int>(a.n_samples);
+        const float2 *src = reinterpret_cast<const float2 *>(xc + start) + jj;
+        float2 v[16];
+        if (__all(inside)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = src[32 * e];
+        } else {
+            // clip edges and inactive rows: start and n_samples are even, the valid sample pairs form one range per lane
+            // (the address of a masked load may lie outside the clip; it is never dereferenced)
+            const int base = start + 2 * jj;
+            const int n = static_cast<int>(a.n_samples);
+            const int e_lo = base >= 0 ? 0 : (63 - base) >> 6;
+            int e_hi = base >= n ? 0 : min(16, (n - base + 63) >> 6);
+            if (!active) e_hi = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float2 s = make_float2(0.f, 0.f);
+                if (e >= e_lo && e < e_hi) s = src[32 * e];
+                v[e] = s;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float2 w = s_win[jj + 32 * e];
+            v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
+        }
+        // ---- 512-point complex FFT as in ss_mfcc_c512 ----
+        fft_reg<16>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
+        wave_order_k();
+        float2 u[16];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(&exr[34 * p]);
+            u[2 * p] = make_float2(t4.x, t4.y);
+            u[2 * p + 1] = make_float2(t4.z, t4.w);
+        }
+        wave_order_k();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float4 w2 = s_t1[p * 16 + k1];
+            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+            if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        }
+        fft_reg<16>(u);
+        float2 r0[8], r1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float px = u[i].x, qx = u[8 + i].x, py = u[i].y, qy = u[8 + i].y;
+            swap_rows(px, qx);
+            swap_rows(py, qy);
+            const float2 wq = cmul(make_float2(qx, qy), s_t2[i * 32 + jj]);
+            r0[i] = make_float2(px + wq.x, py + wq.y);
+            r1[i] = make_float2(px - wq.x, py - wq.y);
+        }
+        // ---- untangle Z -> X; (|X| wnorm)^2 (functions.rs:166-169 + feature.rs:164) ----
+        float2 zcs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 sv = k1z ? r1[(8 - i) & 7] : r1[7 - i];
+            zcs[i] = make_float2(bperm_k(paddr, sv.x), bperm_k(paddr, sv.y));
+        }
+        const int kb = k1 + 128 * h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 zk = r0[i];
+            float2 zc = zcs[i];
+            if (i == 0) zc = k1z ? (h ? r1[0] : zk) : zc;
+            const float2 w = s_twn[i * 32 + jj];
+            const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+            const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+            // 2 X[k] = s - i w dd, 2 conj X[512-k] = 2 s - 2 X[k]
+            const float xr = fmaf(w.y, dd.x, fmaf(w.x, dd.y, s.x));
+            const float xi = fmaf(w.y, dd.y, fmaf(-w.x, dd.x, s.y));
+            prow[kb + 16 * i] = hs * fmaf(xr, xr, xi * xi);
+            if (a.fullp) {  // the bank reaches past (F+1)/2: bins 257..512 as well
+                const float yr = fmaf(2.f, s.x, -xr), yi = fmaf(2.f, s.y, -xi);
+                prow[512 - (kb + 16 * i)] = hs * fmaf(yr, yr, yi * yi);
+            }
+        }
+        if (jj == 0) {
+            const float2 z = r1[0];  // X[256] = conj Z[256]
+            prow[256] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+        }
+        if (jj < 3) prow[(a.fullp ? 513 : 257) + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        wave_order_k();
+        // ---- banded mel reduction (feature.rs:173); the two rows of the wave are adjacent words of out[clip][m][.] ----
+        if (r < R) {
+            float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+            int off = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float m = mel_slot_k(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
+                off += a.mel_q4[s];
+            }
+        }
+        wave_order_k();
+        unit = next;
+    }
+}
+
 template <int WAVES>
 hipError_t launch_k(const Mfcc1024Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
@@ -376,6 +545,24 @@ hipError_t launch_k(const Mfcc1024Args &a, hipStream_t stream, int num_cus, Laun
 hipError_t launch_mfcc_c512(const Mfcc1024Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
     return launch_k<12>(a, stream, num_cus, info);
+}
+
+hipError_t launch_mel_c512(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    constexpr int WAVES = 12;
+    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloatsK + L::kMelW + 32 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.batch == 0 || a.rows == 0) return hipSuccess;
+    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    if (units >= 0xffffffffull) return hipErrorInvalidValue;
+    const unsigned long long blocks = (units + WAVES - 1) / WAVES;
+    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c512<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    if (info) *info = LaunchInfo{"ss_mel_c512", grid, static_cast<unsigned>(WAVES * 64), lds};
+    hipLaunchKernelGGL(ss_mel_c512<WAVES>, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
 }
 
 }  // namespace ss

@@ -161,6 +161,26 @@ def test_mel_spectrogram_512_kernel(ss, oracle, sslib):
         np.testing.assert_array_equal(one, got[3])
 
 
+def test_mel_spectrogram_1024_kernel(ss, oracle, sslib):
+    """mel_spectrogram at fft_points = 1024 (32 / 16 ms chunks at 16 kHz, 22.05 kHz with a Slaney bank over the whole spectrum):
+    two rows per wave on the 1024-point FFT mapping; partial last chunks, odd row counts, odd filter counts."""
+    import torch
+
+    for sr, n, frame, M, sw in ((16000, 16000, 0.032, 80, {}), (16000, 15872, 0.016, 64, {}), (22050, 22050, 512 / 22050, 128, dict(mel_scale="slaney", mel_norm="slaney")),
+                                (16000, 4100, 0.020, 23, dict(high_frequency=3800.0)), (16000, 1500, 0.032, 41, {})):
+        x = _signal(43, (5, n))
+        kw = dict(frame_length=frame, frame_stride=frame, num_filters=M, fft_length=1024)
+        got = ss.mel_spectrogram(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name() == b"ss_mel_c512", (sslib.ss_last_kernel_name(), n, frame, M)
+        p = oracle.make_params(sample_rate=sr, fft_points=1024, frame_length=frame, frame_stride=frame, num_filters=M, **sw)
+        want = oracle.mel_spectrogram(p, x)
+        assert got.shape == want.shape
+        for b in range(5):
+            assert _rel(got[b], want[b]) <= RTOL, (sr, n, frame, M, sw, b)
+        one = ss.mel_spectrogram(x[2], sr, **kw, **sw)
+        np.testing.assert_array_equal(one, got[2])
+
+
 def test_cfg5_highres(ss, oracle):
     import torch
 
