@@ -151,6 +151,7 @@ def main():
                     "(independent batches in flight: one launch's tail overlaps the next one's head); the roofline block "
                     "is then per-step wall time, not a kernel duration -- not the headline setting")
     ap.add_argument("--params", default="", help='JSON dict of extra ss_params switches, e.g. \'{"mfcc_window": 1, "preemph_coef": 0.97}\' (not the headline config)')
+    ap.add_argument("--kind", default="", choices=["", "mfcc", "mel"], help="run the workload's clips through the other path (mfcc / mel_spectrogram); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -188,6 +189,9 @@ def main():
     if args.params:
         pkw = dict(pkw, **json.loads(args.params))
         desc += " + " + args.params
+    if args.kind and args.kind != kind:
+        kind = args.kind
+        desc += " through the " + ("mel_spectrogram" if kind == "mel" else "mfcc") + " path"
     strong = args.workload == "cfg4"
     if args.clips:
         clips = args.clips

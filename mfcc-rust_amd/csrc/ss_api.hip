@@ -52,6 +52,9 @@ struct ss_config {
     // fft_points = 1024 mel-spectrogram kernel tables (ss_mel_c512 in ss_mfcc1024.hip)
     ss::Mfcc1024Tables mel1024;
     float *d_mel1024_tab = nullptr;
+    // fft_points = 4096 mel-spectrogram kernel tables (ss_mel_c2048 in ss_mfcc4096.hip)
+    ss::Mfcc4096Tables mel4096;
+    float *d_mel4096_tab = nullptr;
 };
 
 namespace {
@@ -464,8 +467,9 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    // fft_points = 1024 mel spectrogram: two rows per wave (ss_mel_c512 in ss_mfcc1024.hip), same layout assumptions
-    if (!force_generic && out_kind == ss::OUT_MEL && cfg->mel1024.ok && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
+    // fft_points = 1024 / 4096 mel spectrogram: two rows / one row per wave (ss_mel_c512 in ss_mfcc1024.hip, ss_mel_c2048 in
+    // ss_mfcc4096.hip), same layout assumptions
+    if (!force_generic && out_kind == ss::OUT_MEL && (cfg->mel1024.ok || cfg->mel4096.ok) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0) && static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
         ss::Mel2048Args m{};
         m.x = d_x;
@@ -477,14 +481,15 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.rows = a.rows;
         m.real_rows = a.real_rows;
         m.scale = a.scale;
-        m.tab = cfg->d_mel1024_tab;
-        m.mel_wpitch = cfg->mel1024.wpitch;
-        for (int s = 0; s < 4; ++s) m.mel_q4[s] = cfg->mel1024.q4[s];
-        m.fullp = cfg->mel1024.fullp;
+        const bool k1024 = cfg->mel1024.ok;
+        m.tab = k1024 ? cfg->d_mel1024_tab : cfg->d_mel4096_tab;
+        m.mel_wpitch = k1024 ? cfg->mel1024.wpitch : cfg->mel4096.wpitch;
+        for (int s = 0; s < 4; ++s) m.mel_q4[s] = k1024 ? cfg->mel1024.q4[s] : cfg->mel4096.q4[s];
+        m.fullp = k1024 && cfg->mel1024.fullp;
         m.n_filters = a.n_filters;
         m.out = out0;
-        hipError_t e = ss::launch_mel_c512(m, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mel_c512");
+        hipError_t e = k1024 ? ss::launch_mel_c512(m, stream, cfg->num_cus, &info) : ss::launch_mel_c2048(m, stream, cfg->num_cus, &info);
+        if (e != hipSuccess) return hip_fail(e, k1024 ? "launch_mel_c512" : "launch_mel_c2048");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
@@ -572,6 +577,8 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mel512.ok) SS_UP(d_mel512_tab, c->mel512.tab);
     ss::build_mel1024(h, c->mel1024);
     if (c->mel1024.ok) SS_UP(d_mel1024_tab, c->mel1024.tab);
+    ss::build_mel4096(h, c->mel4096);
+    if (c->mel4096.ok) SS_UP(d_mel4096_tab, c->mel4096.tab);
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
@@ -588,7 +595,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

@@ -152,6 +152,9 @@ struct Mel2048Args {
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 // fft_points = 1024 mel-spectrogram kernel (ss_mfcc1024.hip): same argument block, table layout ss::mfcc1024_layout
 hipError_t launch_mel_c512(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+// fft_points = 4096 mel-spectrogram kernel (ss_mfcc4096.hip): same argument block, table layout ss::mfcc4096_layout
+// without cosine rows, Vorbis window [4096] behind the mel rows
+hipError_t launch_mel_c2048(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
 // Arguments of the fft_points = 512 mel-spectrogram kernel (ss_mel512.hip).
 struct Mel512Args {

@@ -747,12 +747,16 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
     f.ok = true;
 }
 
-void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f)
+// mel = false: the frame-path kernel (ss_mfcc_c2048); mel = true: the mel-spectrogram kernel (ss_mel_c2048) -- same FFT
+// tables and bank layout, no cosine rows, the Vorbis STFT window behind the mel rows
+static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
 {
     namespace L = mfcc4096_layout;
     f = Mfcc4096Tables{};
-    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
-    if (t.d.n_fft != 4096 || M != 256 || Cc > 64) return;  // the symmetric DCT below is written for 256 filters
+    const size_t M = t.params.num_filters, Cc = mel ? 0 : t.params.num_cepstral;
+    if (t.d.n_fft != 4096 || M > 256 || Cc > 64) return;
+    if (!mel && M != 256) return;  // the symmetric DCT below is written for 256 filters
+    if (mel && (!t.d.stft_ok || t.window_stft.size() != 4096)) return;
     if (t.bank.last_bin > 1025) return;  // the kernel keeps P bins 0..1024
     constexpr int32_t kRow = 1028;       // P bins a tap may touch: 0..1024 plus three zero pad bins
     std::vector<int32_t> order(M);
@@ -793,6 +797,9 @@ void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f)
         const int32_t span = 4 * f.q4[s];
         for (int j = 0; j < 64; ++j) {
             const size_t q = static_cast<size_t>(s) * 64 + j;
+            start[q] = 0;
+            filt[q] = -1;
+            if (q >= M) continue;
             const int32_t m = order[q];
             filt[q] = m;
             const int32_t len = t.bank.len[m];
@@ -810,8 +817,16 @@ void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f)
     }
     for (size_t cc = 0; cc < Cc; ++cc)
         for (size_t m = 0; m < 128; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
+    if (mel) {
+        const size_t base = f.tab.size();
+        f.tab.resize(base + 4096);
+        for (size_t i = 0; i < 4096; ++i) f.tab[base + i] = t.window_stft[i];
+    }
     f.ok = true;
 }
+
+void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f) { build_4096(t, f, false); }
+void build_mel4096(const HostTables &t, Mfcc4096Tables &f) { build_4096(t, f, true); }
 
 }  // namespace ss
 

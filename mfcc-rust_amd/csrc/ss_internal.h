@@ -221,5 +221,6 @@ struct Mfcc4096Tables {
     int32_t wpitch = 0;
 };
 void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f);
+void build_mel4096(const HostTables &t, Mfcc4096Tables &f);  // the mel-spectrogram kernel's block: no cosines, Vorbis window appended
 
 }  // namespace ss

@@ -364,6 +364,184 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     }
 }
 
+// ss_mel_c2048: the mel-spectrogram path (frame_analysis + |X wnorm|^2 + mel einsum, functions.rs:125-170, feature.rs:151-174)
+// at fft_points = 4096 on the same FFT mapping: one wave owns one row (a 4096-sample window), the work unit is a (clip, row).
+// Row r covers the 4096 samples that end at chunk r + n_pad: zero initial state, zero tail, rows past the real ones all zero
+// (D3); windows inside the clip load at constant offsets, clip edges through one masked range per lane.  The table block is
+// mfcc4096_layout without cosine rows (the mel rows start at kCos) and with the Vorbis window behind the mel rows.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int k1 = lane & 31, d = lane >> 5;  // reader view: column k1, half a = d
+    const int cls = lane & 1, bw = lane >> 1; // writer view: n1 = lane = cls + 2 bw
+
+    float *wbase = reinterpret_cast<float *>(smem) + wave * kExFloats;
+    float2 *ex = reinterpret_cast<float2 *>(wbase);
+    float *prow = wbase;  // P[0..1024] + zero pad bins, after the exchange
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kExFloats;
+    const float4 *s_t1 = reinterpret_cast<const float4 *>(s_tab + L::kT1);
+    const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
+    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
+    const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
+    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
+    const float *s_melw = s_tab + L::kCos;
+    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kCos + 64 * a.mel_wpitch);
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kCos + 64 * a.mel_wpitch + 4096);
+
+    const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows), M = static_cast<int>(a.n_filters);
+    const unsigned total = a.batch * a.rows;
+    const unsigned f_lo = static_cast<unsigned>(static_cast<unsigned long long>(total) * blockIdx.x / gridDim.x);
+    const unsigned f_hi = static_cast<unsigned>(static_cast<unsigned long long>(total) * (blockIdx.x + 1) / gridDim.x);
+    {
+        const int n4 = (L::kCos + 64 * a.mel_wpitch + 4096) / 4;
+        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = f_lo + WAVES;
+    }
+    __syncthreads();
+    int st[4], fi[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st[s] = s_start[s * 64 + lane];
+        fi[s] = s_filt[s * 64 + lane];
+    }
+    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * a.mel_wpitch);
+    const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
+    float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
+    const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
+    const float hs = 0.25f * a.scale * a.scale;                      // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
+    const bool k1z = k1 == 0;
+
+    unsigned row = f_lo + wave;
+    while (row < f_hi) {
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
+
+        const unsigned clip = row / a.rows;
+        const int r = static_cast<int>(row - clip * a.rows);
+        const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+        // functions.rs:137-151: the window covers the last 4096 samples ending at chunk r + n_pad
+        const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 4096;
+        const float2 *src = reinterpret_cast<const float2 *>(xc + start) + lane;
+        float2 v[32];
+        if (r < Rreal && start >= 0 && start + 4096 <= static_cast<int>(a.n_samples)) {  // uniform: one row per wave
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v[e] = src[64 * e];
+        } else {
+            // clip edges and inactive rows: start and n_samples are even, the valid sample pairs form one range per lane
+            // (the address of a masked load may lie outside the clip; it is never dereferenced)
+            const int base = start + 2 * lane;
+            const int n = static_cast<int>(a.n_samples);
+            const int e_lo = base >= 0 ? 0 : (127 - base) >> 7;
+            int e_hi = base >= n ? 0 : min(32, (n - base + 127) >> 7);
+            if (r >= Rreal) e_hi = 0;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                float2 s = make_float2(0.f, 0.f);
+                if (e >= e_lo && e < e_hi) s = src[64 * e];
+                v[e] = s;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const float2 w = s_win[lane + 64 * e];
+            v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
+        }
+        // ---- 2048-point complex FFT as in ss_mfcc_c2048 ----
+        fft_reg<32>(v);
+        float2 u[32];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
+        wave_order_h();
+        if (k1 < 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&exr[34 * p]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order_h();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) exw[2 * k] = v[16 + k];
+        wave_order_h();
+        if (k1 >= 16) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(&exr[34 * p]);
+                u[2 * p] = make_float2(t4.x, t4.y);
+                u[2 * p + 1] = make_float2(t4.z, t4.w);
+            }
+        }
+        wave_order_h();
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float4 w2 = s_t1[p * 32 + k1];
+            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
+            if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        }
+        fft_reg<32>(u);
+        float2 r0[16], r1[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float px = u[i].x, qx = u[16 + i].x, py = u[i].y, qy = u[16 + i].y;
+            swap_halves(px, qx);
+            swap_halves(py, qy);
+            const float2 wq = cmul(make_float2(qx, qy), s_t2[i * 64 + lane]);
+            r0[i] = make_float2(px + wq.x, py + wq.y);
+            r1[i] = make_float2(px - wq.x, py - wq.y);
+        }
+        // ---- untangle Z -> X; (|X| wnorm)^2 of bins 0..1024 (functions.rs:166-169 + feature.rs:164) ----
+        if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        float *pdst = prow + k1 + 512 * d;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            float2 zcs[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = 8 * hb + q;
+                const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
+                zcs[q] = make_float2(bperm_h(paddr, sv.x), bperm_h(paddr, sv.y));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = 8 * hb + q;
+                const float2 zk = r0[i];
+                float2 zc = zcs[q];
+                if (i == 0) zc = k1z ? (d ? r1[0] : zk) : zc;
+                const float2 w = s_twn[i * 64 + lane];
+                const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+                const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+                const float xr = fmaf(w.y, dd.x, fmaf(w.x, dd.y, s.x));  // 2 X[k] = s - i w dd
+                const float xi = fmaf(w.y, dd.y, fmaf(-w.x, dd.x, s.y));
+                pdst[32 * i] = hs * fmaf(xr, xr, xi * xi);
+            }
+        }
+        if (lane == 0) {
+            const float2 z = r1[0];  // X[1024] = conj Z[1024]
+            prow[1024] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+        }
+        wave_order_h();
+        // ---- banded mel reduction (feature.rs:173) -> out[clip][m][r] ----
+        {
+            float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+            int off = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float m = mel_slot_h(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
+                off += a.mel_q4[s];
+            }
+        }
+        wave_order_h();
+        row = next;
+    }
+}
+
 template <int WAVES>
 hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
@@ -404,6 +582,24 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
 hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
     return launch_h<8>(a, stream, num_cus, info);
+}
+
+hipError_t launch_mel_c2048(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    constexpr int WAVES = 8;
+    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + L::kCos + 64 * static_cast<size_t>(a.mel_wpitch) + 4096 + 4) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.rows;
+    if (total == 0) return hipSuccess;
+    if (total >= 0xffffffffull) return hipErrorInvalidValue;
+    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
+    const unsigned long long blocks = (total + WAVES - 1) / WAVES;
+    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c2048<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    if (info) *info = LaunchInfo{"ss_mel_c2048", grid, static_cast<unsigned>(WAVES * 64), lds};
+    hipLaunchKernelGGL(ss_mel_c2048<WAVES>, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
 }
 
 }  // namespace ss

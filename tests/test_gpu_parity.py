@@ -181,6 +181,24 @@ def test_mel_spectrogram_1024_kernel(ss, oracle, sslib):
         np.testing.assert_array_equal(one, got[2])
 
 
+def test_mel_spectrogram_4096_kernel(ss, oracle, sslib):
+    """mel_spectrogram at fft_points = 4096 (44.1 kHz, 1024- and 2048-sample chunks, 256 / 128 / 100 mels): one row per wave on
+    the 4096-point FFT mapping; partial last chunks, clips shorter than a window."""
+    import torch
+
+    sr = 44100
+    for n, hop, M in ((44100, 1024, 256), (44100, 2048, 128), (30000, 1024, 100), (3000, 1024, 64)):
+        x = _signal(45, (3, n))
+        kw = dict(frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=4096)
+        got = ss.mel_spectrogram(torch.from_numpy(x).cuda(), sr, **kw).cpu().numpy()
+        assert sslib.ss_last_kernel_name() == b"ss_mel_c2048", (sslib.ss_last_kernel_name(), n, hop, M)
+        p = oracle.make_params(sample_rate=sr, fft_points=4096, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M)
+        want = oracle.mel_spectrogram(p, x)
+        assert got.shape == want.shape
+        for b in range(3):
+            assert _rel(got[b], want[b]) <= RTOL, (n, hop, M, b)
+
+
 def test_cfg5_highres(ss, oracle):
     import torch
 
