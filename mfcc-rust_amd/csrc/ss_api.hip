@@ -420,7 +420,8 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     ss::LaunchInfo info{};
     // fft_points = 2048 mel spectrogram: the wave-private kernel when its layout assumptions hold
     static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
-    if (!force_generic && (out_kind == ss::OUT_MEL || out_kind == ss::OUT_STFT) && cfg->mel2048.ok && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
+    const bool want_stft = out_kind == ss::OUT_STFT;  // the stft builds do not use the bank (stft_only table blocks)
+    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel2048.ok || (want_stft && cfg->mel2048.stft_only)) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mel2048Args m{};
         m.x = d_x;
@@ -444,7 +445,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         return SS_OK;
     }
     // fft_points = 512 mel spectrogram: four rows per wave (ss_mel512.hip), same layout assumptions
-    if (!force_generic && out_kind == ss::OUT_MEL && cfg->mel512.ok && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
+    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel512.ok || (want_stft && cfg->mel512.stft_only)) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0) && static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
         ss::Mel512Args m{};
         m.x = d_x;
@@ -462,6 +463,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.fullp = cfg->mel512.fullp;
         m.n_filters = a.n_filters;
         m.out = out0;
+        m.out_stft = out_kind == ss::OUT_STFT;
         hipError_t e = ss::launch_mel_c256(m, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, "launch_mel_c256");
         g_last_kernel = info.kernel_name;
@@ -469,7 +471,8 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     }
     // fft_points = 1024 / 4096 mel spectrogram: two rows / one row per wave (ss_mel_c512 in ss_mfcc1024.hip, ss_mel_c2048 in
     // ss_mfcc4096.hip), same layout assumptions
-    if (!force_generic && out_kind == ss::OUT_MEL && (cfg->mel1024.ok || cfg->mel4096.ok) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
+    const bool use1024 = cfg->mel1024.ok || (want_stft && cfg->mel1024.stft_only), use4096 = cfg->mel4096.ok || (want_stft && cfg->mel4096.stft_only);
+    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (use1024 || use4096) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
         (reinterpret_cast<uintptr_t>(d_x) % 8 == 0) && static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
         ss::Mel2048Args m{};
         m.x = d_x;
@@ -481,13 +484,14 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.rows = a.rows;
         m.real_rows = a.real_rows;
         m.scale = a.scale;
-        const bool k1024 = cfg->mel1024.ok;
+        const bool k1024 = use1024;
         m.tab = k1024 ? cfg->d_mel1024_tab : cfg->d_mel4096_tab;
         m.mel_wpitch = k1024 ? cfg->mel1024.wpitch : cfg->mel4096.wpitch;
         for (int s = 0; s < 4; ++s) m.mel_q4[s] = k1024 ? cfg->mel1024.q4[s] : cfg->mel4096.q4[s];
         m.fullp = k1024 && cfg->mel1024.fullp;
         m.n_filters = a.n_filters;
         m.out = out0;
+        m.out_stft = out_kind == ss::OUT_STFT;
         hipError_t e = k1024 ? ss::launch_mel_c512(m, stream, cfg->num_cus, &info) : ss::launch_mel_c2048(m, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, k1024 ? "launch_mel_c512" : "launch_mel_c2048");
         g_last_kernel = info.kernel_name;
@@ -574,13 +578,13 @@ int ss_config_create(const ss_params *p, ss_config **out)
     ss::build_mfcc256(h, c->mfcc256);
     if (c->mfcc256.ok) SS_UP(d_mfcc256_tab, c->mfcc256.tab);
     ss::build_mel512(h, c->mel512);
-    if (c->mel512.ok) SS_UP(d_mel512_tab, c->mel512.tab);
+    if (c->mel512.ok || c->mel512.stft_only) SS_UP(d_mel512_tab, c->mel512.tab);
     ss::build_mel1024(h, c->mel1024);
-    if (c->mel1024.ok) SS_UP(d_mel1024_tab, c->mel1024.tab);
+    if (c->mel1024.ok || c->mel1024.stft_only) SS_UP(d_mel1024_tab, c->mel1024.tab);
     ss::build_mel4096(h, c->mel4096);
-    if (c->mel4096.ok) SS_UP(d_mel4096_tab, c->mel4096.tab);
+    if (c->mel4096.ok || c->mel4096.stft_only) SS_UP(d_mel4096_tab, c->mel4096.tab);
     ss::build_mel2048(h, c->mel2048);
-    if (c->mel2048.ok) SS_UP(d_mel2048_tab, c->mel2048.tab);
+    if (c->mel2048.ok || c->mel2048.stft_only) SS_UP(d_mel2048_tab, c->mel2048.tab);
     ss::build_fast512m(h, c->fastm);
     if (c->fastm.ok) {
         SS_UP(d_fastm_tab, c->fastm.tab);

@@ -168,7 +168,8 @@ struct Mel512Args {
     int32_t mel_q4[5];   // taps / 4 per slot
     int32_t fullp;       // the bank reaches past bin 128: P rows hold all 257 bins
     uint32_t n_filters;
-    float *out;          // [batch][n_filters][rows]
+    float *out;          // [batch][n_filters][rows], or (out_stft) [batch][rows][257][2]
+    int32_t out_stft;    // 1: write the scaled complex spectrum stft2 returns (functions.rs:86-123) instead of the mel rows
 };
 
 hipError_t launch_mel_c256(const Mel512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

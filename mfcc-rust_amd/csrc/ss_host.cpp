@@ -289,6 +289,16 @@ int build_tables(const ss_params &p, HostTables &t)
 }
 
 
+// The stft builds of the mel-spectrogram kernels do not touch the bank: when a configuration's bank does not fit a kernel's
+// mel stage (filter count, tap count, last bin), its table block is built once more without filters and marked stft_only.
+static HostTables without_bank(const HostTables &t)
+{
+    HostTables e = t;
+    e.params.num_filters = 0;
+    e.bank = decltype(e.bank){};
+    return e;
+}
+
 void build_fast512(const HostTables &t, Fast512Tables &f)
 {
     namespace L = fast512_layout;
@@ -359,7 +369,7 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     f.ok = true;
 }
 
-void build_mel512(const HostTables &t, Mel512Tables &f)
+static void build_mel512_bank(const HostTables &t, Mel512Tables &f)
 {
     namespace L = mel512_layout;
     f = Mel512Tables{};
@@ -533,7 +543,7 @@ void build_fast512m(const HostTables &t, Fast512MTables &f)
 }
 
 
-void build_mel2048(const HostTables &t, Mel2048Tables &f)
+static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
 {
     namespace L = mel2048_layout;
     f = Mel2048Tables{};
@@ -596,6 +606,26 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f)
     f.ok = true;
 }
 
+
+void build_mel2048(const HostTables &t, Mel2048Tables &f)
+{
+    build_mel2048_bank(t, f);
+    if (f.ok) return;
+    HostTables e = without_bank(t);
+    build_mel2048_bank(e, f);
+    f.stft_only = f.ok;
+    f.ok = false;
+}
+
+void build_mel512(const HostTables &t, Mel512Tables &f)
+{
+    build_mel512_bank(t, f);
+    if (f.ok) return;
+    HostTables e = without_bank(t);
+    build_mel512_bank(e, f);
+    f.stft_only = f.ok;
+    f.ok = false;
+}
 
 // mel = false: the frame-path kernel (ss_mfcc_c512); mel = true: the mel-spectrogram kernel (ss_mel_c512) -- same FFT tables
 // and bank layout, the Vorbis STFT window in kWin, no cosine rows
@@ -677,7 +707,15 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
 }
 
 void build_mfcc1024(const HostTables &t, Mfcc1024Tables &f) { build_1024(t, f, false); }
-void build_mel1024(const HostTables &t, Mfcc1024Tables &f) { build_1024(t, f, true); }
+void build_mel1024(const HostTables &t, Mfcc1024Tables &f)
+{
+    build_1024(t, f, true);
+    if (f.ok) return;
+    HostTables e = without_bank(t);
+    build_1024(e, f, true);
+    f.stft_only = f.ok;
+    f.ok = false;
+}
 
 void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
 {
@@ -826,7 +864,15 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
 }
 
 void build_mfcc4096(const HostTables &t, Mfcc4096Tables &f) { build_4096(t, f, false); }
-void build_mel4096(const HostTables &t, Mfcc4096Tables &f) { build_4096(t, f, true); }
+void build_mel4096(const HostTables &t, Mfcc4096Tables &f)
+{
+    build_4096(t, f, true);
+    if (f.ok) return;
+    HostTables e = without_bank(t);
+    build_4096(e, f, true);
+    f.stft_only = f.ok;
+    f.ok = false;
+}
 
 }  // namespace ss
 

@@ -112,6 +112,7 @@ constexpr int kPRow = 520;               // floats per P row: bins 0..512 + zero
 
 struct Mel2048Tables {
     bool ok = false;
+    bool stft_only = false;  // the bank does not fit the kernel's mel stage: the block serves the stft build only
     std::vector<float> tab;
     int32_t q4[4] = {0, 0, 0, 0};
     int32_t wpitch = 0;
@@ -130,6 +131,7 @@ constexpr int kMelW = kFilt + 80;        // [16][pitch]
 
 struct Mel512Tables {
     bool ok = false;
+    bool stft_only = false;  // the bank does not fit the kernel's mel stage: the block serves the stft build only
     bool fullp = false;
     std::vector<float> tab;
     int32_t q4[5] = {0, 0, 0, 0, 0};
@@ -170,6 +172,7 @@ constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
 
 struct Mfcc1024Tables {
     bool ok = false;
+    bool stft_only = false;  // mel-spectrogram block whose bank does not fit the mel stage: stft build only
     bool windowed = false;
     bool fullp = false;  // the bank reaches past bin 256: LIB builds
     std::vector<float> tab;
@@ -216,6 +219,7 @@ constexpr int kPRow = 1032;               // floats per P row: bins 0..1024 + ze
 
 struct Mfcc4096Tables {
     bool ok = false;
+    bool stft_only = false;  // mel-spectrogram block whose bank does not fit the mel stage: stft build only
     std::vector<float> tab;
     int32_t q4[4] = {0, 0, 0, 0};
     int32_t wpitch = 0;

@@ -13,6 +13,7 @@
 //     bank reaches past (F+1)/2 -- goes to a P row inside the slot.
 //   * banded mel, up to 5 filters per lane (80 filters), host-sorted by tap count; the four rows of a wave are adjacent
 //     words of out[clip][m][.].  No zero handling, no log (feature.rs:164-173).
+//   * stft build (ss_stft_device): skips the mel stage and writes X[k] wnorm for all 257 bins of a row.
 // Tables: ss::mel512_layout (ss_internal.h).
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -69,7 +70,7 @@ __device__ __forceinline__ float mel_slot_e(const float4 *w4, const float *p, in
     return acc;
 }
 
-template <int WAVES>
+template <int WAVES, bool STFT>
 __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
         fft16_reg(u);  // u[q] = Z[j + 16 q]
 
         // ---- untangle Z -> X; (|X| wnorm)^2 (functions.rs:166-169 + feature.rs:164) ----
+        // stft build (functions.rs:86-123, :166-169): X[k] * wnorm for all 257 bins of the row, interleaved re / im
+        float2 *srow = nullptr;
+        if (STFT && r < R) srow = reinterpret_cast<float2 *>(a.out) + (static_cast<unsigned long long>(clip) * R + r) * 257ull;
+        const float cs = 0.5f * a.scale;
         float2 zcs[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm_e(paddr, u[15 - q].x), bperm_e(paddr, u[15 - q].y));
@@ -201,6 +206,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
             // 2 X[k] = s - i w d, 2 conj X[256-k] = 2 s - 2 X[k]
             const float xr = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
             const float xi = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
+            if (STFT) {
+                if (srow) {
+                    srow[j + 16 * q] = make_float2(cs * xr, cs * xi);
+                    srow[256 - j - 16 * q] = make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
+                }
+                continue;
+            }
             prow[j + 16 * q] = hs * fmaf(xr, xr, xi * xi);
             if (a.fullp) {  // the bank reaches past (F+1)/2: bins 129..256 as well
                 const float yr = fmaf(2.f, s.x, -xr), yi = fmaf(2.f, s.y, -xi);
@@ -209,7 +221,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
         }
         if (j == 0) {
             const float2 z = u[8];  // X[128] = conj Z[128]
-            prow[128] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+            if (STFT) {
+                if (srow) srow[128] = make_float2(a.scale * z.x, -a.scale * z.y);
+            } else {
+                prow[128] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+            }
+        }
+        if (STFT) {
+            wave_order_e();
+            unit = next;
+            continue;
         }
         if (j < 3) prow[(a.fullp ? 257 : 129) + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         wave_order_e();
@@ -244,11 +265,14 @@ hipError_t launch_mel_c256(const Mel512Args &a, hipStream_t stream, int num_cus,
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
     const unsigned long long blocks = (units + WAVES - 1) / WAVES;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c256<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    if (info) *info = LaunchInfo{"ss_mel_c256", grid, static_cast<unsigned>(WAVES * 64), lds};
-    hipLaunchKernelGGL(ss_mel_c256<WAVES>, dim3(grid), dim3(WAVES * 64), lds, stream, a);
-    return hipGetLastError();
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    return a.out_stft ? go(ss_mel_c256<WAVES, true>, "ss_mel_c256<stft>") : go(ss_mel_c256<WAVES, false>, "ss_mel_c256");
 }
 
 }  // namespace ss

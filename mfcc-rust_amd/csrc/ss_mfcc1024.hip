@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 // one clip, the work unit is a (clip, row pair).  Row r covers the 1024 samples that end at chunk r + n_pad: zero initial
 // state, zero tail, rows past the real ones all zero (D3); windows inside the clip load at constant offsets, clip edges
 // through one masked range per lane.  The table block is mfcc1024_layout with the Vorbis window in kWin (kCos unused).
-template <int WAVES>
+template <int WAVES, bool STFT>
 __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -462,6 +462,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
             zcs[i] = make_float2(bperm_k(paddr, sv.x), bperm_k(paddr, sv.y));
         }
         const int kb = k1 + 128 * h;
+        // stft build (functions.rs:86-123, :166-169): X[k] * wnorm for all 513 bins of the row, interleaved re / im
+        float2 *srow = nullptr;
+        if (STFT && r < R) srow = reinterpret_cast<float2 *>(a.out) + (static_cast<unsigned long long>(clip) * R + r) * 513ull;
+        const float cs = 0.5f * a.scale;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float2 zk = r0[i];
@@ -473,6 +477,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
             // 2 X[k] = s - i w dd, 2 conj X[512-k] = 2 s - 2 X[k]
             const float xr = fmaf(w.y, dd.x, fmaf(w.x, dd.y, s.x));
             const float xi = fmaf(w.y, dd.y, fmaf(-w.x, dd.x, s.y));
+            if (STFT) {
+                if (srow) {
+                    srow[kb + 16 * i] = make_float2(cs * xr, cs * xi);
+                    srow[512 - (kb + 16 * i)] = make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
+                }
+                continue;
+            }
             prow[kb + 16 * i] = hs * fmaf(xr, xr, xi * xi);
             if (a.fullp) {  // the bank reaches past (F+1)/2: bins 257..512 as well
                 const float yr = fmaf(2.f, s.x, -xr), yi = fmaf(2.f, s.y, -xi);
@@ -481,7 +492,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
         }
         if (jj == 0) {
             const float2 z = r1[0];  // X[256] = conj Z[256]
-            prow[256] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+            if (STFT) {
+                if (srow) srow[256] = make_float2(a.scale * z.x, -a.scale * z.y);
+            } else {
+                prow[256] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+            }
+        }
+        if (STFT) {
+            wave_order_k();
+            unit = next;
+            continue;
         }
         if (jj < 3) prow[(a.fullp ? 513 : 257) + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
         wave_order_k();
@@ -558,11 +578,14 @@ hipError_t launch_mel_c512(const Mel2048Args &a, hipStream_t stream, int num_cus
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
     const unsigned long long blocks = (units + WAVES - 1) / WAVES;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c512<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    if (info) *info = LaunchInfo{"ss_mel_c512", grid, static_cast<unsigned>(WAVES * 64), lds};
-    hipLaunchKernelGGL(ss_mel_c512<WAVES>, dim3(grid), dim3(WAVES * 64), lds, stream, a);
-    return hipGetLastError();
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    return a.out_stft ? go(ss_mel_c512<WAVES, true>, "ss_mel_c512<stft>") : go(ss_mel_c512<WAVES, false>, "ss_mel_c512");
 }
 
 }  // namespace ss

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 // Row r covers the 4096 samples that end at chunk r + n_pad: zero initial state, zero tail, rows past the real ones all zero
 // (D3); windows inside the clip load at constant offsets, clip edges through one masked range per lane.  The table block is
 // mfcc4096_layout without cosine rows (the mel rows start at kCos) and with the Vorbis window behind the mel rows.
-template <int WAVES>
+template <int WAVES, bool STFT>
 __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -496,8 +496,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
             r1[i] = make_float2(px - wq.x, py - wq.y);
         }
         // ---- untangle Z -> X; (|X| wnorm)^2 of bins 0..1024 (functions.rs:166-169 + feature.rs:164) ----
-        if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        if (!STFT && lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float *pdst = prow + k1 + 512 * d;
+        // stft build (functions.rs:86-123, :166-169): X[k] * wnorm for all 2049 bins of the row, interleaved re / im
+        float2 *srow = STFT ? reinterpret_cast<float2 *>(a.out) + static_cast<unsigned long long>(row) * 2049ull : nullptr;
+        const int kb = k1 + 512 * d;
+        const float cs = 0.5f * a.scale;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             float2 zcs[8];
@@ -518,14 +522,25 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
                 const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
                 const float xr = fmaf(w.y, dd.x, fmaf(w.x, dd.y, s.x));  // 2 X[k] = s - i w dd
                 const float xi = fmaf(w.y, dd.y, fmaf(-w.x, dd.x, s.y));
-                pdst[32 * i] = hs * fmaf(xr, xr, xi * xi);
+                if (STFT) {
+                    srow[kb + 32 * i] = make_float2(cs * xr, cs * xi);
+                    // 2 conj X[2048 - k] = 2 s - 2 X[k]
+                    srow[2048 - (kb + 32 * i)] = make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
+                } else {
+                    pdst[32 * i] = hs * fmaf(xr, xr, xi * xi);
+                }
             }
         }
         if (lane == 0) {
             const float2 z = r1[0];  // X[1024] = conj Z[1024]
-            prow[1024] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
+            if (STFT) srow[1024] = make_float2(a.scale * z.x, -a.scale * z.y);
+            else prow[1024] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
         }
         wave_order_h();
+        if (STFT) {
+            row = next;
+            continue;
+        }
         // ---- banded mel reduction (feature.rs:173) -> out[clip][m][r] ----
         {
             float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
@@ -595,11 +610,14 @@ hipError_t launch_mel_c2048(const Mel2048Args &a, hipStream_t stream, int num_cu
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
     const unsigned long long blocks = (total + WAVES - 1) / WAVES;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ss_mel_c2048<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    if (info) *info = LaunchInfo{"ss_mel_c2048", grid, static_cast<unsigned>(WAVES * 64), lds};
-    hipLaunchKernelGGL(ss_mel_c2048<WAVES>, dim3(grid), dim3(WAVES * 64), lds, stream, a);
-    return hipGetLastError();
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    return a.out_stft ? go(ss_mel_c2048<WAVES, true>, "ss_mel_c2048<stft>") : go(ss_mel_c2048<WAVES, false>, "ss_mel_c2048");
 }
 
 }  // namespace ss

@@ -243,6 +243,33 @@ def test_stft_stage(ss, oracle, sslib):
     assert np.all(g[:, Rreal:] == 0)
 
 
+@pytest.mark.parametrize("nfft,sr,hop,kernel", [(512, 16000, 256, b"ss_mel_c256<stft>"), (512, 16000, 160, b"ss_mel_c256<stft>"),
+                                                 (1024, 16000, 512, b"ss_mel_c512<stft>"), (1024, 22050, 256, b"ss_mel_c512<stft>"),
+                                                 (4096, 44100, 1024, b"ss_mel_c2048<stft>")])
+def test_stft_stage_other_sizes(ss, oracle, sslib, nfft, sr, hop, kernel):
+    """stft2's output (functions.rs:86-123) from the stft builds of the 512-, 1024- and 4096-point mel kernels: all bins of
+    every row, trailing n_pad rows zero, row counts that do not fill the last wave, partial last chunks."""
+    import torch
+    from speechsauce_amd import _lib
+
+    kw = dict(sample_rate=sr, fft_points=nfft, frame_length=hop / sr, frame_stride=hop / sr, num_filters=128)  # 512 points: more filters than the mel stage takes -> a table block for the stft build only
+    cfg = _cfg(ss, **kw)
+    n = 3 * nfft + 6 * hop + 88
+    x = _signal(73, (5, n))
+    R, Rreal = cfg.stft_rows(n)
+    F = nfft // 2 + 1
+    out = torch.full((5, R, F, 2), 7.0, dtype=torch.float32, device="cuda")
+    _lib.check(sslib.ss_stft_device(cfg.handle, torch.from_numpy(x).cuda().data_ptr(), 5, n, n, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert sslib.ss_last_kernel_name() == kernel, sslib.ss_last_kernel_name()
+    got = out.cpu().numpy()
+    g = got[..., 0] + 1j * got[..., 1]
+    want = oracle.stft(oracle.make_params(**kw), x)
+    assert g.shape == want.shape
+    assert np.abs(g - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.all(g[:, Rreal:] == 0)
+
+
 def test_preemphasis(ss, oracle):
     x = _signal(8, 4001)
     for shift, cof in [(1, 0.98), (3, 0.5), (4001, 0.9)]:
