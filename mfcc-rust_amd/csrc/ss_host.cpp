@@ -793,7 +793,7 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
     f = Mfcc4096Tables{};
     const size_t M = t.params.num_filters, Cc = mel ? 0 : t.params.num_cepstral;
     if (t.d.n_fft != 4096 || M > 256 || Cc > 64) return;
-    if (!mel && M != 256) return;  // the symmetric DCT below is written for 256 filters
+    if (!mel && (M & 1)) return;  // the symmetric DCT is written for an even filter count
     if (mel && (!t.d.stft_ok || t.window_stft.size() != 4096)) return;
     if (t.bank.last_bin > 1025) return;  // the kernel keeps P bins 0..1024
     constexpr int32_t kRow = 1028;       // P bins a tap may touch: 0..1024 plus three zero pad bins
@@ -854,7 +854,7 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
         off += span;
     }
     for (size_t cc = 0; cc < Cc; ++cc)
-        for (size_t m = 0; m < 128; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
+        for (size_t m = 0; m < M / 2; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
     if (mel) {
         const size_t base = f.tab.size();
         f.tab.resize(base + 4096);

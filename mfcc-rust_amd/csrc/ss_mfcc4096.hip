@@ -153,6 +153,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
     const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32H;
     const bool k1z = k1 == 0;
+    const int M = static_cast<int>(a.n_filters), Mh = M / 2;
 
     unsigned frame = f_lo + wave;
     while (frame < f_hi) {
@@ -303,8 +304,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int s = 0; s < 4; ++s) {
                 float m = hscale32 * mel_slot_h(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 m = m == 0.f ? kEpsH * kTwo32H : m;
-                if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32H);  // exact: power of two
-                else frow[fi[s]] = ln_scaled_h(m);
+                if (fi[s] >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
+                    if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32H);  // exact: power of two
+                    else frow[fi[s]] = ln_scaled_h(m);
+                }
                 off += a.mel_q4[s];
             }
         }
@@ -328,7 +331,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int m = lane + 64 * h2;
-                const float lo = frow[m], hi = frow[255 - m];
+                const bool in = m < Mh;  // M < 256: the rows are zero beyond M/2 (as are the cosine rows)
+                const float lo = in ? frow[m] : 0.f, hi = in ? frow[M - 1 - m] : 0.f;
                 srow[m] = lo + hi;
                 drow[m] = lo - hi;
             }

@@ -571,6 +571,29 @@ def test_cpp_mirror_parity(tmp_path, oracle):
     assert _rel(n, oracle.cmvn(m, True)) <= RTOL
 
 
+def test_mfcc_4096_other_filter_counts(ss, oracle, sslib):
+    """The 4096-point kernel with fewer than 256 filters (any even count): 128 mels / 20 cepstra, 100 mels with a window, mfe."""
+    import torch
+
+    sr = 44100
+    x = _signal(26, (4, sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, M, C, sw in ((4096, 128, 20, {}), (3000, 100, 13, dict(mfcc_window="hann")), (4096, 64, 40, dict(dc_elimination=False))):
+        kw = dict(frame_length=flen / sr, frame_stride=1024 / sr, num_cepstral=C, num_filters=M, fft_length=4096)
+        p = oracle.make_params(sample_rate=sr, fft_points=4096, frame_length=flen / sr, frame_stride=1024 / sr, num_cepstral=C,
+                               num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c2048<"), sslib.ss_last_kernel_name()
+        for b in (0, 3):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, M, C, sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        msw = {k: v for k, v in sw.items() if k != "dc_elimination"}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
+        assert b"mfe" in sslib.ss_last_kernel_name()
+        wf, we = oracle.mfe(p, x[3])
+        assert _rel(feat[3].cpu().numpy(), wf) <= RTOL and _rel(en[3].cpu().numpy(), we) <= RTOL
+
+
 def test_cfg5_mfe(ss, oracle, sslib):
     """mfe at the high-resolution configuration: the mfe build of the 4096-point kernel (256 filters, 19 of them empty)."""
     import torch
