@@ -46,6 +46,9 @@ struct ss_config {
     // fft_points = 256 MFCC kernel tables (ss_mfcc256.hip)
     ss::Mfcc256Tables mfcc256;
     float *d_mfcc256_tab = nullptr;
+    // wide-bank fft_points = 512 MFCC kernel tables (ss_mfcc512w.hip)
+    ss::Mfcc512wTables mfcc512w;
+    float *d_mfcc512w_tab = nullptr;
     // fft_points = 512 mel-spectrogram kernel tables (ss_mel512.hip)
     ss::Mel512Tables mel512;
     float *d_mel512_tab = nullptr;
@@ -267,6 +270,39 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         }
         hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256");
+        g_last_kernel = info.kernel_name;
+        return SS_OK;
+    }
+    // fft_points = 512 MFCC / mfe with more than 48 filters (ss_mfcc512w.hip): layout assumptions of the headline kernel,
+    // optional frame window, no fused pre-emphasis
+    if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
+        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL && a.preemph == 0.0f &&
+        (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        ss::Mfcc256Args f{};
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tab = cfg->d_mfcc512w_tab;
+        f.mel_wpitch = cfg->mfcc512w.wpitch;
+        for (int s = 0; s < 5; ++s) f.mel_q4[s] = cfg->mfcc512w.q4[s];
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        f.windowed = cfg->mfcc512w.windowed;
+        f.out_mfe = out_kind == ss::OUT_MFE;
+        f.out = out0;
+        f.out_energy = out1;
+        hipError_t e5 = ss::launch_mfcc_c256w(f, stream, cfg->num_cus, &info);
+        if (e5 != hipSuccess) return hip_fail(e5, "launch_mfcc_c256w");
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
@@ -577,6 +613,10 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mfcc1024.ok) SS_UP(d_mfcc1024_tab, c->mfcc1024.tab);
     ss::build_mfcc256(h, c->mfcc256);
     if (c->mfcc256.ok) SS_UP(d_mfcc256_tab, c->mfcc256.tab);
+    if (!c->fast.ok) {  // the headline kernel takes up to 48 filters; beyond that the wide-bank build
+        ss::build_mfcc512w(h, c->mfcc512w);
+        if (c->mfcc512w.ok) SS_UP(d_mfcc512w_tab, c->mfcc512w.tab);
+    }
     ss::build_mel512(h, c->mel512);
     if (c->mel512.ok || c->mel512.stft_only) SS_UP(d_mel512_tab, c->mel512.tab);
     ss::build_mel1024(h, c->mel1024);
@@ -599,7 +639,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
+                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mfcc512w_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;

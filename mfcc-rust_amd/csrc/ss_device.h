@@ -211,7 +211,7 @@ struct Mfcc256Args {
     int32_t spectrum_exponent;
     const float *tab;    // table block (layout: ss::mfcc256_layout in ss_internal.h), copied verbatim into LDS
     int32_t mel_wpitch;  // floats per lane weight row
-    int32_t mel_q4[3];   // taps / 4 per slot
+    int32_t mel_q4[5];   // taps / 4 per slot (three slots in the 256-point kernel, five in the wide-bank 512-point one)
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
@@ -223,6 +223,8 @@ struct Mfcc256Args {
 };
 
 hipError_t launch_mfcc_c256x2(const Mfcc256Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+// fft_points = 512 MFCC / mfe with up to 80 filters (ss_mfcc512w.hip): same argument block, table layout ss::mfcc512w_layout
+hipError_t launch_mfcc_c256w(const Mfcc256Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
 // Arguments of the fft_points = 4096 MFCC kernel (ss_mfcc4096.hip).
 struct Mfcc4096Args {

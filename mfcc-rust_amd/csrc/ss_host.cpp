@@ -431,6 +431,72 @@ static void build_mel512_bank(const HostTables &t, Mel512Tables &f)
     f.ok = true;
 }
 
+void build_mfcc512w(const HostTables &t, Mfcc512wTables &f)
+{
+    namespace L = mfcc512w_layout;
+    f = Mfcc512wTables{};
+    const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
+    if (t.d.n_fft != 512 || M > 80 || Cc > 16) return;
+    if (t.bank.last_bin > 257) return;
+    constexpr int32_t kRow = 260;  // P bins a tap may touch: 0..256 plus three zero pad bins
+    std::vector<int32_t> order(M);
+    for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
+    int32_t maxlen[5] = {0, 0, 0, 0, 0};
+    for (size_t q = 0; q < M; ++q) maxlen[q / 16] = std::max(maxlen[q / 16], t.bank.len[order[q]]);
+    f.wpitch = 0;
+    for (int s = 0; s < 5; ++s) {
+        f.q4[s] = (maxlen[s] + 3) / 4;
+        f.wpitch += 4 * f.q4[s];
+    }
+    if (f.wpitch == 0) f.wpitch = 4;
+    if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the 16 lanes' ds_read_b128 rows spread over the banks
+    if (f.wpitch > 320) return;
+    f.tab.assign(static_cast<size_t>(L::kMelW) + 16 * static_cast<size_t>(f.wpitch), 0.0f);
+    for (int r = 1; r < 16; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256) = tw_c[j r]; two twiddles per 16-byte slot
+            const int p = (r - 1) / 2, half = (r - 1) % 2;
+            f.tab[L::kTw2 + (p * 16 + j) * 4 + 2 * half] = t.tw_c[2 * (j * r)];
+            f.tab[L::kTw2 + (p * 16 + j) * 4 + 2 * half + 1] = t.tw_c[2 * (j * r) + 1];
+        }
+    for (int r = 0; r < 8; ++r)
+        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i (j + 16 r) / 512) = tw_n[j + 16 r]
+            f.tab[L::kTwn + (r * 16 + j) * 2] = t.tw_n[2 * (j + 16 * r)];
+            f.tab[L::kTwn + (r * 16 + j) * 2 + 1] = t.tw_n[2 * (j + 16 * r) + 1];
+        }
+    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
+    int32_t off = 0;
+    for (int s = 0; s < 5; ++s) {
+        const int32_t span = 4 * f.q4[s];
+        for (int j = 0; j < 16; ++j) {
+            const size_t q = static_cast<size_t>(s) * 16 + j;
+            start[q] = 0;
+            filt[q] = -1;
+            if (q >= M) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
+            const int32_t m = order[q];
+            filt[q] = m;
+            int32_t st = t.bank.start[m];
+            const int32_t len = t.bank.len[m];
+            int32_t shift = 0;  // the lock-step loop reads `span` taps: keep st + span inside the row
+            if (st + span > kRow) shift = st + span - kRow;
+            st -= shift;
+            start[q] = st;
+            for (int32_t i = 0; i < len; ++i)
+                f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
+            for (size_t c = 0; c < Cc; ++c) f.tab[L::kCos + c * L::kCosPitch + q] = t.dct[c * M + m];
+        }
+        off += span;
+    }
+    if (!t.window_mfcc.empty()) {  // optional frame window (mfcc_window switch), read as sample pairs
+        f.windowed = true;
+        const size_t base = f.tab.size();
+        f.tab.resize(base + 512, 0.0f);
+        for (size_t i = 0; i < t.window_mfcc.size() && i < 512; ++i) f.tab[base + i] = t.window_mfcc[i];
+    }
+    f.ok = true;
+}
+
 void build_mfcc256(const HostTables &t, Mfcc256Tables &f)
 {
     namespace L = mfcc256_layout;

@@ -687,6 +687,40 @@ def test_mfcc_1024_kernel(ss, oracle, sslib):
         assert _rel(feat[8].cpu().numpy(), wf) <= RTOL and _rel(en[8].cpu().numpy(), we) <= RTOL
 
 
+def test_mfcc_512_wide_bank_kernel(ss, oracle, sslib):
+    """fft_points = 512 with more than 48 filters (log-mel front ends: 25 ms frames, 64 / 80 mels): the wide-bank kernel;
+    mfe and MFCC, window, power spectrum, Slaney bank over the whole spectrum, 20 ms frames, short clips."""
+    import torch
+
+    sr = 16000
+    x = _signal(35, (9, sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, M, C, sw in ((400, 80, 13, {}), (400, 64, 16, dict(mfcc_window="hann", spectrum_exponent=2)), (320, 64, 13, {}),
+                           (512, 80, 13, dict(mel_scale="slaney", mel_norm="slaney", mfcc_window="hann", spectrum_exponent=2, dct_norm="ortho")),
+                           (400, 57, 12, dict(dc_elimination=False))):
+        kw = dict(frame_length=flen / sr, frame_stride=0.01, num_cepstral=C, num_filters=M, fft_length=512)
+        p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=flen / sr, frame_stride=0.01, num_cepstral=C, num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<"), sslib.ss_last_kernel_name()
+        assert got.shape == (9, oracle.num_frames(p, sr), C)
+        for b in (0, 4, 8):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, M, sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        msw = {k: v for k, v in sw.items() if k not in ("dc_elimination", "dct_norm")}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
+        assert b"mfe" in sslib.ss_last_kernel_name() and sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<")
+        for b in (0, 8):
+            wf, we = oracle.mfe(p, x[b])
+            assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL
+    # three frames per clip (the per-lane division path), odd clip count
+    p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=0.025, num_filters=80)
+    xs = _signal(36, (5, 400 + 160 * 3 + 2))
+    got = ss.mfcc_batch(torch.from_numpy(xs).cuda(), sr, frame_length=0.025, num_filters=80).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<") and got.shape[1] == oracle.num_frames(p, xs.shape[1]) < 4
+    for b in range(5):
+        assert _rel(got[b], oracle.mfcc(p, xs[b])) <= RTOL, b
+
+
 def test_mfcc_256_kernel(ss, oracle, sslib):
     """MFCC / mfe at fft_points = 256 (8 kHz telephony front ends): two frames per complex transform.  20 ms and 25 ms frames,
     odd hops (scalar loads: no alignment assumptions), window, power spectrum, filter counts up to 48, batches whose frame count
