@@ -436,7 +436,7 @@ void build_mfcc512w(const HostTables &t, Mfcc512wTables &f)
     namespace L = mfcc512w_layout;
     f = Mfcc512wTables{};
     const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
-    if (t.d.n_fft != 512 || M > 80 || Cc > 16) return;
+    if (t.d.n_fft != 512 || M > 80 || Cc > 32) return;
     if (t.bank.last_bin > 257) return;
     constexpr int32_t kRow = 260;  // P bins a tap may touch: 0..256 plus three zero pad bins
     std::vector<int32_t> order(M);

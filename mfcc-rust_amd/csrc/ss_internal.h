@@ -123,9 +123,9 @@ void build_mel2048(const HostTables &t, Mel2048Tables &f);
 namespace mfcc512w_layout {
 constexpr int kTw2 = 0;                  // [8][16] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 256); last .zw unused
 constexpr int kTwn = kTw2 + 8 * 64;      // [8][16] float2: exp(-2 pi i (j + 16 r) / 512)
-constexpr int kCos = kTwn + 8 * 32;      // [16][84]: row c: cos(pi c (2m+1) / 2M) in (slot, lane) order, zero where no filter
+constexpr int kCos = kTwn + 8 * 32;      // [32][84]: row c: cos(pi c (2m+1) / 2M) in (slot, lane) order, zero where no filter
 constexpr int kCosPitch = 84;
-constexpr int kStart = kCos + 16 * kCosPitch;  // [5][16] int32: first P bin of the filter owned by (slot, lane)
+constexpr int kStart = kCos + 32 * kCosPitch;  // [5][16] int32: first P bin of the filter owned by (slot, lane)
 constexpr int kFilt = kStart + 80;       // [5][16] int32: filter index of (slot, lane), -1 if none
 constexpr int kMelW = kFilt + 80;        // [16][pitch]; an optional frame window [512] follows
 }  // namespace mfcc512w_layout

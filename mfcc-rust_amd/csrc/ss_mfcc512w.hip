@@ -10,7 +10,8 @@
 //     and to the frame energy.
 //   * banded mel, five filters per lane (host-sorted by tap count), zero handling, ln -> (slot, lane)-ordered row of 80;
 //     DCT-II as an 80-term product per lane with the lane's cosine row; reference scaling and column-0 replacement.
-//     mfe builds stop after the mel stage.  Optional frame window from the table block.
+//     mfe builds stop after the mel stage.  Optional frame window from the table block.  Up to 32 cepstra (two coefficients
+//     per lane beyond 16), which also brings configurations with at most 48 filters but more than 16 cepstra here.
 // Reference semantics: feature.rs:99-148 (mfcc), :200-233 (mfe), processing.rs:65-181.  Tables: ss::mfcc512w_layout.
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -274,27 +275,60 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
                 for (int k = 0; k < 5; ++k) frow[16 * k + j] = ln_scaled_x(m[k]);
                 wave_order_x();
                 // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 80-entry row ----
-                float acc = 0.f;
+                if (Cc <= 16) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    float4 lq[5], cq[5];
+                    for (int h = 0; h < 4; ++h) {
+                        float4 lq[5], cq[5];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (5 * h + i)]);
-                        cq[i] = c4[5 * h + i];
+                        for (int i = 0; i < 5; ++i) {
+                            lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (5 * h + i)]);
+                            cq[i] = c4[5 * h + i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            acc = fmaf(lq[i].x, cq[i].x, acc);
+                            acc = fmaf(lq[i].y, cq[i].y, acc);
+                            acc = fmaf(lq[i].z, cq[i].z, acc);
+                            acc = fmaf(lq[i].w, cq[i].w, acc);
+                        }
                     }
+                    // scaling + column-0 replacement (feature.rs:126-146)
+                    float o = acc * a.dct_scale_k;
+                    if (j == 0) o = a.dc_elimination ? ln_scaled_x(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                    if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
+                } else {
+                    // 17..32 cepstra: the lane also forms coefficient 16 + j from the same row fetches
+                    const float4 *d4 = c4 + 16 * (L::kCosPitch / 4);
+                    float acc = 0.f, acc2 = 0.f;
+#pragma unroll 1
+                    for (int h = 0; h < 10; ++h) {  // small batches: this path runs next to the prefetch registers
+                        float4 lq[2], cq[2], dq[2];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        acc = fmaf(lq[i].x, cq[i].x, acc);
-                        acc = fmaf(lq[i].y, cq[i].y, acc);
-                        acc = fmaf(lq[i].z, cq[i].z, acc);
-                        acc = fmaf(lq[i].w, cq[i].w, acc);
+                        for (int i = 0; i < 2; ++i) {
+                            lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (2 * h + i)]);
+                            cq[i] = c4[2 * h + i];
+                            dq[i] = d4[2 * h + i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            acc = fmaf(lq[i].x, cq[i].x, acc);
+                            acc = fmaf(lq[i].y, cq[i].y, acc);
+                            acc = fmaf(lq[i].z, cq[i].z, acc);
+                            acc = fmaf(lq[i].w, cq[i].w, acc);
+                            acc2 = fmaf(lq[i].x, dq[i].x, acc2);
+                            acc2 = fmaf(lq[i].y, dq[i].y, acc2);
+                            acc2 = fmaf(lq[i].z, dq[i].z, acc2);
+                            acc2 = fmaf(lq[i].w, dq[i].w, acc2);
+                        }
+                    }
+                    float o = acc * a.dct_scale_k;
+                    if (j == 0) o = a.dc_elimination ? ln_scaled_x(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                    if (gf < total) {
+                        a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
+                        if (16 + j < Cc) a.out[static_cast<unsigned long long>(gf) * Cc + 16 + j] = acc2 * a.dct_scale_k;
                     }
                 }
-                // scaling + column-0 replacement (feature.rs:126-146)
-                float o = acc * a.dct_scale_k;
-                if (j == 0) o = a.dc_elimination ? ln_scaled_x(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
-                if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
             }
         }
         wave_order_x();

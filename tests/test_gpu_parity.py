@@ -697,7 +697,8 @@ def test_mfcc_512_wide_bank_kernel(ss, oracle, sslib):
     xd = torch.from_numpy(x).cuda()
     for flen, M, C, sw in ((400, 80, 13, {}), (400, 64, 16, dict(mfcc_window="hann", spectrum_exponent=2)), (320, 64, 13, {}),
                            (512, 80, 13, dict(mel_scale="slaney", mel_norm="slaney", mfcc_window="hann", spectrum_exponent=2, dct_norm="ortho")),
-                           (400, 57, 12, dict(dc_elimination=False))):
+                           (400, 57, 12, dict(dc_elimination=False)), (400, 80, 30, {}), (320, 40, 20, dict(dc_elimination=False)),
+                           (400, 64, 32, dict(dct_norm="ortho"))):  # more than 16 cepstra: two coefficients per lane
         kw = dict(frame_length=flen / sr, frame_stride=0.01, num_cepstral=C, num_filters=M, fft_length=512)
         p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=flen / sr, frame_stride=0.01, num_cepstral=C, num_filters=M, **sw)
         got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
@@ -708,7 +709,8 @@ def test_mfcc_512_wide_bank_kernel(ss, oracle, sslib):
         mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
         msw = {k: v for k, v in sw.items() if k not in ("dc_elimination", "dct_norm")}
         feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
-        assert b"mfe" in sslib.ss_last_kernel_name() and sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<")
+        # (mfe takes no cepstrum count: with at most 48 filters the headline kernel's mfe build serves it)
+        assert b"mfe" in sslib.ss_last_kernel_name() and sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<" if M > 48 else b"ss_mfcc_c256<")
         for b in (0, 8):
             wf, we = oracle.mfe(p, x[b])
             assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL
