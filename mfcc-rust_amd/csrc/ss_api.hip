@@ -276,9 +276,11 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // fft_points = 512 MFCC / mfe with more than 48 filters (ss_mfcc512w.hip): layout assumptions of the headline kernel,
     // optional frame window, no fused pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
-        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL && a.preemph == 0.0f &&
-        (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) &&
+        a.preemph == 0.0f && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
         ss::Mfcc256Args f{};
+        f.center = centre;
+        f.pad_reflect = a.pad_reflect;
         f.x = d_x;
         f.ld = ld;
         f.n_samples = a.n_samples;
@@ -613,7 +615,7 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mfcc1024.ok) SS_UP(d_mfcc1024_tab, c->mfcc1024.tab);
     ss::build_mfcc256(h, c->mfcc256);
     if (c->mfcc256.ok) SS_UP(d_mfcc256_tab, c->mfcc256.tab);
-    if (!c->fast.ok) {  // the headline kernel takes up to 48 filters; beyond that the wide-bank build
+    if (!c->fast.ok) {  // the headline kernel takes up to 48 filters and 16 cepstra; beyond that the wide-bank build
         ss::build_mfcc512w(h, c->mfcc512w);
         if (c->mfcc512w.ok) SS_UP(d_mfcc512w_tab, c->mfcc512w.tab);
     }

@@ -217,6 +217,8 @@ struct Mfcc256Args {
     int32_t dc_elimination;
     int32_t windowed;    // the table block carries a frame window (mfcc_window switch)
     int32_t out_mfe;     // 1: write mfe's (features, energy) instead of the cepstra
+    int32_t center;      // wide-bank 512-point kernel only: librosa center=True framing (flen % 4 == 0)
+    int32_t pad_reflect; // np.pad 'reflect' (else zeros) outside the clip for centred frames
     uint32_t nf_magic, nf_shift;  // set by the launcher: frame -> (clip, t) by multiply-high
     float *out;
     float *out_energy;

@@ -10,7 +10,8 @@
 //     and to the frame energy.
 //   * banded mel, five filters per lane (host-sorted by tap count), zero handling, ln -> (slot, lane)-ordered row of 80;
 //     DCT-II as an 80-term product per lane with the lane's cosine row; reference scaling and column-0 replacement.
-//     mfe builds stop after the mel stage.  Optional frame window from the table block.  Up to 32 cepstra (two coefficients
+//     mfe builds stop after the mel stage.  Optional frame window from the table block; centred frames (librosa
+//     center=True, reflect / zero padding at the clip edges) at run time.  Up to 32 cepstra (two coefficients
 //     per lane beyond 16), which also brings configurations with at most 48 filters but more than 16 cepstra here.
 // Reference semantics: feature.rs:99-148 (mfcc), :200-233 (mfe), processing.rs:65-181.  Tables: ss::mfcc512w_layout.
 #include "ss_device.h"
@@ -113,10 +114,35 @@ __device__ __forceinline__ unsigned load_quad_w(const Mfcc256Args &a, unsigned q
         clip = gf / a.n_frames;
         t = gf - clip * a.n_frames;
     }
-    // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
-    const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + static_cast<unsigned long long>(t) * a.step) + j;
+    const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+    // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step.  librosa center=True (the
+    // `framing` switch): frame t is centred on sample t*step; frames inside the clip load the same way from their (even)
+    // start, the few at the clip edges mirror (np.pad 'reflect') or zero their out-of-range samples
+    const int s0 = static_cast<int>(t * a.step) - (a.center ? static_cast<int>(a.flen / 2) : 0), ns = static_cast<int>(a.n_samples);
+    if (!a.center || __all(s0 >= 0 && s0 + static_cast<int>(a.flen) <= ns)) {
+        const float2 *src = reinterpret_cast<const float2 *>(xc + s0) + j;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) vin[e] = 2 * (j + 16 * e) < static_cast<int>(a.flen) ? src[16 * e] : make_float2(0.f, 0.f);
+        for (int e = 0; e < NE; ++e) vin[e] = 2 * (j + 16 * e) < static_cast<int>(a.flen) ? src[16 * e] : make_float2(0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int n = j + 16 * e;
+            float sv[2] = {0.f, 0.f};
+            if (2 * n < static_cast<int>(a.flen)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int pos = s0 + 2 * n + h;
+                    bool ok = true;
+                    if (pos < 0 || pos >= ns) {
+                        if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+                        else ok = false;
+                    }
+                    if (ok) sv[h] = xc[pos];
+                }
+            }
+            vin[e] = make_float2(sv[0], sv[1]);
+        }
+    }
     return t;
 }
 

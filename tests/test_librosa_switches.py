@@ -189,3 +189,36 @@ def test_librosa_like_large_fft_gpu(ss, oracle, sslib, nfft, hop, mels, kernel):
     p = oracle.make_params(**base, **lib)
     got = ss.mfcc(xs, sr, **args, **lib)
     assert _rel(got, oracle.mfcc(p, xs)) <= RTOL
+
+
+@pytest.mark.gpu
+def test_log_mel_80_centred_gpu(ss, oracle, sslib):
+    """The modern speech front end at a power-of-two FFT: 16 kHz, n_fft = win_length = 512, hop 160, 80 Slaney mels over
+    0..8 kHz, centred reflect-padded frames, Hann window, power 2 -- mel energies (mfe) and MFCCs -- on the wide-bank kernel."""
+    import torch
+
+    sr = 16000
+    sw = dict(framing="center", pad_mode="reflect", mfcc_window="hann", spectrum_exponent=2, mel_scale="slaney", mel_norm="slaney",
+              dct_norm="ortho")
+    x = _signal(66, (6, sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, pad in ((512, "reflect"), (400, "constant")):
+        s2 = dict(sw, pad_mode=pad)
+        p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=flen / sr, frame_stride=0.01, num_cepstral=13, num_filters=80, **s2)
+        margs = dict(frame_length=flen / sr, frame_stride=0.01, fft_length=512, num_filters=80)
+        feat, en = ss.mfe_batch(xd, sr, **margs, **{k: v for k, v in s2.items() if k != "dct_norm"})
+        name = sslib.ss_last_kernel_name().decode()
+        assert name.startswith("ss_mfcc_c256w<") and "mfe" in name and "win" in name, name
+        assert feat.shape == (6, oracle.num_frames(p, sr), 80)
+        for b in (0, 5):
+            wf, we = oracle.mfe(p, x[b])
+            assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL, (flen, b)
+        got = ss.mfcc_batch(xd, sr, num_cepstral=13, **margs, **s2).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<")
+        for b in (0, 5):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, b)
+    # a clip barely longer than half a frame: every frame touches both edges
+    xs = _signal(67, 300)
+    p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=512 / sr, frame_stride=0.01, num_cepstral=13, num_filters=80, **sw)
+    got = ss.mfcc(xs, sr, frame_length=512 / sr, num_filters=80, **sw)
+    assert _rel(got, oracle.mfcc(p, xs)) <= RTOL
