@@ -1,6 +1,6 @@
 """Seeded sweep over the configuration space: every case goes through the public Python front (hence through whichever
-kernel build the dispatcher picks: default-bank / generic-bank / windowed / pre-emphasised builds of the 512-point kernel,
-the 2048- and 4096-point kernels, the generic kernel) and is compared with the oracle."""
+kernel build the dispatcher picks: the builds of the 512-point kernel, the wide-bank one, the 256-, 1024-, 2048- and
+4096-point kernels, the mel-spectrogram kernels, the generic kernel) and is compared with the oracle."""
 import numpy as np
 import pytest
 
@@ -50,7 +50,10 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("block", range(4))
+SEEN = set()
+
+
+@pytest.mark.parametrize("block", range(6))
 def test_random_configurations(ss, oracle, sslib, block):
     import torch
 
@@ -68,6 +71,7 @@ def test_random_configurations(ss, oracle, sslib, block):
                     high_frequency=kw["high_frequency"], dc_elimination=kw["dc_elimination"])
         got = ss.mfcc_batch(torch.from_numpy(x).cuda(), kw["sample_rate"], **args, **sw).cpu().numpy()
         kernels.add(sslib.ss_last_kernel_name().decode().split("<")[0])
+        SEEN.add(sslib.ss_last_kernel_name().decode().split("<")[0])
         assert got.shape == (batch, T, kw["num_cepstral"]), (kw, sw)
         for b in {0, batch - 1}:
             assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (kw, sw, b)
@@ -76,6 +80,14 @@ def test_random_configurations(ss, oracle, sslib, block):
         wf, we = oracle.mfe(p, x[batch - 1])
         assert _rel(feat[batch - 1].cpu().numpy(), wf) <= RTOL and _rel(en[batch - 1].cpu().numpy(), we) <= RTOL, (kw, sw)
     assert kernels  # at least one case ran
+
+
+def test_sweep_reached_every_frame_kernel():
+    """The seeded sweep above is only worth its name if the dispatcher sent cases to every frame-path kernel family."""
+    if not SEEN:
+        pytest.skip("runs after test_random_configurations in the same process")
+    want = {"ss_mfcc_c256", "ss_mfcc_c256w", "ss_mfcc_c256x2", "ss_mfcc_c512", "ss_mfcc_c1024", "ss_mfcc_c2048", "ss_front_generic"}
+    assert want <= SEEN, sorted(want - SEEN)
 
 
 def test_random_mel_spectrogram_configurations(ss, oracle, sslib):
