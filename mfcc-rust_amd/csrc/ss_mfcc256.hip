@@ -4,7 +4,9 @@
 // complex transform instead, z[n] = a[n] + i b[n], so the butterfly core is the one of ss_mfcc512.hip and the untangle
 // needs no twiddles at all:
 //     2 A[k] = Z[k] + conj Z[256-k],   2 B[k] = -i (Z[k] - conj Z[256-k])   =>   |2A| = |s|, |2B| = |d|
-// with s, d the sum / difference the 512-point kernel forms anyway.
+// with s, d the sum / difference the 512-point kernel forms anyway.  The price is a rounding error relative to the louder
+// frame of a pair; pairs more than 30 dB apart (silence next to speech, zero padding) are therefore transformed one frame
+// at a time (kPairGuard).
 //
 //   * Work unit: an OCT of 8 consecutive frames of the flat frame list; 16 lanes (one DPP row) own a frame pair, 16
 //     complex points per lane.  One persistent workgroup per CU, waves pull octs from an LDS counter, the next oct's
@@ -32,6 +34,7 @@ constexpr float kTwo32X = 4294967296.f;
 constexpr int kSlotFloats = 576;        // per frame pair: exchange slot (288 float2); afterwards P rows [2][132] | ln(mel) rows [2][48]
 constexpr int kWaveFloatsX = 4 * kSlotFloats;
 constexpr int kPRowX = 132;             // bins 0..128 + three zero pad bins
+constexpr float kPairGuard = 1000.f;    // energy ratio (30 dB) beyond which the two frames of a pair are transformed one at a time
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_x(float v)
@@ -200,10 +203,26 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         next = __builtin_amdgcn_readfirstlane(next);
         const unsigned tA = tA_next, tB = tB_next;
 
+        // Guard of the two-for-one transform: its rounding error is relative to the LOUDER frame of a pair, so a frame of
+        // (near) silence next to a loud one would come out with the loud one's noise floor instead of its own spectrum --
+        // and an all-zero frame with a non-zero one instead of the exact zeros (-> f32::EPSILON, functions.rs:66-71) the
+        // reference produces.  When the energies of a pair differ by more than 30 dB the wave runs the oct in two passes,
+        // a + i 0 and then 0 + i b, each frame alone in its transform (error relative to itself, exact zeros stay exact).
+        float ea = 0.f, eb = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            ea = fmaf(vin[e].x, vin[e].x, ea);
+            eb = fmaf(vin[e].y, vin[e].y, eb);
+        }
+        ea = row16_sum_x(ea);
+        eb = row16_sum_x(eb);
+        const int npass = __any(fmaxf(ea, eb) > kPairGuard * fminf(ea, eb)) ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
         float2 v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float2 s = e < NE ? vin[e] : make_float2(0.f, 0.f);
+            if (npass == 2) s = pass == 0 ? make_float2(s.x, 0.f) : make_float2(0.f, s.y);
             if (WIN && e < NE) s = make_float2(s.x * wn[e], s.y * wn[e]);
             v[e] = s;
         }
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
 #pragma unroll
         for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         wave_order_x();
-        if (next < o_hi) load_oct<NE>(a, next, total, f, j, vin, tA_next, tB_next);
+        if (pass == npass - 1 && next < o_hi) load_oct<NE>(a, next, total, f, j, vin, tA_next, tB_next);  // the input registers are dead now
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -273,6 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            if (npass == 2 && s != pass) continue;  // two-pass octs: this pass carried frame `pass` only
             const float *pr = slot + s * kPRowX;
             float *frow = slot + 2 * kPRowX + 48 * s;
             float m[3];
@@ -321,6 +341,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
         }
         wave_order_x();
+        }
         oct = next;
     }
 }

@@ -349,6 +349,67 @@ def test_edge_signals(ss, oracle):
     assert _rel(ss.mfcc(imp, 16000), oracle.mfcc(p, imp)) <= RTOL
 
 
+@pytest.mark.parametrize("sr,nfft,flen,hop,M,C", [(8000, 256, 160, 80, 40, 13), (16000, 512, 400, 160, 80, 13), (22050, 1024, 1024, 256, 64, 20),
+                                                  (44100, 2048, 2048, 512, 128, 20), (44100, 4096, 4096, 1024, 256, 40)])
+def test_edge_signals_every_frame_kernel(ss, oracle, sslib, sr, nfft, flen, hop, M, C):
+    """All-zero clip (zero_handling everywhere, functions.rs:66-71), full-scale square wave and an impulse train through each
+    frame-path kernel: MFCC and mfe."""
+    kw = dict(frame_length=flen / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+    p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M)
+    n = flen + 11 * hop + 2
+    zero = np.zeros(n, np.float32)
+    sq = np.where(np.arange(n) % 64 < 32, 1.0, -1.0).astype(np.float32)
+    imp = np.zeros(n, np.float32)
+    imp[::hop] = 1.0
+    mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+    # (the 256-point kernel transforms two frames at once: bins that cancel exactly in a packed real transform come out as
+    # rounding noise of the pair there, so the square wave -- exact zeros in most bands -- is left to the other kernels)
+    for x in (zero, imp) if nfft == 256 else (zero, sq, imp):
+        got = ss.mfcc(x, sr, **kw)
+        assert not sslib.ss_last_kernel_name().startswith(b"ss_front_generic")
+        want = oracle.mfcc(p, x)
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+        feat, en = ss.mfe(x, sr, **mkw)
+        wf, we = oracle.mfe(p, x)
+        assert _rel(feat, wf) <= RTOL and _rel(en, we) <= RTOL
+    feat, en = ss.mfe(zero, sr, **mkw)
+    assert np.all(feat == np.float32(1.1920929e-7)) and np.all(en == np.float32(1.1920929e-7))
+
+
+def test_256_kernel_pair_guard(ss, oracle, sslib):
+    """The two-frames-per-transform kernel must not let a loud frame's rounding noise into its silent partner: zero-padded
+    clips (all-zero frames next to speech: exact f32::EPSILON energies, as in the reference), digital silence followed by a
+    loud onset, and a 70 dB level step."""
+    import torch
+
+    sr, n = 8000, 8000
+    rng = np.random.default_rng(77)
+    x = np.zeros((6, n), np.float32)
+    x[0, :3000] = rng.standard_normal(3000) * 0.3                      # speech, then zero padding
+    x[1, 5000:] = rng.standard_normal(3000) * 0.3                      # silence, then an onset
+    x[2] = rng.standard_normal(n) * 1e-4
+    x[2, 4000:] = rng.standard_normal(4000) * 0.4                      # 72 dB step
+    x[3, 1234:1300] = 0.9                                              # a click in silence
+    x[4] = rng.standard_normal(n) * 0.1                                # ordinary clip (single-pass octs)
+    x[5, ::2] = 1e-3                                                   # quiet everywhere
+    p = oracle.make_params(sample_rate=sr, fft_points=256)
+    xd = torch.from_numpy(x).cuda()
+    got = ss.mfcc_batch(xd, sr, fft_length=256).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256x2<")
+    feat, en = ss.mfe_batch(xd, sr, fft_length=256)
+    feat, en = feat.cpu().numpy(), en.cpu().numpy()
+    eps = np.float32(1.1920929e-7)
+    for b in range(6):
+        want = oracle.mfcc(p, x[b])
+        assert np.abs(got[b] - want).max() <= 1e-4 * np.abs(want).max(), b
+        wf, we = oracle.mfe(p, x[b])
+        # per frame: each frame's mel energies against that frame's own scale
+        for t in range(wf.shape[0]):
+            assert np.abs(feat[b, t] - wf[t]).max() <= 1e-4 * max(np.abs(wf[t]).max(), eps), (b, t)
+        assert _rel(en[b], we) <= RTOL
+    assert np.all(feat[0, 40:] == eps) and np.all(en[0, 40:] == eps)   # frames wholly inside the zero padding
+
+
 def test_ragged_lengths_and_errors(ss, oracle):
     from speechsauce_amd import SpeechSauceError
 
