@@ -376,6 +376,24 @@ def test_edge_signals_every_frame_kernel(ss, oracle, sslib, sr, nfft, flen, hop,
     assert np.all(feat == np.float32(1.1920929e-7)) and np.all(en == np.float32(1.1920929e-7))
 
 
+@pytest.mark.parametrize("sr,nfft,hop,M", [(16000, 512, 256, 40), (16000, 1024, 512, 80), (16000, 2048, 512, 128), (44100, 4096, 1024, 256)])
+def test_edge_signals_every_mel_kernel(ss, oracle, sslib, sr, nfft, hop, M):
+    """All-zero clip (no zero handling on this path: exact zeros), full-scale square wave and an impulse train through each
+    mel-spectrogram kernel."""
+    kw = dict(frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=nfft)
+    p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M)
+    n = nfft + 12 * hop
+    sq = np.where(np.arange(n) % 64 < 32, 1.0, -1.0).astype(np.float32)
+    imp = np.zeros(n, np.float32)
+    imp[::hop] = 1.0
+    got = ss.mel_spectrogram(np.zeros(n, np.float32), sr, **kw)
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mel_c") and np.all(got == 0.0)
+    for x in (sq, imp):
+        got = ss.mel_spectrogram(x, sr, **kw)
+        want = oracle.mel_spectrogram(p, x)
+        assert got.shape == want.shape and _rel(got, want) <= RTOL
+
+
 def test_256_kernel_pair_guard(ss, oracle, sslib):
     """The two-frames-per-transform kernel must not let a loud frame's rounding noise into its silent partner: zero-padded
     clips (all-zero frames next to speech: exact f32::EPSILON energies, as in the reference), digital silence followed by a
