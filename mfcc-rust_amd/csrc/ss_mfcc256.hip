@@ -188,9 +188,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
     }
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
-    float4 tw2r[8];  // the 15 pass-2 twiddles stay in registers
+    constexpr bool RES_TW = NE <= 10;  // the 15 pass-2 twiddles stay in registers when the prefetch leaves room for them
+    float4 tw2r[RES_TW ? 8 : 1];
+    if (RES_TW) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) tw2r[p] = s_tw2[p * 16 + j];
+        for (int p = 0; p < 8; ++p) tw2r[p] = s_tw2[p * 16 + j];
+    }
     float wn[WIN ? NE : 1];
     if (WIN) {
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         wave_order_x();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const float4 w2 = tw2r[p];
+            const float4 w2 = RES_TW ? tw2r[RES_TW ? p : 0] : s_tw2[p * 16 + j];
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
         }
