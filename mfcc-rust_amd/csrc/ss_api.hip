@@ -163,8 +163,8 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     a.out0 = out0;
     a.out1 = out1;
     ss::LaunchInfo info{};
-    // fft_points = 512 MFCC: the specialised wave-private kernel when its layout assumptions hold
-    // (8-byte aligned frame starts, even frame length, rectangular window, no fused pre-emphasis).
+    // fft_points = 512 MFCC: the specialised wave-private kernel (its builds: default bank / run-time bank, window,
+    // pre-emphasis, mfe and power outputs, librosa variants)
     static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
     // the mfe-output build of that kernel exists for the default bank shape only
     const bool mfe_shape = a.flen == 320 && a.spectrum_exponent != 2 && cfg->fast.q4[0] == 4 && cfg->fast.q4[1] == 2 &&
@@ -175,18 +175,20 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool centre = a.frame_mode == ss::FRAME_CENTER;
     const bool lib_variant = centre || cfg->fast.fullp;
     const bool lib_ok = out_kind == ss::OUT_MFCC && a.preemph == 0.0f && (!centre || a.flen % 4 == 0);
+    // Sample pairs load as 8-byte words at dword alignment (gfx950 global loads need no more: tools/unaligned_probe.py), and an
+    // odd frame length ends in a half pair that one lane loads as a single float -- so hops, leading dimensions, base offsets
+    // and frame lengths of either parity reach the dedicated kernels.
     const bool fast_ok = !force_generic && cfg->fast.ok &&
                          (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape) || (out_kind == ss::OUT_POWER && mfe_shape && !front)) &&
-                         (lib_variant ? lib_ok : (!front || mfe_shape)) && (a.frame_mode == ss::FRAME_NORMAL || centre) &&
-                         (a.flen % 2 == 0) && (a.step % 2 == 0) &&
-                         (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0);
+                         (lib_variant ? lib_ok : (!front || mfe_shape)) && (a.frame_mode == ss::FRAME_NORMAL || centre);
     // SS_MFCC512_VARIANT=mfma selects the block-sparse f32-MFMA mel+DCT build (ss_mfcc512_mfma.hip) for A/B runs
     static const char *variant = std::getenv("SS_MFCC512_VARIANT");
     const bool want_mfma = variant && std::strcmp(variant, "mfma") == 0;
     const bool fits32 = static_cast<unsigned long long>(batch) * T < 0xffffffffull;
     static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only: per-wave realtime stamps of ONE launch
     static bool dbg_done = false;
-    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC && !front && !lib_variant) {
+    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC && !front && !lib_variant && (a.flen % 2 == 0) &&
+        (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {  // the A/B build keeps the old layout assumptions
         ss::Fast512MArgs f{};
         f.x = d_x;
         f.ld = ld;
@@ -273,11 +275,11 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    // fft_points = 512 MFCC / mfe with more than 48 filters (ss_mfcc512w.hip): layout assumptions of the headline kernel,
-    // optional frame window, no fused pre-emphasis
+    // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra (ss_mfcc512w.hip): optional frame window, no fused
+    // pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
         (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) &&
-        a.preemph == 0.0f && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        a.preemph == 0.0f) {
         ss::Mfcc256Args f{};
         f.center = centre;
         f.pad_reflect = a.pad_reflect;
@@ -340,12 +342,10 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    // fft_points = 2048 / 1024 MFCC / mfe: two frames per wave (ss_mfcc2048.hip, ss_mfcc1024.hip), same layout assumptions,
-    // optional frame window
+    // fft_points = 2048 / 1024 MFCC / mfe: two frames per wave (ss_mfcc2048.hip, ss_mfcc1024.hip), optional frame window
     // (both have librosa-compatible builds: centred frames with flen % 4 == 0, banks up to fs/2)
     if (!force_generic && (cfg->mfcc2048.ok || cfg->mfcc1024.ok) && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
-        (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) && a.preemph == 0.0f &&
-        (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) && a.preemph == 0.0f) {
         ss::Mfcc2048Args f{};
         f.x = d_x;
         f.ld = ld;
@@ -378,10 +378,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    // fft_points = 4096 MFCC (256 filters): the one-frame-per-wave kernel under the same layout assumptions
+    // fft_points = 4096 MFCC / mfe (even filter count up to 256): the one-frame-per-wave kernel
     if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL &&
-        a.preemph == 0.0f && (a.window == nullptr || a.spectrum_exponent != 2) && (a.flen % 2 == 0) && (a.step % 2 == 0) && (ld % 2 == 0) &&
-        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+        a.preemph == 0.0f && (a.window == nullptr || a.spectrum_exponent != 2)) {
         ss::Mfcc4096Args f{};
         f.x = d_x;
         f.ld = ld;

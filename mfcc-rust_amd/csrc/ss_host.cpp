@@ -361,7 +361,9 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
         for (size_t c = 0; c < Cc; ++c)
             for (size_t m = 0; m < 20; ++m) f.tab[L::kCosH + c * 20 + m] = t.dct[c * M + m];
     if (!t.window_mfcc.empty()) {  // optional frame window (mfcc_window switch), read as sample pairs by the kernel
-        f.win_floats = static_cast<int32_t>((t.window_mfcc.size() + 3) / 4 * 4);
+        // all 256 pairs a 16-input build may touch (zero beyond flen): a shorter table would let the padded inputs multiply
+        // whatever follows it in LDS -- 0 x NaN-patterned table words of an earlier kernel is NaN
+        f.win_floats = 512;
         const size_t base = f.tab.size();
         f.tab.resize(base + static_cast<size_t>(f.win_floats), 0.0f);
         for (size_t i = 0; i < t.window_mfcc.size(); ++i) f.tab[base + i] = t.window_mfcc[i];

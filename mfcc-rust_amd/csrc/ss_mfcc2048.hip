@@ -132,6 +132,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
     const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2;
     // valid sample pairs of this lane: n = j + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
     const int e_hi = min(32, max(0, (static_cast<int>(a.flen) / 2 - j + 31) >> 5));
+    const int half_pairs = static_cast<int>(a.flen) / 2;
+    const bool odd_tail = (a.flen & 1) != 0;
 
     unsigned unit = u_lo + wave;
     while (unit < u_hi) {
@@ -157,6 +159,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
             for (int e = 0; e < 32; ++e) {
                 float2 s = make_float2(0.f, 0.f);
                 if (e < e_hi) s = src[32 * e];
+                // odd frame length: the last sample is the first half of a pair (its partner is zero padding)
+                if (odd_tail && j + 32 * e == half_pairs) s = make_float2(xc[s0 + 2 * half_pairs], 0.f);
                 v[e] = s;
             }
         } else {

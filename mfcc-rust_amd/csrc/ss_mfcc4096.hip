@@ -169,7 +169,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
             if (EXACT) v[e] = src[64 * e];
-            else v[e] = 2 * (lane + 64 * e) < static_cast<int>(a.flen) ? src[64 * e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
+            else {  // zero pad, processing.rs:147-156; an odd frame length ends in a half pair
+                const int rem = static_cast<int>(a.flen) - 2 * (lane + 64 * e);
+                v[e] = rem >= 2 ? src[64 * e] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[128 * e] : 0.f, 0.f);
+            }
         }
         if (WIN) {
             // optional frame window (mfcc_window switch): sample pairs from the copy in LDS
@@ -584,7 +587,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
     };
     const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096;
     if (a.window) {  // windowed builds: MFCC and mfe, magnitude spectrum
-        if (pow2 || (a.flen & 1)) return hipErrorInvalidValue;
+        if (pow2) return hipErrorInvalidValue;
         if (a.out_mfe) return exact ? go(ss_mfcc_c2048<true, false, WAVES, true, true>, "ss_mfcc_c2048<exact,mfe,win>") : go(ss_mfcc_c2048<false, false, WAVES, true, true>, "ss_mfcc_c2048<mfe,win>");
         return exact ? go(ss_mfcc_c2048<true, false, WAVES, false, true>, "ss_mfcc_c2048<exact,win>") : go(ss_mfcc_c2048<false, false, WAVES, false, true>, "ss_mfcc_c2048<win>");
     }

@@ -151,8 +151,13 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int n = j + 16 * e;
-        if (EXACT) vin[e] = src[n];
-        else vin[e] = 2 * n < static_cast<int>(a.flen) ? src[n] : make_float2(0.f, 0.f);
+        if (EXACT) {
+            vin[e] = src[n];
+        } else {
+            // zero pad beyond flen (processing.rs:147-156); an odd frame length ends in a half pair
+            const int rem = static_cast<int>(a.flen) - 2 * n;
+            vin[e] = rem >= 2 ? src[n] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[2 * n] : 0.f, 0.f);
+        }
         if (PRE) {
             // pre-emphasis taps x[(i - shift) mod L] of the sample pair (processing.rs:31-53, np.roll semantics over the clip)
             const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;

@@ -122,7 +122,11 @@ __device__ __forceinline__ unsigned load_quad_w(const Mfcc256Args &a, unsigned q
     if (!a.center || __all(s0 >= 0 && s0 + static_cast<int>(a.flen) <= ns)) {
         const float2 *src = reinterpret_cast<const float2 *>(xc + s0) + j;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) vin[e] = 2 * (j + 16 * e) < static_cast<int>(a.flen) ? src[16 * e] : make_float2(0.f, 0.f);
+        for (int e = 0; e < NE; ++e) {
+            // zero pad beyond flen; an odd frame length ends in a half pair
+            const int rem = static_cast<int>(a.flen) - 2 * (j + 16 * e);
+            vin[e] = rem >= 2 ? src[16 * e] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[32 * e] : 0.f, 0.f);
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {

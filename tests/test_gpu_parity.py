@@ -394,6 +394,40 @@ def test_edge_signals_every_mel_kernel(ss, oracle, sslib, sr, nfft, hop, M):
         assert got.shape == want.shape and _rel(got, want) <= RTOL
 
 
+@pytest.mark.parametrize("sr,nfft,flen,step,M,C,kernel", [
+    (16000, 512, 320, 161, 40, 13, b"ss_mfcc_c256<"), (22050, 512, 441, 221, 40, 13, b"ss_mfcc_c256<"), (16000, 512, 399, 160, 80, 13, b"ss_mfcc_c256w<"),
+    (22050, 1024, 883, 221, 64, 20, b"ss_mfcc_c512"), (44100, 2048, 1765, 441, 128, 20, b"ss_mfcc_c1024"), (44100, 4096, 4095, 1023, 256, 40, b"ss_mfcc_c2048"),
+    (44100, 4096, 4096, 1025, 128, 20, b"ss_mfcc_c2048")])
+def test_odd_lengths_hops_and_offsets(ss, oracle, sslib, sr, nfft, flen, step, M, C, kernel):
+    """Odd frame lengths (22.05 kHz x 20 ms = 441 samples), odd hops, odd leading dimensions and odd base offsets reach the
+    dedicated frame kernels: sample pairs load at dword alignment, an odd frame ends in a half pair.  The last frame of the
+    last clip ends exactly at the end of the buffer (no pair may read past it)."""
+    import torch
+
+    T = 7
+    n = flen + (T - 1) * step  # the last frame ends with the clip
+    x = _signal(51, (3, n + 1))
+    xd = torch.from_numpy(x).cuda()[:, 1:]  # odd base offset; the leading dimension n + 1 has the other parity of n
+    kw = dict(frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+    p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M)
+    # (the headline kernel's window builds exist for the default frame shape only)
+    for sw in ({},) if kernel == b"ss_mfcc_c256<" else ({}, dict(mfcc_window="hann")):
+        q = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(kernel), sslib.ss_last_kernel_name()
+        assert got.shape[1] == oracle.num_frames(q, n)
+        for b in range(3):
+            assert _rel(got[b], oracle.mfcc(q, x[b, 1:])) <= RTOL, (sw, b)
+    mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+    feat, en = ss.mfe_batch(xd, sr, **mkw)
+    wf, we = oracle.mfe(p, x[2, 1:])
+    assert _rel(feat[2].cpu().numpy(), wf) <= RTOL and _rel(en[2].cpu().numpy(), we) <= RTOL
+    # a contiguous exact-size tensor: the last pair of the last frame of the last clip is the end of the allocation
+    xe = torch.from_numpy(np.ascontiguousarray(x[:, 1:])).cuda()
+    got = ss.mfcc_batch(xe, sr, **kw).cpu().numpy()
+    assert _rel(got[2], oracle.mfcc(p, x[2, 1:])) <= RTOL
+
+
 def test_256_kernel_pair_guard(ss, oracle, sslib):
     """The two-frames-per-transform kernel must not let a loud frame's rounding noise into its silent partner: zero-padded
     clips (all-zero frames next to speech: exact f32::EPSILON energies, as in the reference), digital silence followed by a
