@@ -458,8 +458,8 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     // fft_points = 2048 mel spectrogram: the wave-private kernel when its layout assumptions hold
     static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
     const bool want_stft = out_kind == ss::OUT_STFT;  // the stft builds do not use the bank (stft_only table blocks)
-    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel2048.ok || (want_stft && cfg->mel2048.stft_only)) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
-        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {
+    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel2048.ok || (want_stft && cfg->mel2048.stft_only)) &&
+        static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
         ss::Mel2048Args m{};
         m.x = d_x;
         m.ld = ld;
@@ -482,8 +482,8 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         return SS_OK;
     }
     // fft_points = 512 mel spectrogram: four rows per wave (ss_mel512.hip), same layout assumptions
-    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel512.ok || (want_stft && cfg->mel512.stft_only)) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
-        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0) && static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
+    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel512.ok || (want_stft && cfg->mel512.stft_only)) &&
+        static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
         ss::Mel512Args m{};
         m.x = d_x;
         m.ld = ld;
@@ -509,8 +509,8 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     // fft_points = 1024 / 4096 mel spectrogram: two rows / one row per wave (ss_mel_c512 in ss_mfcc1024.hip, ss_mel_c2048 in
     // ss_mfcc4096.hip), same layout assumptions
     const bool use1024 = cfg->mel1024.ok || (want_stft && cfg->mel1024.stft_only), use4096 = cfg->mel4096.ok || (want_stft && cfg->mel4096.stft_only);
-    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (use1024 || use4096) && (a.hop % 2 == 0) && (ld % 2 == 0) && (a.n_samples % 2 == 0) &&
-        (reinterpret_cast<uintptr_t>(d_x) % 8 == 0) && static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
+    if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (use1024 || use4096) &&
+        static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
         ss::Mel2048Args m{};
         m.x = d_x;
         m.ld = ld;

@@ -122,14 +122,22 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
             // (the address of a masked load may lie outside the clip; it is never dereferenced)
             const int base = start + 2 * j;
             const int n = static_cast<int>(a.n_samples);
-            const int e_lo = base >= 0 ? 0 : (31 - base) >> 5;
-            int e_hi = base >= n ? 0 : min(16, (n - base + 31) >> 5);
-            if (!active) e_hi = 0;
+            if (((start | n) & 1) == 0) {
+                const int e_lo = base >= 0 ? 0 : (31 - base) >> 5;
+                int e_hi = base >= n ? 0 : min(16, (n - base + 31) >> 5);
+                if (!active) e_hi = 0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float2 s = make_float2(0.f, 0.f);
-                if (e >= e_lo && e < e_hi) s = src[16 * e];
-                vv[e] = s;
+                for (int e = 0; e < 16; ++e) {
+                    float2 s = make_float2(0.f, 0.f);
+                    if (e >= e_lo && e < e_hi) s = src[16 * e];
+                    vv[e] = s;
+                }
+            } else {  // odd hop or clip length: a pair may straddle the clip edge, bounds per sample
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int p0 = base + 32 * e;
+                    vv[e] = make_float2(active && p0 >= 0 && p0 < n ? xc[p0] : 0.f, active && p0 + 1 >= 0 && p0 + 1 < n ? xc[p0 + 1] : 0.f);
+                }
             }
         }
     };

@@ -443,14 +443,23 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
             // (the address of a masked load may lie outside the clip; it is never dereferenced)
             const int base = start + 2 * lane;
             const int n = static_cast<int>(a.n_samples);
-            const int e_lo = base >= 0 ? 0 : (127 - base) >> 7;
-            int e_hi = base >= n ? 0 : min(32, (n - base + 127) >> 7);
-            if (r >= Rreal) e_hi = 0;
+            if (((start | n) & 1) == 0) {
+                const int e_lo = base >= 0 ? 0 : (127 - base) >> 7;
+                int e_hi = base >= n ? 0 : min(32, (n - base + 127) >> 7);
+                if (r >= Rreal) e_hi = 0;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                float2 s = make_float2(0.f, 0.f);
-                if (e >= e_lo && e < e_hi) s = src[64 * e];
-                v[e] = s;
+                for (int e = 0; e < 32; ++e) {
+                    float2 s = make_float2(0.f, 0.f);
+                    if (e >= e_lo && e < e_hi) s = src[64 * e];
+                    v[e] = s;
+                }
+            } else {  // odd hop or clip length: a pair may straddle the clip edge, bounds per sample
+                const bool act = r < Rreal;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const int p0 = base + 128 * e;
+                    v[e] = make_float2(act && p0 >= 0 && p0 < n ? xc[p0] : 0.f, act && p0 + 1 >= 0 && p0 + 1 < n ? xc[p0 + 1] : 0.f);
+                }
             }
         }
 #pragma unroll

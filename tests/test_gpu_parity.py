@@ -428,6 +428,26 @@ def test_odd_lengths_hops_and_offsets(ss, oracle, sslib, sr, nfft, flen, step, M
     assert _rel(got[2], oracle.mfcc(p, x[2, 1:])) <= RTOL
 
 
+@pytest.mark.parametrize("sr,nfft,hop,M,kernel", [(22050, 512, 221, 40, b"ss_mel_c256"), (22050, 1024, 441, 80, b"ss_mel_c512"),
+                                                  (22050, 2048, 441, 128, b"ss_mel_c1024"), (44100, 4096, 1103, 128, b"ss_mel_c2048")])
+def test_mel_odd_hops_lengths_and_offsets(ss, oracle, sslib, sr, nfft, hop, M, kernel):
+    """Odd chunk sizes (22.05 kHz x 20 ms = 441), odd clip lengths, odd leading dimensions and odd base offsets on the
+    mel-spectrogram kernels: pairs load at dword alignment, pairs that straddle a clip edge are bounded per sample."""
+    import torch
+
+    kw = dict(frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=nfft)
+    p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M)
+    for n in (nfft + 9 * hop + 1, nfft + 7 * hop + 2, 3 * hop + 1):
+        x = _signal(53, (4, n + 1))
+        xd = torch.from_numpy(x).cuda()[:, 1:]
+        got = ss.mel_spectrogram(xd, sr, **kw).cpu().numpy()
+        assert sslib.ss_last_kernel_name() == kernel, sslib.ss_last_kernel_name()
+        want = oracle.mel_spectrogram(p, x[:, 1:])
+        assert got.shape == want.shape
+        for b in range(4):
+            assert _rel(got[b], want[b]) <= RTOL, (n, b)
+
+
 def test_256_kernel_pair_guard(ss, oracle, sslib):
     """The two-frames-per-transform kernel must not let a loud frame's rounding noise into its silent partner: zero-padded
     clips (all-zero frames next to speech: exact f32::EPSILON energies, as in the reference), digital silence followed by a
