@@ -23,6 +23,8 @@ struct ss_config {
     float *d_window_stft = nullptr;
     float2 *d_tw_c = nullptr;
     float2 *d_tw_n = nullptr;
+    float2 *d_blu_c = nullptr;  // chirp-z tables (fft_points not a power of two)
+    float2 *d_blu_b = nullptr;
     int32_t *d_f_start = nullptr, *d_f_len = nullptr, *d_f_off = nullptr;
     float *d_f_w = nullptr;
     float *d_dct = nullptr;
@@ -105,6 +107,9 @@ void fill_common(const ss_config *cfg, ss::FrontArgs &a)
     const ss::HostTables &h = cfg->host;
     a.tw_c = cfg->d_tw_c;
     a.tw_n = cfg->d_tw_n;
+    a.blu_c = cfg->d_blu_c;
+    a.blu_b = cfg->d_blu_b;
+    a.blu_n = h.d.bluestein ? h.params.fft_points : 0u;
     a.f_start = cfg->d_f_start;
     a.f_len = cfg->d_f_len;
     a.f_off = cfg->d_f_off;
@@ -597,6 +602,10 @@ int ss_config_create(const ss_params *p, ss_config **out)
     SS_UP(d_window_stft, h.window_stft);
     SS_UP(d_tw_c, h.tw_c);
     SS_UP(d_tw_n, h.tw_n);
+    if (h.d.bluestein) {
+        SS_UP(d_blu_c, h.blu_c);
+        SS_UP(d_blu_b, h.blu_b);
+    }
     SS_UP(d_f_start, h.bank.start);
     SS_UP(d_f_len, h.bank.len);
     SS_UP(d_f_off, h.bank.off);
@@ -638,7 +647,7 @@ int ss_config_create(const ss_params *p, ss_config **out)
 void ss_config_destroy(ss_config *cfg)
 {
     if (!cfg) return;
-    void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_f_start,
+    void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_blu_c, cfg->d_blu_b, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
                     cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mfcc512w_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
     for (void *p : ptrs)

@@ -37,6 +37,10 @@ struct FrontArgs {
     // FFT tables
     const float2 *tw_c;  // exp(-2 pi i t / C), t < C
     const float2 *tw_n;  // exp(-2 pi i k / N), k <= C/2
+    // chirp-z mode (fft_points not a power of two): the FFT is a complex one of C = blu_len points
+    const float2 *blu_c;  // exp(-i pi n^2 / N), n < N
+    const float2 *blu_b;  // FFT_C of the wrapped conjugate chirp
+    uint32_t blu_n;       // N = fft_points (0: packed power-of-two mode)
     // sparse mel bank
     const int32_t *f_start, *f_len, *f_off;
     const float *f_w;
@@ -60,7 +64,8 @@ struct LaunchInfo {
     size_t lds_bytes;
 };
 
-// Generic front-end (any power-of-two fft_points in [32, 4096]).
+// Generic front-end (any power-of-two fft_points in [32, 4096]; with a.blu_n != 0 the chirp-z build for other lengths, log2c then
+// being the length of its complex FFT).
 hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info);
 // Element-wise pre-emphasis (processing.rs:31-53).
 hipError_t launch_preemphasis(const float *x, float *y, size_t n, size_t shift, float cof, hipStream_t stream);

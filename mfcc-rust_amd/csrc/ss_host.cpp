@@ -36,7 +36,18 @@ int derive(const ss_params &p, Derived &d)
     d.n_fft = p.fft_points;
     d.n_bins = p.fft_points / 2 + 1;
     d.log2c = 0;
-    while ((2u << d.log2c) < p.fft_points) ++d.log2c;
+    d.bluestein = !is_pow2(p.fft_points);
+    if (d.bluestein) {
+        // chirp-z: circular convolution long enough for a[n], n < N, against the chirp at offsets -(N-1) .. N/2
+        d.blu_len = 16;
+        d.log2c = 4;
+        while (d.blu_len < p.fft_points + p.fft_points / 2 + 1) {
+            d.blu_len *= 2;
+            ++d.log2c;
+        }
+    } else {
+        while ((2u << d.log2c) < p.fft_points) ++d.log2c;
+    }
     // config.rs:154: frame_size = (frame_length * sample_rate as f32) as usize  (truncation)
     const float hs = p.frame_length * static_cast<float>(p.sample_rate);
     const uint32_t hop = hs >= 1.0f ? static_cast<uint32_t>(hs) : 0u;
@@ -57,8 +68,10 @@ int validate(const ss_params &p)
 {
     if (p.struct_size != sizeof(ss_params)) return fail(SS_ERR_ARG, "ss_params.struct_size mismatch (ABI)");
     if (p.sample_rate == 0) return fail(SS_ERR_BAD_CONFIG, "sample_rate must be > 0");
-    if (p.fft_points < 32 || p.fft_points > 4096 || !is_pow2(p.fft_points))
-        return fail(SS_ERR_UNSUPPORTED, "fft_points must be a power of two in [32, 4096]");
+    // powers of two in [32, 4096]; any other length from 16 up whose chirp-z transform fits a 2048-point complex FFT
+    // (fft_points + fft_points/2 < 2048, i.e. up to 1365: 400, 441, 800, 882, 1000, 1103, 1200 ...)
+    if (is_pow2(p.fft_points) ? (p.fft_points < 32 || p.fft_points > 4096) : (p.fft_points < 16 || p.fft_points + p.fft_points / 2 + 1 > 2048))
+        return fail(SS_ERR_UNSUPPORTED, "fft_points must be a power of two in [32, 4096] or any length in [16, 1365]");
     if (p.num_filters == 0 || p.num_filters > 1024) return fail(SS_ERR_BAD_CONFIG, "num_filters out of range");
     // feature.rs:133 slice_move(s![.., ..num_cepstral]) panics for num_cepstral > num_filters
     if (p.num_cepstral == 0 || p.num_cepstral > p.num_filters)
@@ -266,7 +279,63 @@ int build_tables(const ss_params &p, HostTables &t)
     vorbis_window(p.fft_points, t.window_stft.data());
 
     const double pi = 3.14159265358979323846;
-    const size_t C = p.fft_points / 2, N = p.fft_points;
+    const size_t C = t.d.bluestein ? t.d.blu_len : p.fft_points / 2, N = p.fft_points;
+    t.blu_c.clear();
+    t.blu_b.clear();
+    if (t.d.bluestein) {
+        // X[k] = c[k] sum_n (x[n] c[n]) conj(c[k - n]),  c[n] = exp(-i pi n^2 / N); n^2 is reduced mod 2N in integers
+        const size_t L = t.d.blu_len;
+        auto chirp = [&](long long m, double *re, double *im) {
+            const unsigned long long q = static_cast<unsigned long long>(m * m) % (2ull * N);
+            const double ang = -pi * static_cast<double>(q) / static_cast<double>(N);
+            *re = std::cos(ang);
+            *im = std::sin(ang);
+        };
+        t.blu_c.resize(2 * N);
+        for (size_t n = 0; n < N; ++n) {
+            double re, im;
+            chirp(static_cast<long long>(n), &re, &im);
+            t.blu_c[2 * n] = static_cast<float>(re);
+            t.blu_c[2 * n + 1] = static_cast<float>(im);
+        }
+        // b[m] = conj c[m] at offsets -(N-1) .. N/2 (negative ones wrapped to L + m), transformed once in f64
+        std::vector<double> br(L, 0.0), bi(L, 0.0);
+        for (long long m = -static_cast<long long>(N) + 1; m <= static_cast<long long>(N / 2); ++m) {
+            double re, im;
+            chirp(m, &re, &im);
+            const size_t at = m >= 0 ? static_cast<size_t>(m) : L - static_cast<size_t>(-m);
+            br[at] = re;
+            bi[at] = -im;
+        }
+        // iterative radix-2 FFT (L is a power of two)
+        for (size_t i = 1, jr = 0; i < L; ++i) {
+            size_t bit = L >> 1;
+            for (; jr & bit; bit >>= 1) jr ^= bit;
+            jr ^= bit;
+            if (i < jr) {
+                std::swap(br[i], br[jr]);
+                std::swap(bi[i], bi[jr]);
+            }
+        }
+        for (size_t len = 2; len <= L; len <<= 1) {
+            const double ang = -2.0 * pi / static_cast<double>(len);
+            for (size_t i = 0; i < L; i += len)
+                for (size_t k = 0; k < len / 2; ++k) {
+                    const double wr = std::cos(ang * static_cast<double>(k)), wi = std::sin(ang * static_cast<double>(k));
+                    const size_t u = i + k, v = i + k + len / 2;
+                    const double xr = br[v] * wr - bi[v] * wi, xi = br[v] * wi + bi[v] * wr;
+                    br[v] = br[u] - xr;
+                    bi[v] = bi[u] - xi;
+                    br[u] += xr;
+                    bi[u] += xi;
+                }
+        }
+        t.blu_b.resize(2 * L);
+        for (size_t k = 0; k < L; ++k) {
+            t.blu_b[2 * k] = static_cast<float>(br[k]);
+            t.blu_b[2 * k + 1] = static_cast<float>(bi[k]);
+        }
+    }
     t.tw_c.resize(2 * C);
     for (size_t i = 0; i < C; ++i) {
         const double a = -2.0 * pi * static_cast<double>(i) / static_cast<double>(C);

@@ -21,6 +21,10 @@ struct Derived {
     uint32_t hop = 0, n_pad = 0;
     float wnorm = 0.f;
     uint32_t n_fft = 0, n_bins = 0, log2c = 0;  // c = n_fft/2 complex points
+    // fft_points that are not a power of two: chirp-z (Bluestein) transform through a complex FFT of blu_len = 2^log2c
+    // points, blu_len >= n_fft + n_fft/2 (bins 0..n_fft/2 of an n_fft-sample frame)
+    bool bluestein = false;
+    uint32_t blu_len = 0;
 };
 
 // Sparse triangular bank: filter m covers bins [start[m], start[m]+len[m]) with weights
@@ -43,6 +47,8 @@ struct HostTables {
     std::vector<float> tw_c;          // interleaved re,im: exp(-2*pi*i*t/C), t in [0,C)
     std::vector<float> tw_n;          // interleaved re,im: exp(-2*pi*i*k/N), k in [0,C/2]
     std::vector<float> dct;           // [num_cepstral x M] cos(pi*k*(2m+1)/(2M))
+    // chirp-z tables (Derived::bluestein): c[n] = exp(-i pi n^2 / N), n < N; FFT_L of the wrapped conjugate chirp
+    std::vector<float> blu_c, blu_b;
 };
 
 void set_error(const std::string &msg);

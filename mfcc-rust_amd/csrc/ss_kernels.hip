@@ -16,6 +16,12 @@
 //   * HBM traffic: the clip samples once (neighbouring frames re-read them through L1/L2) and
 //     the features once.
 //
+//   * fft_points that are not a power of two (the reference takes any length) run the chirp-z (Bluestein) build BLU of the
+//     same kernel: a[n] = x[n] c[n], c[n] = exp(-i pi n^2 / N); A = FFT_L(a) with the complex L-point transform above
+//     (L >= N + N/2 a power of two); A .* FFT_L(conj c) (host table); the inverse transform as conj FFT_L(conj .);
+//     X[k] = c[k] (a * conj c)[k] / L for the N/2 + 1 bins.  Two L-point transforms per frame instead of one N/2-point one:
+//     a completeness path, not a fast one.
+//
 // Reference semantics (file:line relative to the reference checkout) are cited at each stage.
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -169,6 +175,50 @@ __device__ __forceinline__ float untangle_row(const float2 *zbuf, float *prow, f
     return esum;
 }
 
+// Chirp-z epilogue: zbuf holds FFT_L(conj(A .* B)) in natural order; X[k] = c[k] conj(zbuf[k]) / L for k < F.  Same scaling,
+// magnitude / power and stft output as untangle_row.
+template <int LOG2C>
+__device__ __forceinline__ float blu_row(const float2 *zbuf, float *prow, float2 *stft_row, int j, const FrontArgs &a, bool mel_mode,
+                                         bool active, int F)
+{
+    using G = Geo<LOG2C>;
+    const float inv_l = 1.0f / static_cast<float>(G::C);
+    float esum = 0.0f;
+    for (int k = j; k < F; k += G::TPF) {
+        const float2 w = zbuf[phys(k)];
+        const float2 c = a.blu_c[k];
+        float2 xa = cmul(c, make_float2(w.x * inv_l, -w.y * inv_l));
+        float pa;
+        if (mel_mode) {
+            xa.x *= a.scale;
+            xa.y *= a.scale;
+            pa = xa.x * xa.x + xa.y * xa.y;
+            if (stft_row && active) stft_row[k] = xa;
+        } else {
+            const float ma = __builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y);
+            pa = a.spectrum_exponent == 2 ? a.scale * (ma * ma) : a.scale * ma;
+        }
+        prow[k] = pa;
+        esum += pa;
+    }
+    return esum;
+}
+
+// After the forward transform of the chirped frame: conj(A[k] B[k]) back into the pass-1 registers (v[e] = z[j + e TPF]) and
+// the second transform.  The first pass of frame_fft stores only after a frame-wide sync, so the reads here are safe.
+template <int LOG2C>
+__device__ __forceinline__ void blu_convolve(float2 *zbuf, int j, const FrontArgs &a, float2 (&v)[16])
+{
+    using G = Geo<LOG2C>;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = j + e * G::TPF;
+        const float2 p = cmul(zbuf[phys(k)], a.blu_b[k]);
+        v[e] = make_float2(p.x, -p.y);
+    }
+    frame_fft<LOG2C>(zbuf, j, a.tw_c, v);
+}
+
 // Banded mel reduction of one magnitude row (feature.rs:229 / :173 restricted to the non-zero taps).
 __device__ __forceinline__ float mel_dot(const float *prow, const FrontArgs &a, int m)
 {
@@ -179,7 +229,7 @@ __device__ __forceinline__ float mel_dot(const float *prow, const FrontArgs &a, 
     return s;
 }
 
-template <int LOG2C>
+template <int LOG2C, bool BLU>
 __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
 {
     using G = Geo<LOG2C>;
@@ -201,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
     float *tile = reinterpret_cast<float *>(smem_raw + slot_bytes * G::FPB);
 
     const bool mel_mode = a.out_kind == OUT_MEL || a.out_kind == OUT_STFT;
+    const int F = BLU ? static_cast<int>(a.blu_n / 2 + 1) : G::F;  // bins per row
 
     if (!mel_mode) {
         // ---------------- MFCC / MFE / power-spectrum path: flat list of B*T frames ----------------
@@ -216,52 +267,62 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
             // stack_frames (processing.rs:65-129, contract framing) + zero pad to N (:147-156)
             const unsigned base = a.frame_mode == FRAME_NORMAL ? t * a.step : 0u;
             const unsigned lim = a.frame_mode == FRAME_ZERO ? 0u : (a.frame_mode == FRAME_FIRST ? (a.flen & ~1u) : a.flen);
-            float2 v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned n = static_cast<unsigned>(j + e * G::TPF);
-                float s[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned i = 2 * n + h;
-                    float val = 0.0f;
-                    if (active && i < lim) {
-                        unsigned idx = base + i;
-                        bool inside = true;
-                        if (a.frame_mode == FRAME_CENTER) {
-                            // librosa center=True: the frame is centred on t*step; outside the clip np.pad 'reflect'
-                            // (mirror without repeating the edge sample) or zeros
-                            long long pos = static_cast<long long>(t) * a.step + i - a.flen / 2;
-                            const long long ns = a.n_samples;
-                            if (pos < 0 || pos >= ns) {
-                                if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
-                                else inside = false;
-                            }
-                            idx = static_cast<unsigned>(pos);
+            // sample i of the frame after framing, fused pre-emphasis and the optional window (zero beyond the frame)
+            auto sample = [&](unsigned i) -> float {
+                float val = 0.0f;
+                if (active && i < lim) {
+                    unsigned idx = base + i;
+                    bool inside = true;
+                    if (a.frame_mode == FRAME_CENTER) {
+                        // librosa center=True: the frame is centred on t*step; outside the clip np.pad 'reflect'
+                        // (mirror without repeating the edge sample) or zeros
+                        long long pos = static_cast<long long>(t) * a.step + i - a.flen / 2;
+                        const long long ns = a.n_samples;
+                        if (pos < 0 || pos >= ns) {
+                            if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+                            else inside = false;
                         }
-                        if (inside) {
+                        idx = static_cast<unsigned>(pos);
+                    }
+                    if (inside) {
                         val = xc[idx];
                         if (a.preemph != 0.0f) {  // processing.rs:31-53 fused
                             const unsigned sh = a.preemph_shift % a.n_samples;
                             const unsigned jdx = idx >= sh ? idx - sh : idx + a.n_samples - sh;
                             val -= a.preemph * xc[jdx];
                         }
-                        }
-                        if (a.window) val *= a.window[i];
                     }
-                    s[h] = val;
+                    if (a.window) val *= a.window[i];
                 }
-                v[e] = make_float2(s[0], s[1]);
+                return val;
+            };
+            float2 v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned n = static_cast<unsigned>(j + e * G::TPF);
+                if (BLU) {  // chirp-z: one real sample per complex point, times the chirp
+                    const float xv = sample(n);
+                    const float2 c = n < a.blu_n ? a.blu_c[n] : make_float2(0.f, 0.f);
+                    v[e] = make_float2(xv * c.x, xv * c.y);
+                } else {
+                    v[e] = make_float2(sample(2 * n), sample(2 * n + 1));
+                }
             }
             frame_fft<LOG2C>(zbuf, j, a.tw_c, v);
-            const float part = untangle_row<LOG2C>(zbuf, prow, nullptr, j, a, false, active);
+            float part;
+            if (BLU) {
+                blu_convolve<LOG2C>(zbuf, j, a, v);
+                part = blu_row<LOG2C>(zbuf, prow, nullptr, j, a, false, active, F);
+            } else {
+                part = untangle_row<LOG2C>(zbuf, prow, nullptr, j, a, false, active);
+            }
             red[j] = part;
             frame_sync<LOG2C>();  // zbuf / prow / frow / red are private to the frame's slot
 
             if (a.out_kind == OUT_POWER) {
                 if (active) {
-                    float *dst = a.out0 + gf * G::F;
-                    for (int k = j; k < G::F; k += G::TPF) dst[k] = prow[k];
+                    float *dst = a.out0 + gf * F;
+                    for (int k = j; k < F; k += G::TPF) dst[k] = prow[k];
                 }
             } else {
                 // feature.rs:216-219: frame energy + zero handling (deterministic serial sum)
@@ -327,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
         // ---------------- STFT / mel-spectrogram path: one clip (channel) per workgroup visit -------
         const int R = static_cast<int>(a.rows);
         const int Rreal = static_cast<int>(a.real_rows);
-        const int W = G::N;
+        const int W = BLU ? static_cast<int>(a.blu_n) : G::N;
         constexpr int TILE = 32;  // rows buffered before a transposed, coalesced flush
         for (unsigned clip = blockIdx.x; clip < a.batch; clip += gridDim.x) {
             const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
@@ -339,33 +400,39 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
                     const bool active = rl < rt && r < Rreal;
                     // functions.rs:137-151: window over the last W samples ending at chunk r + n_pad
                     const long long start = static_cast<long long>(r + a.n_pad + 1) * a.hop - W;
+                    auto wsample = [&](int i) -> float {
+                        const long long idx = start + i;
+                        return active && i < W && idx >= 0 && idx < static_cast<long long>(a.n_samples) ? xc[idx] * a.window[i] : 0.0f;
+                    };
                     float2 v[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int n = j + e * G::TPF;
-                        float s[2];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int i = 2 * n + h;
-                            const long long idx = start + i;
-                            float val = 0.0f;
-                            if (active && idx >= 0 && idx < static_cast<long long>(a.n_samples)) val = xc[idx] * a.window[i];
-                            s[h] = val;
+                        if (BLU) {
+                            const float xv = wsample(n);
+                            const float2 c = n < W ? a.blu_c[n] : make_float2(0.f, 0.f);
+                            v[e] = make_float2(xv * c.x, xv * c.y);
+                        } else {
+                            v[e] = make_float2(wsample(2 * n), wsample(2 * n + 1));
                         }
-                        v[e] = make_float2(s[0], s[1]);
                     }
                     frame_fft<LOG2C>(zbuf, j, a.tw_c, v);
                     float2 *stft_row = nullptr;
                     if (a.out_kind == OUT_STFT)
-                        stft_row = reinterpret_cast<float2 *>(a.out0) + (static_cast<unsigned long long>(clip) * R + r) * G::F;
-                    untangle_row<LOG2C>(zbuf, prow, stft_row, j, a, true, active);
+                        stft_row = reinterpret_cast<float2 *>(a.out0) + (static_cast<unsigned long long>(clip) * R + r) * F;
+                    if (BLU) {
+                        blu_convolve<LOG2C>(zbuf, j, a, v);
+                        blu_row<LOG2C>(zbuf, prow, stft_row, j, a, true, active, F);
+                    } else {
+                        untangle_row<LOG2C>(zbuf, prow, stft_row, j, a, true, active);
+                    }
                     frame_sync<LOG2C>();  // prow is private to the frame; the shared tile has its own barriers below
                     if (a.out_kind == OUT_MEL && rl < rt) {
                         // feature.rs:173: out[n,m,t] = sum_f P[n,t,f] fb[m,f]; rows >= real_rows stay zero
                         for (int m = j; m < M; m += G::TPF) tile[m * (TILE + 1) + rl] = active ? mel_dot(prow, a, m) : 0.0f;
                     }
                     if (a.out_kind == OUT_STFT && rl < rt && r >= Rreal) {
-                        for (int k = j; k < G::F; k += G::TPF) stft_row[k] = make_float2(0.0f, 0.0f);
+                        for (int k = j; k < F; k += G::TPF) stft_row[k] = make_float2(0.0f, 0.0f);
                     }
                     __syncthreads();
                 }
@@ -393,14 +460,14 @@ size_t front_lds_bytes(const FrontArgs &a)
     return (total + 15) & ~static_cast<size_t>(15);
 }
 
-template <int LOG2C>
+template <int LOG2C, bool BLU>
 hipError_t launch_one(const FrontArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info, const char *name)
 {
     using G = Geo<LOG2C>;
     const size_t lds = front_lds_bytes<LOG2C>(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ss_front_generic<LOG2C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ss_front_generic<LOG2C, BLU>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
@@ -412,7 +479,7 @@ hipError_t launch_one(const FrontArgs &a, hipStream_t stream, int num_cus, Launc
     const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * 8;
     const unsigned grid = static_cast<unsigned>(work < cap ? work : cap);
     if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kBlock), lds};
-    hipLaunchKernelGGL(ss_front_generic<LOG2C>, dim3(grid), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((ss_front_generic<LOG2C, BLU>), dim3(grid), dim3(kBlock), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -430,15 +497,28 @@ __global__ void ss_preemphasis_kernel(const float *__restrict__ x, float *__rest
 
 hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
+    if (a.blu_n) {
+        switch (log2c) {
+            case 4: return launch_one<4, true>(a, stream, num_cus, info, "ss_front_generic<4,chirpz>");
+            case 5: return launch_one<5, true>(a, stream, num_cus, info, "ss_front_generic<5,chirpz>");
+            case 6: return launch_one<6, true>(a, stream, num_cus, info, "ss_front_generic<6,chirpz>");
+            case 7: return launch_one<7, true>(a, stream, num_cus, info, "ss_front_generic<7,chirpz>");
+            case 8: return launch_one<8, true>(a, stream, num_cus, info, "ss_front_generic<8,chirpz>");
+            case 9: return launch_one<9, true>(a, stream, num_cus, info, "ss_front_generic<9,chirpz>");
+            case 10: return launch_one<10, true>(a, stream, num_cus, info, "ss_front_generic<10,chirpz>");
+            case 11: return launch_one<11, true>(a, stream, num_cus, info, "ss_front_generic<11,chirpz>");
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (log2c) {
-        case 4: return launch_one<4>(a, stream, num_cus, info, "ss_front_generic<4>");
-        case 5: return launch_one<5>(a, stream, num_cus, info, "ss_front_generic<5>");
-        case 6: return launch_one<6>(a, stream, num_cus, info, "ss_front_generic<6>");
-        case 7: return launch_one<7>(a, stream, num_cus, info, "ss_front_generic<7>");
-        case 8: return launch_one<8>(a, stream, num_cus, info, "ss_front_generic<8>");
-        case 9: return launch_one<9>(a, stream, num_cus, info, "ss_front_generic<9>");
-        case 10: return launch_one<10>(a, stream, num_cus, info, "ss_front_generic<10>");
-        case 11: return launch_one<11>(a, stream, num_cus, info, "ss_front_generic<11>");
+        case 4: return launch_one<4, false>(a, stream, num_cus, info, "ss_front_generic<4>");
+        case 5: return launch_one<5, false>(a, stream, num_cus, info, "ss_front_generic<5>");
+        case 6: return launch_one<6, false>(a, stream, num_cus, info, "ss_front_generic<6>");
+        case 7: return launch_one<7, false>(a, stream, num_cus, info, "ss_front_generic<7>");
+        case 8: return launch_one<8, false>(a, stream, num_cus, info, "ss_front_generic<8>");
+        case 9: return launch_one<9, false>(a, stream, num_cus, info, "ss_front_generic<9>");
+        case 10: return launch_one<10, false>(a, stream, num_cus, info, "ss_front_generic<10>");
+        case 11: return launch_one<11, false>(a, stream, num_cus, info, "ss_front_generic<11>");
         default: return hipErrorInvalidValue;
     }
 }

@@ -448,6 +448,68 @@ def test_mel_odd_hops_lengths_and_offsets(ss, oracle, sslib, sr, nfft, hop, M, k
             assert _rel(got[b], want[b]) <= RTOL, (n, b)
 
 
+@pytest.mark.parametrize("sr,nfft,flen,step,M,C", [(16000, 400, 400, 160, 40, 13), (16000, 400, 320, 160, 80, 13), (22050, 441, 441, 220, 40, 13),
+                                                  (44100, 1000, 882, 441, 64, 20), (44100, 1323, 1323, 441, 128, 20), (8000, 100, 80, 40, 20, 12),
+                                                  (8000, 48, 48, 16, 10, 5), (16000, 1365, 1200, 400, 40, 13)])
+def test_fft_lengths_that_are_not_powers_of_two(ss, oracle, sslib, sr, nfft, flen, step, M, C):
+    """The reference takes any fft_points (rustfft); here every length that is not a power of two runs the chirp-z build of the
+    generic kernel: n_fft = 400 (25 ms at 16 kHz), 441, 1000, odd lengths, tiny ones; MFCC, mfe, windows, centred frames."""
+    import torch
+
+    x = _signal(61, (5, flen + 9 * step + 3))
+    xd = torch.from_numpy(x).cuda()
+    for sw in ({}, dict(mfcc_window="hann", spectrum_exponent=2, dct_norm="ortho"), dict(framing="center", preemph_coef=0.97)):
+        kw = dict(frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+        p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert b"chirpz" in sslib.ss_last_kernel_name(), sslib.ss_last_kernel_name()
+        assert got.shape == (5, oracle.num_frames(p, x.shape[1]), C)
+        for b in (0, 4):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        msw = {k: v for k, v in sw.items() if k != "dct_norm"}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
+        wf, we = oracle.mfe(p, x[4])
+        assert _rel(feat[4].cpu().numpy(), wf) <= RTOL and _rel(en[4].cpu().numpy(), we) <= RTOL, sw
+
+
+@pytest.mark.parametrize("sr,nfft,hop,M", [(16000, 400, 200, 40), (16000, 400, 160, 80), (22050, 441, 147, 40), (44100, 1000, 500, 64), (8000, 101, 50, 20)])
+def test_mel_spectrogram_fft_lengths_that_are_not_powers_of_two(ss, oracle, sslib, sr, nfft, hop, M):
+    """mel_spectrogram / stft2 at fft_points that are not powers of two (chirp-z build of the generic kernel)."""
+    import torch
+    from speechsauce_amd import _lib
+
+    kw = dict(frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=nfft)
+    pk = dict(sample_rate=sr, fft_points=nfft, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M)
+    p = oracle.make_params(**pk)
+    n = 3 * nfft + 7 * hop + 5
+    x = _signal(63, (3, n))
+    got = ss.mel_spectrogram(torch.from_numpy(x).cuda(), sr, **kw).cpu().numpy()
+    assert b"chirpz" in sslib.ss_last_kernel_name()
+    want = oracle.mel_spectrogram(p, x)
+    assert got.shape == want.shape and _rel(got, want) <= RTOL
+    cfg = _cfg(ss, **pk)
+    R, Rreal = cfg.stft_rows(n)
+    F = nfft // 2 + 1
+    out = torch.full((3, R, F, 2), 7.0, dtype=torch.float32, device="cuda")
+    _lib.check(sslib.ss_stft_device(cfg.handle, torch.from_numpy(x).cuda().data_ptr(), 3, n, n, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    g = out.cpu().numpy()
+    g = g[..., 0] + 1j * g[..., 1]
+    ws = oracle.stft(p, x)
+    assert g.shape == ws.shape and np.abs(g - ws).max() <= 2e-5 * np.abs(ws).max()
+    assert np.all(g[:, Rreal:] == 0)
+
+
+def test_fft_length_limits(ss):
+    from speechsauce_amd import SpeechSauceError
+
+    x = _signal(64, 16000)
+    for nfft in (1366, 3000, 8192, 15):
+        with pytest.raises(SpeechSauceError):
+            ss.mfcc(x, 16000, fft_length=nfft, frame_length=10 / 16000 if nfft == 15 else 0.02)
+
+
 def test_256_kernel_pair_guard(ss, oracle, sslib):
     """The two-frames-per-transform kernel must not let a loud frame's rounding noise into its silent partner: zero-padded
     clips (all-zero frames next to speech: exact f32::EPSILON energies, as in the reference), digital silence followed by a
