@@ -507,6 +507,7 @@ hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t 
             case 9: return launch_one<9, true>(a, stream, num_cus, info, "ss_front_generic<9,chirpz>");
             case 10: return launch_one<10, true>(a, stream, num_cus, info, "ss_front_generic<10,chirpz>");
             case 11: return launch_one<11, true>(a, stream, num_cus, info, "ss_front_generic<11,chirpz>");
+            case 12: return launch_one<12, true>(a, stream, num_cus, info, "ss_front_generic<12,chirpz>");
             default: return hipErrorInvalidValue;
         }
     }

@@ -450,7 +450,8 @@ def test_mel_odd_hops_lengths_and_offsets(ss, oracle, sslib, sr, nfft, hop, M, k
 
 @pytest.mark.parametrize("sr,nfft,flen,step,M,C", [(16000, 400, 400, 160, 40, 13), (16000, 400, 320, 160, 80, 13), (22050, 441, 441, 220, 40, 13),
                                                   (44100, 1000, 882, 441, 64, 20), (44100, 1323, 1323, 441, 128, 20), (8000, 100, 80, 40, 20, 12),
-                                                  (8000, 48, 48, 16, 10, 5), (16000, 1365, 1200, 400, 40, 13)])
+                                                  (8000, 48, 48, 16, 10, 5), (16000, 1365, 1200, 400, 40, 13), (44100, 1764, 1764, 441, 128, 20),
+                                                  (44100, 2730, 2205, 1024, 128, 13)])
 def test_fft_lengths_that_are_not_powers_of_two(ss, oracle, sslib, sr, nfft, flen, step, M, C):
     """The reference takes any fft_points (rustfft); here every length that is not a power of two runs the chirp-z build of the
     generic kernel: n_fft = 400 (25 ms at 16 kHz), 441, 1000, odd lengths, tiny ones; MFCC, mfe, windows, centred frames."""
@@ -505,7 +506,7 @@ def test_fft_length_limits(ss):
     from speechsauce_amd import SpeechSauceError
 
     x = _signal(64, 16000)
-    for nfft in (1366, 3000, 8192, 15):
+    for nfft in (2731, 3000, 8192, 15):
         with pytest.raises(SpeechSauceError):
             ss.mfcc(x, 16000, fft_length=nfft, frame_length=10 / 16000 if nfft == 15 else 0.02)
 
