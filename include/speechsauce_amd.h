@@ -40,7 +40,7 @@ typedef enum ss_status {
     SS_ERR_BAD_CONFIG = 2,   /* parameter combination the reference asserts on or underflows with */
     SS_ERR_ARG = 3,          /* null pointer, bad leading dimension, ... */
     SS_ERR_HIP = 4,          /* HIP runtime error or no device (see ss_last_error_string) */
-    SS_ERR_UNSUPPORTED = 5   /* valid in the reference but not built here (fft_points > 4096, or > 2730 and not a power of two) */
+    SS_ERR_UNSUPPORTED = 5   /* valid in the reference but not built here (fft_points > 8192, or > 2730 and not a power of two) */
 } ss_status;
 
 enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1, SS_FRAMING_CENTER = 2 };
@@ -63,7 +63,7 @@ enum { SS_PAD_REFLECT = 0, SS_PAD_CONSTANT = 1 };
 typedef struct ss_params {
     uint32_t struct_size;       /* = sizeof(ss_params); checked by ss_config_create */
     uint32_t sample_rate;       /* config.rs:141 */
-    uint32_t fft_points;        /* :142  (power of two 32..4096, or any length 16..2730: chirp-z transform) */
+    uint32_t fft_points;        /* :142  (power of two 32..8192, or any length 16..2730: chirp-z transform) */
     float    frame_length;      /* :143  seconds */
     float    frame_stride;      /* :144  seconds */
     uint32_t num_cepstral;      /* :145 */

@@ -68,10 +68,10 @@ int validate(const ss_params &p)
 {
     if (p.struct_size != sizeof(ss_params)) return fail(SS_ERR_ARG, "ss_params.struct_size mismatch (ABI)");
     if (p.sample_rate == 0) return fail(SS_ERR_BAD_CONFIG, "sample_rate must be > 0");
-    // powers of two in [32, 4096]; any other length from 16 up whose chirp-z transform fits a 4096-point complex FFT
+    // powers of two in [32, 8192]; any other length from 16 up whose chirp-z transform fits a 4096-point complex FFT
     // (fft_points + fft_points/2 < 4096, i.e. up to 2730: 400, 441, 800, 882, 1000, 1103, 1764, 2000, 2205 ...)
-    if (is_pow2(p.fft_points) ? (p.fft_points < 32 || p.fft_points > 4096) : (p.fft_points < 16 || p.fft_points + p.fft_points / 2 + 1 > 4096))
-        return fail(SS_ERR_UNSUPPORTED, "fft_points must be a power of two in [32, 4096] or any length in [16, 2730]");
+    if (is_pow2(p.fft_points) ? (p.fft_points < 32 || p.fft_points > 8192) : (p.fft_points < 16 || p.fft_points + p.fft_points / 2 + 1 > 4096))
+        return fail(SS_ERR_UNSUPPORTED, "fft_points must be a power of two in [32, 8192] or any length in [16, 2730]");
     if (p.num_filters == 0 || p.num_filters > 1024) return fail(SS_ERR_BAD_CONFIG, "num_filters out of range");
     // feature.rs:133 slice_move(s![.., ..num_cepstral]) panics for num_cepstral > num_filters
     if (p.num_cepstral == 0 || p.num_cepstral > p.num_filters)

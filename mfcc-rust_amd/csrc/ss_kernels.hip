@@ -520,6 +520,7 @@ hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t 
         case 9: return launch_one<9, false>(a, stream, num_cus, info, "ss_front_generic<9>");
         case 10: return launch_one<10, false>(a, stream, num_cus, info, "ss_front_generic<10>");
         case 11: return launch_one<11, false>(a, stream, num_cus, info, "ss_front_generic<11>");
+        case 12: return launch_one<12, false>(a, stream, num_cus, info, "ss_front_generic<12>");
         default: return hipErrorInvalidValue;
     }
 }

@@ -46,7 +46,7 @@ def test_cfg1_single_clip_defaults(ss, oracle):
     np.testing.assert_allclose(got[0, :3], [-0.19977, -0.45368, -0.00118], atol=2e-4)
 
 
-@pytest.mark.parametrize("n_fft", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("n_fft", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_mfcc_all_fft_sizes(ss, oracle, n_fft):
     sr = 16000
     fl = min(0.02, n_fft / sr)
@@ -506,9 +506,28 @@ def test_fft_length_limits(ss):
     from speechsauce_amd import SpeechSauceError
 
     x = _signal(64, 16000)
-    for nfft in (2731, 3000, 8192, 15):
+    for nfft in (2731, 3000, 16384, 15):
         with pytest.raises(SpeechSauceError):
             ss.mfcc(x, 16000, fft_length=nfft, frame_length=10 / 16000 if nfft == 15 else 0.02)
+
+
+def test_fft_8192(ss, oracle, sslib):
+    """fft_points = 8192 (the generic kernel with one workgroup per frame): 48 kHz, full-length frames, MFCC and mel-spectrogram."""
+    import torch
+
+    sr = 48000
+    x = _signal(65, (2, 8192 + 5 * 2048 + 7))
+    kw = dict(frame_length=8192 / sr, frame_stride=2048 / sr, num_cepstral=20, num_filters=128, fft_length=8192)
+    p = oracle.make_params(sample_rate=sr, fft_points=8192, frame_length=8192 / sr, frame_stride=2048 / sr, num_cepstral=20, num_filters=128)
+    got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw).cpu().numpy()
+    assert sslib.ss_last_kernel_name() == b"ss_front_generic<12>"
+    for b in range(2):
+        assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL
+    mk = dict(frame_length=2048 / sr, frame_stride=2048 / sr, num_filters=128, fft_length=8192)
+    pm = oracle.make_params(sample_rate=sr, fft_points=8192, frame_length=2048 / sr, frame_stride=2048 / sr, num_filters=128)
+    gm = ss.mel_spectrogram(x, sr, **mk)
+    wm = oracle.mel_spectrogram(pm, x)
+    assert gm.shape == wm.shape and _rel(gm, wm) <= RTOL
 
 
 def test_256_kernel_pair_guard(ss, oracle, sslib):
