@@ -280,8 +280,8 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         g_last_kernel = info.kernel_name;
         return SS_OK;
     }
-    // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra (ss_mfcc512w.hip): optional frame window, no fused
-    // pre-emphasis
+    // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra, and the output / window / framing combinations the
+    // headline kernel has no build for (ss_mfcc512w.hip): optional frame window, centred frames, no fused pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
         (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) &&
         a.preemph == 0.0f) {
@@ -623,10 +623,10 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mfcc1024.ok) SS_UP(d_mfcc1024_tab, c->mfcc1024.tab);
     ss::build_mfcc256(h, c->mfcc256);
     if (c->mfcc256.ok) SS_UP(d_mfcc256_tab, c->mfcc256.tab);
-    if (!c->fast.ok) {  // the headline kernel takes up to 48 filters and 16 cepstra; beyond that the wide-bank build
-        ss::build_mfcc512w(h, c->mfcc512w);
-        if (c->mfcc512w.ok) SS_UP(d_mfcc512w_tab, c->mfcc512w.tab);
-    }
+    // the wide-bank build also serves what the headline kernel's specialised builds leave out at 512 points (mfe / window /
+    // centred frames at other than the default frame shape)
+    ss::build_mfcc512w(h, c->mfcc512w);
+    if (c->mfcc512w.ok) SS_UP(d_mfcc512w_tab, c->mfcc512w.tab);
     ss::build_mel512(h, c->mel512);
     if (c->mel512.ok || c->mel512.stft_only) SS_UP(d_mel512_tab, c->mel512.tab);
     ss::build_mel1024(h, c->mel1024);

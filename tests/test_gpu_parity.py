@@ -938,6 +938,30 @@ def test_mfcc_512_wide_bank_kernel(ss, oracle, sslib):
         assert _rel(got[b], oracle.mfcc(p, xs[b])) <= RTOL, b
 
 
+def test_512_point_combinations_without_a_headline_build(ss, oracle, sslib):
+    """At 512 points the headline kernel has mfe / window / power builds for the default frame shape only; other shapes (25 ms
+    frames with 40 mels: the log-mel front end) fall to the wide-bank kernel, not to the generic one."""
+    import torch
+
+    sr = 16000
+    x = _signal(37, (7, sr))
+    xd = torch.from_numpy(x).cuda()
+    for flen, M, sw in ((400, 40, {}), (400, 40, dict(mfcc_window="hann")), (512, 26, dict(mfcc_window="vorbis", spectrum_exponent=2)),
+                        (256, 40, dict(framing="center", mfcc_window="hann"))):
+        kw = dict(frame_length=flen / sr, frame_stride=0.01, num_filters=M, fft_length=512)
+        p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=flen / sr, frame_stride=0.01, num_filters=M, **sw)
+        feat, en = ss.mfe_batch(xd, sr, **kw, **sw)
+        assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256w<") and b"mfe" in sslib.ss_last_kernel_name(), sslib.ss_last_kernel_name()
+        for b in (0, 6):
+            wf, we = oracle.mfe(p, x[b])
+            assert _rel(feat[b].cpu().numpy(), wf) <= RTOL and _rel(en[b].cpu().numpy(), we) <= RTOL, (flen, M, sw, b)
+        if sw:
+            got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+            assert not sslib.ss_last_kernel_name().startswith(b"ss_front_generic"), sslib.ss_last_kernel_name()
+            for b in (0, 6):
+                assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, M, sw, b)
+
+
 def test_mfcc_256_kernel(ss, oracle, sslib):
     """MFCC / mfe at fft_points = 256 (8 kHz telephony front ends): two frames per complex transform.  20 ms and 25 ms frames,
     odd hops (scalar loads: no alignment assumptions), window, power spectrum, filter counts up to 48, batches whose frame count
