@@ -385,7 +385,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     }
     // fft_points = 4096 MFCC / mfe (even filter count up to 256): the one-frame-per-wave kernel
     if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL &&
-        a.preemph == 0.0f && (a.window == nullptr || a.spectrum_exponent != 2)) {
+        a.preemph == 0.0f) {
         ss::Mfcc4096Args f{};
         f.x = d_x;
         f.ld = ld;

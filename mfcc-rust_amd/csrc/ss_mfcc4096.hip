@@ -595,8 +595,11 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096;
-    if (a.window) {  // windowed builds: MFCC and mfe, magnitude spectrum
-        if (pow2) return hipErrorInvalidValue;
+    if (a.window) {  // windowed builds: MFCC and mfe
+        if (pow2) {
+            if (a.out_mfe) return exact ? go(ss_mfcc_c2048<true, true, WAVES, true, true>, "ss_mfcc_c2048<exact,pow2,mfe,win>") : go(ss_mfcc_c2048<false, true, WAVES, true, true>, "ss_mfcc_c2048<pow2,mfe,win>");
+            return exact ? go(ss_mfcc_c2048<true, true, WAVES, false, true>, "ss_mfcc_c2048<exact,pow2,win>") : go(ss_mfcc_c2048<false, true, WAVES, false, true>, "ss_mfcc_c2048<pow2,win>");
+        }
         if (a.out_mfe) return exact ? go(ss_mfcc_c2048<true, false, WAVES, true, true>, "ss_mfcc_c2048<exact,mfe,win>") : go(ss_mfcc_c2048<false, false, WAVES, true, true>, "ss_mfcc_c2048<mfe,win>");
         return exact ? go(ss_mfcc_c2048<true, false, WAVES, false, true>, "ss_mfcc_c2048<exact,win>") : go(ss_mfcc_c2048<false, false, WAVES, false, true>, "ss_mfcc_c2048<win>");
     }

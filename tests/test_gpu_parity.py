@@ -793,7 +793,8 @@ def test_mfcc_4096_other_filter_counts(ss, oracle, sslib):
     sr = 44100
     x = _signal(26, (4, sr))
     xd = torch.from_numpy(x).cuda()
-    for flen, M, C, sw in ((4096, 128, 20, {}), (3000, 100, 13, dict(mfcc_window="hann")), (4096, 64, 40, dict(dc_elimination=False))):
+    for flen, M, C, sw in ((4096, 128, 20, {}), (3000, 100, 13, dict(mfcc_window="hann")), (4096, 64, 40, dict(dc_elimination=False)),
+                           (4096, 128, 20, dict(mfcc_window="hann", spectrum_exponent=2, dct_norm="ortho")), (3001, 256, 13, dict(mfcc_window="vorbis", spectrum_exponent=2))):
         kw = dict(frame_length=flen / sr, frame_stride=1024 / sr, num_cepstral=C, num_filters=M, fft_length=4096)
         p = oracle.make_params(sample_rate=sr, fft_points=4096, frame_length=flen / sr, frame_stride=1024 / sr, num_cepstral=C,
                                num_filters=M, **sw)
@@ -802,7 +803,7 @@ def test_mfcc_4096_other_filter_counts(ss, oracle, sslib):
         for b in (0, 3):
             assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, M, C, sw, b)
         mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
-        msw = {k: v for k, v in sw.items() if k != "dc_elimination"}
+        msw = {k: v for k, v in sw.items() if k not in ("dc_elimination", "dct_norm")}
         feat, en = ss.mfe_batch(xd, sr, **mkw, **msw)
         assert b"mfe" in sslib.ss_last_kernel_name()
         wf, we = oracle.mfe(p, x[3])
