@@ -206,6 +206,10 @@ int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t bat
 int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
                                    size_t ld, float *d_out, void *stream, int iters, float *avg_ms);
 
+/* Test aid: fills the LDS of every compute unit with 0xFFFFFFFF (a NaN pattern as f32, -1 as i32).  LDS is not cleared
+ * between kernels, so a kernel that lets a word it never wrote reach its results fails loudly after this. */
+int ss_debug_poison_lds(void *stream);
+
 const char *ss_status_string(int status);
 const char *ss_last_error_string(void); /* thread-local detail of the last failure */
 int ss_abi_version(void);

@@ -804,6 +804,16 @@ int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, floa
 
 const char *ss_last_kernel_name(void) { return g_last_kernel; }
 
+int ss_debug_poison_lds(void *stream)
+{
+    int dev = 0, cus = 0;
+    SS_HIP(hipGetDevice(&dev));
+    SS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipError_t e = ss::launch_poison_lds(static_cast<hipStream_t>(stream), cus);
+    if (e != hipSuccess) return hip_fail(e, "launch_poison_lds");
+    return SS_OK;
+}
+
 int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
                               float *d_out, void *stream, int iters, float *avg_ms)
 {

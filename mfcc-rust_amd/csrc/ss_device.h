@@ -67,6 +67,8 @@ struct LaunchInfo {
 // Generic front-end (any power-of-two fft_points in [32, 4096]; with a.blu_n != 0 the chirp-z build for other lengths, log2c then
 // being the length of its complex FFT).
 hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info);
+// Test aid: every word of every CU's LDS := 0xFFFFFFFF (ss_debug_poison_lds).
+hipError_t launch_poison_lds(hipStream_t stream, int num_cus);
 // Element-wise pre-emphasis (processing.rs:31-53).
 hipError_t launch_preemphasis(const float *x, float *y, size_t n, size_t shift, float cof, hipStream_t stream);
 

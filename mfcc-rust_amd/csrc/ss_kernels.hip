@@ -493,7 +493,28 @@ __global__ void ss_preemphasis_kernel(const float *__restrict__ x, float *__rest
     }
 }
 
+// One workgroup takes a CU's whole LDS (160 KB), so a grid of several workgroups per CU sweeps every CU several times.
+__global__ __launch_bounds__(256) void ss_poison_lds_kernel(unsigned words)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned *w = reinterpret_cast<unsigned *>(smem_raw);
+    for (unsigned i = threadIdx.x; i < words; i += 256) w[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    // keep the stores observable
+    if (w[(threadIdx.x * 97u) % words] != 0xFFFFFFFFu) __builtin_trap();
+}
+
 }  // namespace
+
+hipError_t launch_poison_lds(hipStream_t stream, int num_cus)
+{
+    const size_t lds = 160 * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ss_poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    const unsigned grid = static_cast<unsigned>(num_cus > 0 ? num_cus : 256) * 4;
+    hipLaunchKernelGGL(ss_poison_lds_kernel, dim3(grid), dim3(256), lds, stream, static_cast<unsigned>(lds / 4));
+    return hipGetLastError();
+}
 
 hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info)
 {

@@ -123,3 +123,61 @@ def test_random_mel_spectrogram_configurations(ss, oracle, sslib):
         assert _rel(got, want) <= RTOL, (kw, ch, n)
         ran += 1
     assert ran >= 20
+
+
+def test_uninitialised_lds_never_reaches_results(ss, oracle, sslib):
+    """LDS keeps what the previous kernel left in it.  Every sweep configuration (and a list of named ones: windowed and
+    librosa builds, mel / stft kernels, chirp-z) runs once normally and once right after ss_debug_poison_lds has filled every
+    CU's LDS with 0xFFFFFFFF (NaN as f32, -1 as i32): the results must be finite and bit-identical -- a kernel that multiplies
+    a padded zero with a table word it never wrote, or reads a pad bin it never cleared, fails here."""
+    import torch
+
+    def both(fn):
+        a = fn()
+        assert sslib.ss_debug_poison_lds(None) == 0
+        b = fn()
+        torch.cuda.synchronize()
+        return a, b
+
+    def same(a, b, what):
+        a = [t.cpu().numpy() for t in (a if isinstance(a, tuple) else (a,))]
+        b = [t.cpu().numpy() for t in (b if isinstance(b, tuple) else (b,))]
+        for u, v in zip(a, b):
+            assert np.all(np.isfinite(v)), what
+            assert np.array_equal(u, v), what
+
+    ran = 0
+    for block in range(6):
+        for i, (kw, sw, batch, n) in enumerate(_cases(24, 1000 + block)):
+            try:
+                p = oracle.make_params(**kw, **sw)
+                oracle.filterbank(p)
+                oracle.num_frames(p, n)
+            except oracle.OracleError:
+                continue
+            x = torch.from_numpy((np.random.default_rng(7 * i + block).standard_normal((batch, n)) * 0.1).astype(np.float32)).cuda()
+            args = dict(frame_length=kw["frame_length"], frame_stride=kw["frame_stride"], num_cepstral=kw["num_cepstral"],
+                        num_filters=kw["num_filters"], fft_length=kw["fft_points"], low_frequency=kw["low_frequency"],
+                        high_frequency=kw["high_frequency"], dc_elimination=kw["dc_elimination"])
+            same(*both(lambda: ss.mfcc_batch(x, kw["sample_rate"], **args, **sw)), (kw, sw))
+            margs = {k: v for k, v in args.items() if k not in ("num_cepstral", "dc_elimination")}
+            same(*both(lambda: ss.mfe_batch(x, kw["sample_rate"], **margs, **sw)), (kw, sw, "mfe"))
+            ran += 1
+    assert ran > 60
+    # named configurations
+    lib = dict(framing="center", pad_mode="reflect", mfcc_window="hann", spectrum_exponent=2, mel_scale="slaney", mel_norm="slaney", dct_norm="ortho")
+    x16 = torch.from_numpy((np.random.default_rng(5).standard_normal((5, 16000)) * 0.1).astype(np.float32)).cuda()
+    x44 = torch.from_numpy((np.random.default_rng(6).standard_normal((3, 30000)) * 0.1).astype(np.float32)).cuda()
+    named = [
+        (x16, 16000, dict(), {}), (x16, 16000, dict(), dict(mfcc_window="hann")), (x16, 16000, dict(), dict(preemph_coef=0.97)),
+        (x16, 16000, dict(frame_length=260 / 16000), dict(lib, pad_mode="constant")), (x16, 16000, dict(frame_length=0.025, num_filters=80), lib),
+        (x16, 8000, dict(fft_length=256), dict(mfcc_window="hann")), (x16, 16000, dict(fft_length=400, frame_length=0.025), {}),
+        (x44, 22050, dict(fft_length=1024, frame_length=700 / 22050, frame_stride=256 / 22050, num_filters=64, num_cepstral=20), dict(mfcc_window="hann")),
+        (x44, 44100, dict(fft_length=2048, frame_length=1500 / 44100, frame_stride=512 / 44100, num_filters=128, num_cepstral=20), lib),
+        (x44, 44100, dict(fft_length=4096, frame_length=3000 / 44100, frame_stride=1024 / 44100, num_filters=128, num_cepstral=20), dict(mfcc_window="hann")),
+    ]
+    for x, sr, kw, sw in named:
+        same(*both(lambda: ss.mfcc_batch(x, sr, **kw, **sw)), (sr, kw, sw))
+    for nfft, sr, hop, M in ((512, 16000, 256, 40), (1024, 16000, 512, 80), (2048, 16000, 512, 128), (4096, 44100, 1024, 128), (400, 16000, 200, 40), (256, 8000, 128, 20)):
+        x = x44 if sr == 44100 else x16
+        same(*both(lambda: ss.mel_spectrogram(x, sr, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=nfft)), ("mel", nfft))
