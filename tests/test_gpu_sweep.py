@@ -181,3 +181,16 @@ def test_uninitialised_lds_never_reaches_results(ss, oracle, sslib):
     for nfft, sr, hop, M in ((512, 16000, 256, 40), (1024, 16000, 512, 80), (2048, 16000, 512, 128), (4096, 44100, 1024, 128), (400, 16000, 200, 40), (256, 8000, 128, 20)):
         x = x44 if sr == 44100 else x16
         same(*both(lambda: ss.mel_spectrogram(x, sr, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=nfft)), ("mel", nfft))
+
+
+def test_post_processing_on_poisoned_lds(ss, sslib):
+    """cmvn / cmvnw / derivative kernels (processing.rs:222-380) give bit-identical results after ss_debug_poison_lds."""
+    import torch
+
+    feats = torch.from_numpy((np.random.default_rng(9).standard_normal((6, 98, 13))).astype(np.float32)).cuda()
+    for fn in (lambda: ss.cmvn(feats, False), lambda: ss.cmvn(feats, True), lambda: ss.cmvnw(feats, 301, False),
+               lambda: ss.cmvnw(feats, 51, True), lambda: ss.derivative_extraction(feats, 2), lambda: ss.extract_derivative_feature(feats)):
+        a = fn().cpu().numpy()
+        assert sslib.ss_debug_poison_lds(None) == 0
+        b = fn().cpu().numpy()
+        assert np.all(np.isfinite(b)) and np.array_equal(a, b)
