@@ -31,7 +31,7 @@ def sslib():
     from speechsauce_amd import _lib
 
     if not os.path.exists(_lib.LIB_PATH):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc")], check=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc"), "-j4"], check=True)
 
     return _lib.lib()
 
