@@ -772,7 +772,6 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
     f = Mfcc1024Tables{};
     const size_t M = t.params.num_filters, Cc = mel ? 0 : t.params.num_cepstral;
     if (t.d.n_fft != 1024 || M > 128 || Cc > 32) return;
-    if (!mel && (M & 1)) return;  // the symmetric DCT is written for an even filter count
     if (mel && (!t.d.stft_ok || t.window_stft.size() != 1024)) return;
     if (t.bank.last_bin > 513) return;
     f.fullp = t.bank.last_bin > 257;  // reference banks end at (F+1)/2 (P bins 0..256); librosa-style ones need all 513
@@ -839,7 +838,7 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
         off += span;
     }
     for (size_t c = 0; c < Cc; ++c)
-        for (size_t m = 0; m < M / 2; ++m) f.tab[L::kCos + c * L::kCosPitch + m] = t.dct[c * M + m];
+        for (size_t m = 0; m < (M + 1) / 2; ++m) f.tab[L::kCos + c * L::kCosPitch + m] = t.dct[c * M + m];
     f.ok = true;
 }
 
@@ -859,7 +858,7 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
     namespace L = mfcc2048_layout;
     f = Mfcc2048Tables{};
     const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
-    if (t.d.n_fft != 2048 || M > 128 || (M & 1) || Cc > 32) return;  // the symmetric DCT is written for an even filter count
+    if (t.d.n_fft != 2048 || M > 128 || Cc > 32) return;
     if (t.bank.last_bin > 1025) return;
     f.fullp = t.bank.last_bin > 513;  // reference banks end at (F+1)/2 (P bins 0..512); librosa-style ones need all 1025
     const int32_t kRow = f.fullp ? 1028 : 516;
@@ -918,7 +917,7 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
         off += span;
     }
     for (size_t c = 0; c < Cc; ++c)
-        for (size_t m = 0; m < M / 2; ++m) f.tab[L::kCos + c * L::kCosPitch + m] = t.dct[c * M + m];
+        for (size_t m = 0; m < (M + 1) / 2; ++m) f.tab[L::kCos + c * L::kCosPitch + m] = t.dct[c * M + m];
     f.ok = true;
 }
 
@@ -930,7 +929,6 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
     f = Mfcc4096Tables{};
     const size_t M = t.params.num_filters, Cc = mel ? 0 : t.params.num_cepstral;
     if (t.d.n_fft != 4096 || M > 256 || Cc > 64) return;
-    if (!mel && (M & 1)) return;  // the symmetric DCT is written for an even filter count
     if (mel && (!t.d.stft_ok || t.window_stft.size() != 4096)) return;
     if (t.bank.last_bin > 1025) return;  // the kernel keeps P bins 0..1024
     constexpr int32_t kRow = 1028;       // P bins a tap may touch: 0..1024 plus three zero pad bins
@@ -991,7 +989,7 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
         off += span;
     }
     for (size_t cc = 0; cc < Cc; ++cc)
-        for (size_t m = 0; m < M / 2; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
+        for (size_t m = 0; m < (M + 1) / 2; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
     if (mel) {
         const size_t base = f.tab.size();
         f.tab.resize(base + 4096);

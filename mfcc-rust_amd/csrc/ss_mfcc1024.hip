@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
     const float2 *exr = exf + h * kClsK + 2 * k1;                  // reader base
     const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32K;
     const bool k1z = k1 == 0;
-    const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2;
+    const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2, Mc = (M + 1) / 2;
     // valid sample pairs of this lane: n = jj + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
     const int e_hi = min(16, max(0, (static_cast<int>(a.flen) / 2 - jj + 31) >> 5));
     const int half_pairs = static_cast<int>(a.flen) / 2;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             continue;
         }
         wave_order_k();
-        // ---- DCT-II (feature.rs:120-123) with the m <-> M-1-m symmetry of the cosine (M even) ----
+        // ---- DCT-II (feature.rs:120-123) with the m <-> M-1-m symmetry of the cosine ----
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int m = jj + 32 * h2;
@@ -308,7 +308,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
                 const float lo = frow[m], hi = frow[M - 1 - m];
                 srow[m] = lo + hi;
                 drow[m] = lo - hi;
-            } else if (m < ((Mh + 3) & ~3)) {  // the product below runs over whole float4s
+            } else if (m < Mc) {  // odd filter count: the middle filter pairs with itself (its odd-coefficient cosines are zero)
+                srow[m] = frow[m];
+                drow[m] = 0.f;
+            } else if (m < ((Mc + 3) & ~3)) {  // the product below runs over whole float4s
                 srow[m] = 0.f;
                 drow[m] = 0.f;
             }
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             const float4 *r4 = reinterpret_cast<const float4 *>((jj & 1) ? drow : srow);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + jj * L::kCosPitch);
             float acc = 0.f;
-            const int nq = (Mh + 3) / 4;
+            const int nq = (Mc + 3) / 4;
             for (int i = 0; i < nq; ++i) {
                 const float4 r = r4[i], c = c4[i];
                 acc = fmaf(r.x, c.x, acc);

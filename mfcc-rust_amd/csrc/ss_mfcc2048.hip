@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
     const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32G;
-    const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2;
+    const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2, Mc = (M + 1) / 2;
     // valid sample pairs of this lane: n = j + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
     const int e_hi = min(32, max(0, (static_cast<int>(a.flen) / 2 - j + 31) >> 5));
     const int half_pairs = static_cast<int>(a.flen) / 2;
@@ -300,7 +300,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                 const float lo = frow[m], hi = frow[M - 1 - m];
                 srow[m] = lo + hi;
                 drow[m] = lo - hi;
-            } else if (m < ((Mh + 3) & ~3)) {  // the product below runs over whole float4s
+            } else if (m < Mc) {  // odd filter count: the middle filter pairs with itself (its odd-coefficient cosines are zero)
+                srow[m] = frow[m];
+                drow[m] = 0.f;
+            } else if (m < ((Mc + 3) & ~3)) {  // the product below runs over whole float4s
                 srow[m] = 0.f;
                 drow[m] = 0.f;
             }
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
             const float4 *r4 = reinterpret_cast<const float4 *>((j & 1) ? drow : srow);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * L::kCosPitch);
             float acc = 0.f;
-            const int nq = (Mh + 3) / 4;  // the rows are zero-padded to a multiple of 4 by the host table / the loop below
+            const int nq = (Mc + 3) / 4;  // the rows are zero-padded to a multiple of 4 by the host table / the loop below
             for (int i = 0; i < nq; ++i) {
                 const float4 r = r4[i], c = c4[i];
                 acc = fmaf(r.x, c.x, acc);

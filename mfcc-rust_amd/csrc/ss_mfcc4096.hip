@@ -335,9 +335,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int m = lane + 64 * h2;
                 const bool in = m < Mh;  // M < 256: the rows are zero beyond M/2 (as are the cosine rows)
-                const float lo = in ? frow[m] : 0.f, hi = in ? frow[M - 1 - m] : 0.f;
+                const bool mid = (M & 1) && m == Mh;  // odd filter count: the middle filter pairs with itself
+                const float lo = in || mid ? frow[m] : 0.f, hi = in ? frow[M - 1 - m] : 0.f;
                 srow[m] = lo + hi;
-                drow[m] = lo - hi;
+                drow[m] = mid ? 0.f : lo - hi;
             }
         }
         wave_order_h();

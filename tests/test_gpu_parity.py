@@ -963,6 +963,24 @@ def test_512_point_combinations_without_a_headline_build(ss, oracle, sslib):
                 assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (flen, M, sw, b)
 
 
+@pytest.mark.parametrize("sr,nfft,hop,M,C,kernel", [(22050, 1024, 256, 41, 13, b"ss_mfcc_c512"), (22050, 1024, 256, 127, 32, b"ss_mfcc_c512"),
+                                                    (44100, 2048, 512, 127, 20, b"ss_mfcc_c1024"), (44100, 2048, 512, 25, 13, b"ss_mfcc_c1024"),
+                                                    (44100, 4096, 1024, 255, 40, b"ss_mfcc_c2048"), (44100, 4096, 1024, 101, 13, b"ss_mfcc_c2048")])
+def test_odd_filter_counts_on_the_symmetric_dct_kernels(ss, oracle, sslib, sr, nfft, hop, M, C, kernel):
+    """The sum / difference DCT of the 1024-, 2048- and 4096-point kernels with an odd number of filters: the middle filter pairs
+    with itself."""
+    import torch
+
+    x = _signal(39, (3, nfft + 8 * hop))
+    kw = dict(frame_length=nfft / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+    for sw in ({}, dict(dct_norm="ortho", dc_elimination=False)):
+        p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=nfft / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, **sw)
+        got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(kernel), sslib.ss_last_kernel_name()
+        for b in range(3):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
+
+
 def test_mfcc_256_kernel(ss, oracle, sslib):
     """MFCC / mfe at fft_points = 256 (8 kHz telephony front ends): two frames per complex transform.  20 ms and 25 ms frames,
     odd hops (scalar loads: no alignment assumptions), window, power spectrum, filter counts up to 48, batches whose frame count

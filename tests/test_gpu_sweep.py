@@ -25,7 +25,7 @@ def _cases(n, seed):
         step = int(rng.integers(max(8, flen // 8), flen + 1))
         if rng.random() < 0.7:
             step &= ~1
-        M = int(rng.choice([20, 26, 40, 40, 48, 64, 128, 256]))
+        M = int(rng.choice([20, 26, 40, 40, 48, 64, 128, 256, 23, 41, 79, 127]))
         C = int(rng.integers(1, min(M, 40) + 1))
         kw = dict(sample_rate=sr, fft_points=n_fft, frame_length=(flen + 0.25) / sr, frame_stride=(step + 0.25) / sr,
                   num_cepstral=C, num_filters=M, low_frequency=float(rng.choice([0.0, 50.0, 300.0])),
