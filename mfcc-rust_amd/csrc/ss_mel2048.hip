@@ -21,6 +21,7 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 #include <cstdlib>
 
@@ -28,20 +29,11 @@ namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mel2048_layout;
 constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
-
-__device__ __forceinline__ void wave_order_m()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_m(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
 
 // One mel slot: q4 aligned float4s of weights against the same span of the P row (the host rounds a filter's first bin down
 // to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip per four taps.
@@ -193,7 +185,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 const int jl = j & 15;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[k];
-                wave_order_m();
+                wave_order();
                 if (j < 16) {
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
@@ -202,10 +194,10 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         u[2 * p + 1] = make_float2(t4.z, t4.w);
                     }
                 }
-                wave_order_m();
+                wave_order();
 #pragma unroll
                 for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[16 + k];
-                wave_order_m();
+                wave_order();
                 if (j >= 16) {
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
@@ -214,7 +206,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         u[2 * p + 1] = make_float2(t4.z, t4.w);
                     }
                 }
-                wave_order_m();
+                wave_order();
                 // the window registers are dead now: the next unit's samples load into them while this one is finished
                 if (PREFETCH_M && next < u_hi) load_unit(next, v);
 #pragma unroll
@@ -235,7 +227,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
                     float2 zcs[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm_m(paddr, u[31 - (8 * hb + q)].x), bperm_m(paddr, u[31 - (8 * hb + q)].y));
+                    for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm(paddr, u[31 - (8 * hb + q)].x), bperm(paddr, u[31 - (8 * hb + q)].y));
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         const int q = 8 * hb + qq;
@@ -268,13 +260,13 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     }
                 }
                 if (STFT) {
-                    wave_order_m();
+                    wave_order();
                     if (!PREFETCH_M && next < u_hi) load_unit(next, v);
                     unit = next;
                     continue;
                 }
                 if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
-                wave_order_m();
+                wave_order();
                 // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are
                 //      adjacent words of out[clip][m][.] ----
                 if (in_rows) {
@@ -287,7 +279,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         off += a.mel_q4[s];
                     }
                 }
-                wave_order_m();
+                wave_order();
             }
         }
         if (!PREFETCH_M && next < u_hi) load_unit(next, v);

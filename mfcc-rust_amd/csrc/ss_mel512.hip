@@ -18,25 +18,17 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mel512_layout;
 constexpr int kSlotFloatsE = 576;  // per row: exchange slot (288 float2); afterwards the P row [260]
 constexpr int kWaveFloatsE = 4 * kSlotFloatsE;
-
-__device__ __forceinline__ void wave_order_e()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_e(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
 
 // q4 float4s of weights against the taps that start at p (any bin): two weight / tap groups per LDS wait
 __device__ __forceinline__ float mel_slot_e(const float4 *w4, const float *p, int q4)
@@ -177,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
         fft16_reg(v);
 #pragma unroll
         for (int q = 0; q < 16; ++q) zh[wbase1 + 2 * q] = v[q];
-        wave_order_e();
+        wave_order();
         if (next < u_hi) load_unit(next, vin);
         float2 u[16];
 #pragma unroll
@@ -186,7 +178,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
             u[2 * p] = make_float2(t4.x, t4.y);
             u[2 * p + 1] = make_float2(t4.z, t4.w);
         }
-        wave_order_e();
+        wave_order();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const float4 w2 = s_tw2[p * 16 + j];
@@ -202,7 +194,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
         const float cs = 0.5f * a.scale;
         float2 zcs[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm_e(paddr, u[15 - q].x), bperm_e(paddr, u[15 - q].y));
+        for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm(paddr, u[15 - q].x), bperm(paddr, u[15 - q].y));
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float2 zk = u[q];
@@ -236,12 +228,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
             }
         }
         if (STFT) {
-            wave_order_e();
+            wave_order();
             unit = next;
             continue;
         }
         if (j < 3) prow[(a.fullp ? 257 : 129) + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
-        wave_order_e();
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:173); the four rows of the wave are adjacent words of out[clip][m][.] ----
         if (r < R) {
@@ -255,7 +247,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
                 off += a.mel_q4[s];
             }
         }
-        wave_order_e();
+        wave_order();
         unit = next;
     }
 }

@@ -19,40 +19,25 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mfcc1024_layout;
-constexpr float kEpsK = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
-constexpr float kTwo32K = 4294967296.f;
 constexpr int kClsK = 8 * 34 + 8;        // float2 per class slice (+8: the two classes of a write group sit 16 banks apart)
 constexpr int kFrameF2 = 560;            // float2 per frame region (4480 B = 128 mod 256: the two frames of a wave use different banks)
 constexpr int kFrameFloats = 2 * kFrameF2;  // after the exchange: P row [260] | ln(mel) row [128] | s [64] | d [64]
 constexpr int kWaveFloatsK = 2 * kFrameFloats;
-
-__device__ __forceinline__ void wave_order_k()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_k(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
 
 // v_permlane16_swap: the odd DPP rows (lanes 16..31, 48..63) of `a` trade places with the even rows of `b`
 // (tools/ubench/permlane16.hip).  Inline assembly with its own hazard s_nop, as for v_permlane32_swap in ss_mfcc4096.hip.
 __device__ __forceinline__ void swap_rows(float &a, float &b)
 {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
-__device__ __forceinline__ float ln_scaled_k(float xs)
-{
-    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
 }
 
 __device__ __forceinline__ float mel_slot_k(const float4 *w4, const float4 *p4, int q4)
@@ -82,13 +67,6 @@ __device__ __forceinline__ float mel_slot_k(const float4 *w4, const float4 *p4, 
         acc = fmaf(w.w, t.w, acc);
     }
     return acc;
-}
-
-__device__ __forceinline__ float half_sum_k(float v)
-{
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
 }
 
 template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
@@ -138,7 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
     const int paddr = ((lane & 32) | ((16 - k1) & 15) | ((1 - h) << 4)) << 2;  // lane holding Z[512 - k]
     float2 *exw = exf + cls * kClsK + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
     const float2 *exr = exf + h * kClsK + 2 * k1;                  // reader base
-    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32K;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     const bool k1z = k1 == 0;
     const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2, Mc = (M + 1) / 2;
     // valid sample pairs of this lane: n = jj + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
@@ -204,7 +182,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
         fft_reg<16>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
-        wave_order_k();
+        wave_order();
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -212,7 +190,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             u[2 * p] = make_float2(t4.x, t4.y);
             u[2 * p + 1] = make_float2(t4.z, t4.w);
         }
-        wave_order_k();
+        wave_order();
         // ---- twiddle W256^(b k1), radix-16 over b ----
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -242,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float2 sv = k1z ? r1[(8 - i) & 7] : r1[7 - i];
-            zcs[i] = make_float2(bperm_k(paddr, sv.x), bperm_k(paddr, sv.y));
+            zcs[i] = make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
         }
         float *pdst = prow + k1 + 128 * h;
 #pragma unroll
@@ -272,9 +250,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             esum += p256;
         }
         if (jj < 3) prow[(LIB ? 513 : 257) + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
-        float energy = hscale32 * half_sum_k(esum);            // E * 2^32
-        energy = energy == 0.f ? kEpsK * kTwo32K : energy;     // zero_handling, feature.rs:219
-        wave_order_k();
+        float energy = hscale32 * half_sum(esum);            // E * 2^32
+        energy = energy == 0.f ? kEps * kTwo32 : energy;     // zero_handling, feature.rs:219
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
         {
@@ -282,24 +260,24 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float m = hscale32 * mel_slot_k(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
-                m = m == 0.f ? kEpsK * kTwo32K : m;
+                m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {
                     if (MFE) {
-                        if (live) a.out[static_cast<unsigned long long>(gf) * M + fi[s]] = m * (1.0f / kTwo32K);  // exact: power of two
+                        if (live) a.out[static_cast<unsigned long long>(gf) * M + fi[s]] = m * (1.0f / kTwo32);  // exact: power of two
                     } else {
-                        frow[fi[s]] = ln_scaled_k(m);
+                        frow[fi[s]] = ln_scaled(m);
                     }
                 }
                 off += a.mel_q4[s];
             }
         }
         if (MFE) {
-            if (jj == 0 && live) a.out_energy[gf] = energy * (1.0f / kTwo32K);
-            wave_order_k();
+            if (jj == 0 && live) a.out_energy[gf] = energy * (1.0f / kTwo32);
+            wave_order();
             unit = next;
             continue;
         }
-        wave_order_k();
+        wave_order();
         // ---- DCT-II (feature.rs:120-123) with the m <-> M-1-m symmetry of the cosine ----
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
@@ -316,7 +294,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
                 drow[m] = 0.f;
             }
         }
-        wave_order_k();
+        wave_order();
         if (jj < Cc) {
             const float4 *r4 = reinterpret_cast<const float4 *>((jj & 1) ? drow : srow);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + jj * L::kCosPitch);
@@ -331,10 +309,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (jj == 0) o = a.dc_elimination ? ln_scaled_k(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (jj == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
             if (live) a.out[static_cast<unsigned long long>(gf) * Cc + jj] = o;
         }
-        wave_order_k();
+        wave_order();
         unit = next;
     }
 }
@@ -443,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
         fft_reg<16>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
-        wave_order_k();
+        wave_order();
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -451,7 +429,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
             u[2 * p] = make_float2(t4.x, t4.y);
             u[2 * p + 1] = make_float2(t4.z, t4.w);
         }
-        wave_order_k();
+        wave_order();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const float4 w2 = s_t1[p * 16 + k1];
@@ -474,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float2 sv = k1z ? r1[(8 - i) & 7] : r1[7 - i];
-            zcs[i] = make_float2(bperm_k(paddr, sv.x), bperm_k(paddr, sv.y));
+            zcs[i] = make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
         }
         const int kb = k1 + 128 * h;
         // stft build (functions.rs:86-123, :166-169): X[k] * wnorm for all 513 bins of the row, interleaved re / im
@@ -514,12 +492,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
             }
         }
         if (STFT) {
-            wave_order_k();
+            wave_order();
             unit = next;
             continue;
         }
         if (jj < 3) prow[(a.fullp ? 513 : 257) + jj] = 0.f;  // pad bins read (with zero weight) by the mel stage
-        wave_order_k();
+        wave_order();
         // ---- banded mel reduction (feature.rs:173); the two rows of the wave are adjacent words of out[clip][m][.] ----
         if (r < R) {
             float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
@@ -531,7 +509,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
                 off += a.mel_q4[s];
             }
         }
-        wave_order_k();
+        wave_order();
         unit = next;
     }
 }

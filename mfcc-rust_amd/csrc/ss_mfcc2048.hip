@@ -17,36 +17,21 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mfcc2048_layout;
-constexpr float kEpsG = 1.1920929e-7f;      // f32::EPSILON, functions.rs:70
-constexpr float kTwo32G = 4294967296.f;
 constexpr int kExSlotsG = 2 * 16 * 34;      // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsG = kExSlotsG * 2;
 constexpr int kHalfFloats = kWaveFloatsG / 2;  // per frame after the exchange: P row [520] | ln(mel) row [128] | s [64] | d [64]
 constexpr int kHalfFloatsLib = 1288;           // LIB: P row [1028] | ln(mel) row [128] | s [64] | d [64]
 template <bool LIB> constexpr int wave_floats() { return LIB ? 2 * kHalfFloatsLib : kWaveFloatsG; }
 
-__device__ __forceinline__ void wave_order_g()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_g(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
-
-// ln(x) for a value handed over as x * 2^32 (see ss_mfcc512.hip)
-__device__ __forceinline__ float ln_scaled_g(float xs)
-{
-    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
-}
 
 __device__ __forceinline__ float mel_slot_g(const float4 *w4, const float4 *p4, int q4)
 {
@@ -77,13 +62,6 @@ __device__ __forceinline__ float mel_slot_g(const float4 *w4, const float4 *p4, 
     return acc;
 }
 
-// sum over the 32 lanes of a half-wave; every lane of the half ends with the same bits
-__device__ __forceinline__ float half_sum(float v)
-{
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 
 template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a)
@@ -128,7 +106,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
     }
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
-    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32G;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     const int M = static_cast<int>(a.n_filters), Cc = static_cast<int>(a.n_ceps), Mh = M / 2, Mc = (M + 1) / 2;
     // valid sample pairs of this lane: n = j + 32 e with 2 n < flen (zero pad to fft_points, processing.rs:147-156)
     const int e_hi = min(32, max(0, (static_cast<int>(a.flen) / 2 - j + 31) >> 5));
@@ -197,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
         const int jl = j & 15;
 #pragma unroll
         for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[k];
-        wave_order_g();
+        wave_order();
         if (j < 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -206,10 +184,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                 u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        wave_order_g();
+        wave_order();
 #pragma unroll
         for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[16 + k];
-        wave_order_g();
+        wave_order();
         if (j >= 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -218,7 +196,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                 u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        wave_order_g();
+        wave_order();
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const float4 w2 = s_tw2[p * 32 + j];
@@ -233,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
         for (int hb2 = 0; hb2 < 2; ++hb2) {
             float2 zcs[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm_g(paddr, u[31 - (8 * hb2 + q)].x), bperm_g(paddr, u[31 - (8 * hb2 + q)].y));
+            for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm(paddr, u[31 - (8 * hb2 + q)].x), bperm(paddr, u[31 - (8 * hb2 + q)].y));
 #pragma unroll
             for (int qq = 0; qq < 8; ++qq) {
                 const int q = 8 * hb2 + qq;
@@ -264,8 +242,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
         }
         if (j < 3) prow[(LIB ? 1025 : 513) + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float energy = hscale32 * half_sum(esum);              // E * 2^32
-        energy = energy == 0.f ? kEpsG * kTwo32G : energy;     // zero_handling, feature.rs:219
-        wave_order_g();
+        energy = energy == 0.f ? kEps * kTwo32 : energy;     // zero_handling, feature.rs:219
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
         {
@@ -273,24 +251,24 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float m = hscale32 * mel_slot_g(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
-                m = m == 0.f ? kEpsG * kTwo32G : m;
+                m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {
                     if (MFE) {
-                        if (live) a.out[static_cast<unsigned long long>(gf) * M + fi[s]] = m * (1.0f / kTwo32G);  // exact: power of two
+                        if (live) a.out[static_cast<unsigned long long>(gf) * M + fi[s]] = m * (1.0f / kTwo32);  // exact: power of two
                     } else {
-                        frow[fi[s]] = ln_scaled_g(m);
+                        frow[fi[s]] = ln_scaled(m);
                     }
                 }
                 off += a.mel_q4[s];
             }
         }
         if (MFE) {
-            if (j == 0 && live) a.out_energy[gf] = energy * (1.0f / kTwo32G);
-            wave_order_g();
+            if (j == 0 && live) a.out_energy[gf] = energy * (1.0f / kTwo32);
+            wave_order();
             unit = next;
             continue;
         }
-        wave_order_g();
+        wave_order();
         // ---- DCT-II (feature.rs:120-123), cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M even: sum and
         // difference rows once per frame, then a M/2-term product per coefficient ----
 #pragma unroll
@@ -308,7 +286,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                 drow[m] = 0.f;
             }
         }
-        wave_order_g();
+        wave_order();
         if (j < Cc) {
             const float4 *r4 = reinterpret_cast<const float4 *>((j & 1) ? drow : srow);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * L::kCosPitch);
@@ -323,10 +301,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (j == 0) o = a.dc_elimination ? ln_scaled_g(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (j == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
             if (live) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
         }
-        wave_order_g();
+        wave_order();
         unit = next;
     }
 }

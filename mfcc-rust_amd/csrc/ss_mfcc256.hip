@@ -23,51 +23,20 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mfcc256_layout;
-constexpr float kEpsX = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
-constexpr float kTwo32X = 4294967296.f;
 constexpr int kSlotFloats = 576;        // per frame pair: exchange slot (288 float2); afterwards P rows [2][132] | ln(mel) rows [2][48]
 constexpr int kWaveFloatsX = 4 * kSlotFloats;
 constexpr int kPRowX = 132;             // bins 0..128 + three zero pad bins
 constexpr float kPairGuard = 1000.f;    // energy ratio (30 dB) beyond which the two frames of a pair are transformed one at a time
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_x(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-
-// sum over the 16 lanes of a DPP row; every lane ends with the same bits
-__device__ __forceinline__ float row16_sum_x(float v)
-{
-    v += dpp_x<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_x<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_x<0x141>(v);  // row_half_mirror
-    v += dpp_x<0x140>(v);  // row_mirror
-    return v;
-}
-
-__device__ __forceinline__ void wave_order_x()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_x(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
-
-// ln(x) for a value handed over as x * 2^32 (see ss_mfcc512.hip)
-__device__ __forceinline__ float ln_scaled_x(float xs)
-{
-    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
-}
 
 // q4 float4s of weights against the taps that start at p (any bin): four weight / tap groups per LDS wait
 __device__ __forceinline__ float mel_slot_x(const float4 *w4, const float *p, int q4)
@@ -178,7 +147,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
     const int Cc = static_cast<int>(a.n_ceps), M = static_cast<int>(a.n_filters);
     // |2A| = |s|: the 1/2 of the untangle is folded into the scale (1/4 for the squared form)
-    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32X;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     __syncthreads();
     int st[3], fi[3];
 #pragma unroll
@@ -217,8 +186,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             ea = fmaf(vin[e].x, vin[e].x, ea);
             eb = fmaf(vin[e].y, vin[e].y, eb);
         }
-        ea = row16_sum_x(ea);
-        eb = row16_sum_x(eb);
+        ea = row16_sum(ea);
+        eb = row16_sum(eb);
         const int npass = __any(fmaxf(ea, eb) > kPairGuard * fminf(ea, eb)) ? 2 : 1;
         for (int pass = 0; pass < npass; ++pass) {
         float2 v[16];
@@ -233,7 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         fft16_reg(v);
 #pragma unroll
         for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
-        wave_order_x();
+        wave_order();
         if (pass == npass - 1 && next < o_hi) load_oct<NE>(a, next, total, f, j, vin, tA_next, tB_next);  // the input registers are dead now
         float2 u[16];
 #pragma unroll
@@ -242,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             u[2 * p] = make_float2(t4.x, t4.y);
             u[2 * p + 1] = make_float2(t4.z, t4.w);
         }
-        wave_order_x();
+        wave_order();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const float4 w2 = RES_TW ? tw2r[RES_TW ? p : 0] : s_tw2[p * 16 + j];
@@ -254,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         // ---- split Z into the two frames' spectra; |X| (processing.rs:168) * 1/N (:180); row sums (feature.rs:216) ----
         float2 zcs[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm_x(paddr, u[15 - r].x), bperm_x(paddr, u[15 - r].y));
+        for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         float *prA = slot, *prB = slot + kPRowX;
         float esA = 0.f, esB = 0.f;
 #pragma unroll
@@ -287,10 +256,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             prA[129 + j] = 0.f;
             prB[129 + j] = 0.f;
         }
-        float en[2] = {hscale32 * row16_sum_x(esA), hscale32 * row16_sum_x(esB)};  // E * 2^32
+        float en[2] = {hscale32 * row16_sum(esA), hscale32 * row16_sum(esB)};  // E * 2^32
 #pragma unroll
-        for (int s = 0; s < 2; ++s) en[s] = en[s] == 0.f ? kEpsX * kTwo32X : en[s];  // zero_handling, feature.rs:219
-        wave_order_x();
+        for (int s = 0; s < 2; ++s) en[s] = en[s] == 0.f ? kEps * kTwo32 : en[s];  // zero_handling, feature.rs:219
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
 #pragma unroll
@@ -303,7 +272,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 m[k] = hscale32 * mel_slot_x(w4 + off, pr + st[k], a.mel_q4[k]);
-                m[k] = m[k] == 0.f ? kEpsX * kTwo32X : m[k];
+                m[k] = m[k] == 0.f ? kEps * kTwo32 : m[k];
                 off += a.mel_q4[k];
             }
             const unsigned gf = oct * 8 + 2 * f + s;
@@ -312,14 +281,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
                     float *row = a.out + static_cast<unsigned long long>(gf) * M;
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-                        if (fi[k] >= 0) row[fi[k]] = m[k] * (1.0f / kTwo32X);  // exact: power of two
-                    if (j == 0) a.out_energy[gf] = en[s] * (1.0f / kTwo32X);
+                        if (fi[k] >= 0) row[fi[k]] = m[k] * (1.0f / kTwo32);  // exact: power of two
+                    if (j == 0) a.out_energy[gf] = en[s] * (1.0f / kTwo32);
                 }
                 continue;
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) frow[16 * k + j] = ln_scaled_x(m[k]);
-            wave_order_x();
+            for (int k = 0; k < 3; ++k) frow[16 * k + j] = ln_scaled(m[k]);
+            wave_order();
             // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 48-entry row ----
             float acc = 0.f;
 #pragma unroll
@@ -340,10 +309,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (j == 0) o = a.dc_elimination ? ln_scaled_x(en[s]) : acc * ((s ? tB : tA) == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (j == 0) o = a.dc_elimination ? ln_scaled(en[s]) : acc * ((s ? tB : tA) == 0 ? a.dct_scale_00 : a.dct_scale_0);
             if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
         }
-        wave_order_x();
+        wave_order();
         }
         oct = next;
     }

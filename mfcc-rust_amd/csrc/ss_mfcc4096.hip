@@ -20,6 +20,7 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 #include <cstdlib>
 
@@ -27,24 +28,14 @@ namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mfcc4096_layout;
-constexpr float kEpsH = 1.1920929e-7f;    // f32::EPSILON, functions.rs:70
 constexpr int kClsStride = 16 * 34 + 8;    // float2 per class slice: +8 keeps the two classes of a write group 16 banks apart
 constexpr int kExFloats = (kClsStride + 16 * 34) * 2;  // exchange region (two classes x half the columns, 8768 B); P row + ln(mel) row reuse it
 constexpr bool kDbgStages = false;        // true: SS_DEBUG_ROWS also dumps frame 0's registers after each FFT stage (tools/dbg4096.py)
 constexpr int kFRowOff = L::kPRow;        // ln(mel) row [256] behind the P row (both inside the exchange region)
 constexpr int kSRowOff = kFRowOff + 256;  // s[128] and d[128] rows of the symmetric DCT, behind the ln(mel) row
-
-__device__ __forceinline__ void wave_order_h()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_h(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
 
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.  Inline assembly: hipcc 7.2 drops the
 // second result of __builtin_amdgcn_permlane32_swap (both extracts read the first register).  The s_nop covers the
@@ -54,13 +45,6 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-// ln(x) for a value handed over as x * 2^32 (the factor rides on the scale multiply that produced it): v_log_f32 then
-// sees a normal number for every non-zero f32 x and no denormal test is needed
-constexpr float kTwo32H = 4294967296.f;
-__device__ __forceinline__ float ln_scaled_h(float xs)
-{
-    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
-}
 
 // One mel slot: q4 aligned float4s of weights against the same span of the P row (the host rounds a filter's first bin down
 // to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip per four taps.
@@ -91,13 +75,6 @@ __device__ __forceinline__ float mel_slot_h(const float4 *w4, const float4 *p4, 
         acc = fmaf(w.w, t.w, acc);
     }
     return acc;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
 }
 
 template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false>
@@ -151,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
     float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
     const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
-    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32H;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     const bool k1z = k1 == 0;
     const int M = static_cast<int>(a.n_filters), Mh = M / 2;
 
@@ -192,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         float2 u[32];
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
-        wave_order_h();
+        wave_order();
         if (k1 < 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -201,10 +178,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        wave_order_h();
+        wave_order();
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[16 + k];
-        wave_order_h();
+        wave_order();
         if (k1 >= 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -213,7 +190,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        wave_order_h();
+        wave_order();
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 1 * 4096)[lane * 32 + e] = u[e];
@@ -267,7 +244,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int q = 0; q < 8; ++q) {
                 const int i = 8 * hb + q;
                 const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
-                zcs[q] = make_float2(bperm_h(paddr, sv.x), bperm_h(paddr, sv.y));
+                zcs[q] = make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -297,8 +274,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             esum += p1024;
         }
         float energy = hscale32 * wave_sum(esum);          // E * 2^32 (see ln_scaled_h)
-        energy = energy == 0.f ? kEpsH * kTwo32H : energy;  // zero_handling, feature.rs:219
-        wave_order_h();
+        energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
         {
@@ -306,21 +283,21 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float m = hscale32 * mel_slot_h(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
-                m = m == 0.f ? kEpsH * kTwo32H : m;
+                m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
-                    if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32H);  // exact: power of two
-                    else frow[fi[s]] = ln_scaled_h(m);
+                    if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32);  // exact: power of two
+                    else frow[fi[s]] = ln_scaled(m);
                 }
                 off += a.mel_q4[s];
             }
         }
         if (MFE) {  // mfe (feature.rs:200-233): mel energies (written above) and the frame energy
-            if (lane == 0) a.out_energy[frame] = energy * (1.0f / kTwo32H);
-            wave_order_h();
+            if (lane == 0) a.out_energy[frame] = energy * (1.0f / kTwo32);
+            wave_order();
             frame = next;
             continue;
         }
-        wave_order_h();
+        wave_order();
         if (a.dbg && frame == 0) {
             for (int i = lane; i < 1028; i += 64) a.dbg[i] = prow[i];
             for (int i = lane; i < 256; i += 64) a.dbg[1028 + i] = frow[i];
@@ -341,7 +318,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 drow[m] = mid ? 0.f : lo - hi;
             }
         }
-        wave_order_h();
+        wave_order();
         if (lane < Cc) {
             const float4 *r4 = reinterpret_cast<const float4 *>(wbase + kSRowOff + ((lane & 1) ? 128 : 0));
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosPitch);
@@ -364,10 +341,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (lane == 0) o = a.dc_elimination ? ln_scaled_h(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
             a.out[static_cast<unsigned long long>(frame) * Cc + lane] = o;
         }
-        wave_order_h();
+        wave_order();
         frame = next;
     }
 }
@@ -473,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
         float2 u[32];
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
-        wave_order_h();
+        wave_order();
         if (k1 < 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -482,10 +459,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
                 u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        wave_order_h();
+        wave_order();
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[16 + k];
-        wave_order_h();
+        wave_order();
         if (k1 >= 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -494,7 +471,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
                 u[2 * p + 1] = make_float2(t4.z, t4.w);
             }
         }
-        wave_order_h();
+        wave_order();
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const float4 w2 = s_t1[p * 32 + k1];
@@ -526,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
             for (int q = 0; q < 8; ++q) {
                 const int i = 8 * hb + q;
                 const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
-                zcs[q] = make_float2(bperm_h(paddr, sv.x), bperm_h(paddr, sv.y));
+                zcs[q] = make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -553,7 +530,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
             if (STFT) srow[1024] = make_float2(a.scale * z.x, -a.scale * z.y);
             else prow[1024] = hs * 4.f * fmaf(z.x, z.x, z.y * z.y);
         }
-        wave_order_h();
+        wave_order();
         if (STFT) {
             row = next;
             continue;
@@ -569,7 +546,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
                 off += a.mel_q4[s];
             }
         }
-        wave_order_h();
+        wave_order();
         row = next;
     }
 }

@@ -40,6 +40,7 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 #include <cstdlib>
 
@@ -47,49 +48,14 @@ namespace ss {
 
 namespace {
 
-constexpr float kEpsF = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
+using namespace wv;
+
 constexpr int kZStride = 288;           // float2 per frame exchange slot (2304 B = 9 bank rows)
 constexpr int kPRow = 144;              // floats per P row: bins 0..128, 3 zero pad bins, padding
 constexpr int kPOff = 4 * kZStride * 2;  // P rows sit behind the exchange slots: their zero pad bins persist
 constexpr int kWaveFloats = 4 * kZStride * 2 + 4 * kPRow;  // four exchange slots (log-mel rows reuse them) + four P rows
 namespace L = fast512_layout;
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-
-// sum over the 16 lanes of a DPP row; every lane ends with the same bits
-__device__ __forceinline__ float row16_sum(float v)
-{
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror
-    return v;
-}
-
-// Wave-private LDS hand-off: the hardware keeps one wave's LDS operations in order; this only stops the
-// compiler from reordering the accesses around the point.
-__device__ __forceinline__ void wave_order()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
-
-// ln(x) for a value handed over as x * 2^32 (the factor rides on the scale multiply that produced it): no
-// denormal test is needed, v_log_f32 sees a normal number for every non-zero f32 x.
-constexpr float kTwo32 = 4294967296.f;
-__device__ __forceinline__ float ln_scaled(float xs)
-{
-    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
-}
 
 // Issues the loads of one quad; returns this lane's frame index within its clip.
 template <int NE, bool EXACT, bool PRE, bool CENTER = false>
@@ -410,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             continue;
         }
         float energy = hscale32 * row16_sum(esum);      // E * 2^32
-        energy = energy == 0.f ? kEpsF * kTwo32 : energy;  // zero_handling, feature.rs:219
+        energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
@@ -431,9 +397,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             if (gf < total) {
                 float *row = a.out + static_cast<unsigned long long>(gf) * a.n_filters;
                 const float e0 = m0 * hs, e1 = m1 * hs, e2 = m2 * hs;
-                if (fidx0 >= 0) row[fidx0] = e0 == 0.f ? kEpsF : e0;
-                if (fidx1 >= 0) row[fidx1] = e1 == 0.f ? kEpsF : e1;
-                if (fidx2 >= 0) row[fidx2] = e2 == 0.f ? kEpsF : e2;
+                if (fidx0 >= 0) row[fidx0] = e0 == 0.f ? kEps : e0;
+                if (fidx1 >= 0) row[fidx1] = e1 == 0.f ? kEps : e1;
+                if (fidx2 >= 0) row[fidx2] = e2 == 0.f ? kEps : e2;
                 if (j == 0) {
                     const float en = energy * (1.0f / kTwo32);  // exact: power-of-two scaling
                     a.out_energy[gf] = en;
@@ -450,9 +416,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         if (SYM) {
             // ---- DCT-II with cos(pi c (2(39-m)+1)/80) = (-1)^c cos(pi c (2m+1)/80): natural-order row, then the sum and
             // difference rows once per frame; an even coefficient is a 20-term product with s, an odd one with d ----
-            fr0[0] = ln_scaled(m0 == 0.f ? kEpsF * kTwo32 : m0);
-            fr1[0] = ln_scaled(m1 == 0.f ? kEpsF * kTwo32 : m1);
-            fr2[0] = ln_scaled(m2 == 0.f ? kEpsF * kTwo32 : m2);
+            fr0[0] = ln_scaled(m0 == 0.f ? kEps * kTwo32 : m0);
+            fr1[0] = ln_scaled(m1 == 0.f ? kEps * kTwo32 : m1);
+            fr2[0] = ln_scaled(m2 == 0.f ? kEps * kTwo32 : m2);
             wave_order();
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
@@ -476,9 +442,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 acc = fmaf(rq[i].w, ch[i].w, acc);
             }
         } else {
-        frow[j] = ln_scaled(m0 == 0.f ? kEpsF * kTwo32 : m0);
-        frow[16 + j] = ln_scaled(m1 == 0.f ? kEpsF * kTwo32 : m1);
-        frow[32 + j] = ln_scaled(m2 == 0.f ? kEpsF * kTwo32 : m2);
+        frow[j] = ln_scaled(m0 == 0.f ? kEps * kTwo32 : m0);
+        frow[16 + j] = ln_scaled(m1 == 0.f ? kEps * kTwo32 : m1);
+        frow[32 + j] = ln_scaled(m2 == 0.f ? kEps * kTwo32 : m2);
         wave_order();
 
         // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 48-entry row ----

@@ -17,50 +17,19 @@
 #include "ss_device.h"
 #include "ss_fft_reg.h"
 #include "ss_internal.h"
+#include "ss_wave.h"
 
 namespace ss {
 
 namespace {
 
+using namespace wv;
+
 namespace L = mfcc512w_layout;
-constexpr float kEpsX = 1.1920929e-7f;  // f32::EPSILON, functions.rs:70
-constexpr float kTwo32X = 4294967296.f;
 constexpr int kSlotFloats = 576;        // per frame: exchange slot (288 float2); afterwards P row [260] | ln(mel) row [80]
 constexpr int kWaveFloatsX = 4 * kSlotFloats;
 constexpr int kPRowX = 260;             // bins 0..256 + three zero pad bins
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_x(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-
-// sum over the 16 lanes of a DPP row; every lane ends with the same bits
-__device__ __forceinline__ float row16_sum_x(float v)
-{
-    v += dpp_x<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_x<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_x<0x141>(v);  // row_half_mirror
-    v += dpp_x<0x140>(v);  // row_mirror
-    return v;
-}
-
-__device__ __forceinline__ void wave_order_x()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float bperm_x(int addr, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-}
-
-// ln(x) for a value handed over as x * 2^32 (see ss_mfcc512.hip)
-__device__ __forceinline__ float ln_scaled_x(float xs)
-{
-    return fmaf(__builtin_amdgcn_logf(xs), 0.69314718055994530942f, -32.f * 0.69314718055994530942f);
-}
 
 // q4 float4s of weights against the taps that start at p (any bin): four weight / tap groups per LDS wait
 __device__ __forceinline__ float mel_slot_x(const float4 *w4, const float *p, int q4)
@@ -190,7 +159,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
     const int Cc = static_cast<int>(a.n_ceps), M = static_cast<int>(a.n_filters);
     // |X| = (1/2)|2X|: the 1/2 of the untangle is folded into the scale (1/4 for the squared form)
-    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32X;
+    const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     __syncthreads();
     int st[5], fi[5];
 #pragma unroll
@@ -224,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
         fft16_reg(v);
 #pragma unroll
         for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
-        wave_order_x();
+        wave_order();
         if (next < q_hi) t_next = load_quad_w<NE>(a, next, total, f, j, vin);
         float2 u[16];
 #pragma unroll
@@ -233,7 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
             u[2 * p] = make_float2(t4.x, t4.y);
             u[2 * p + 1] = make_float2(t4.z, t4.w);
         }
-        wave_order_x();
+        wave_order();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const float4 w2 = s_tw2[p * 16 + j];
@@ -245,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         float2 zcs[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm_x(paddr, u[15 - r].x), bperm_x(paddr, u[15 - r].y));
+        for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         float *prow = slot;
         float esum = 0.f;
 #pragma unroll
@@ -276,9 +245,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
             esum += p128;
         }
         if (j < 3) prow[257 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
-        float en = hscale32 * row16_sum_x(esum);        // E * 2^32
-        en = en == 0.f ? kEpsX * kTwo32X : en;          // zero_handling, feature.rs:219
-        wave_order_x();
+        float en = hscale32 * row16_sum(esum);        // E * 2^32
+        en = en == 0.f ? kEps * kTwo32 : en;          // zero_handling, feature.rs:219
+        wave_order();
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
         {
@@ -288,7 +257,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 m[k] = hscale32 * mel_slot_x(w4 + off, prow + st[k], a.mel_q4[k]);
-                m[k] = m[k] == 0.f ? kEpsX * kTwo32X : m[k];
+                m[k] = m[k] == 0.f ? kEps * kTwo32 : m[k];
                 off += a.mel_q4[k];
             }
             const unsigned gf = quad * 4 + f;
@@ -297,13 +266,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
                     float *row = a.out + static_cast<unsigned long long>(gf) * M;
 #pragma unroll
                     for (int k = 0; k < 5; ++k)
-                        if (fi[k] >= 0) row[fi[k]] = m[k] * (1.0f / kTwo32X);  // exact: power of two
-                    if (j == 0) a.out_energy[gf] = en * (1.0f / kTwo32X);
+                        if (fi[k] >= 0) row[fi[k]] = m[k] * (1.0f / kTwo32);  // exact: power of two
+                    if (j == 0) a.out_energy[gf] = en * (1.0f / kTwo32);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) frow[16 * k + j] = ln_scaled_x(m[k]);
-                wave_order_x();
+                for (int k = 0; k < 5; ++k) frow[16 * k + j] = ln_scaled(m[k]);
+                wave_order();
                 // ---- DCT-II, first n_ceps coefficients (feature.rs:120-123): lane c against the 80-entry row ----
                 if (Cc <= 16) {
                     float acc = 0.f;
@@ -325,7 +294,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
                     }
                     // scaling + column-0 replacement (feature.rs:126-146)
                     float o = acc * a.dct_scale_k;
-                    if (j == 0) o = a.dc_elimination ? ln_scaled_x(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                    if (j == 0) o = a.dc_elimination ? ln_scaled(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
                     if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
                 } else {
                     // 17..32 cepstra: the lane also forms coefficient 16 + j from the same row fetches
@@ -353,7 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
                         }
                     }
                     float o = acc * a.dct_scale_k;
-                    if (j == 0) o = a.dc_elimination ? ln_scaled_x(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                    if (j == 0) o = a.dc_elimination ? ln_scaled(en) : acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
                     if (gf < total) {
                         a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
                         if (16 + j < Cc) a.out[static_cast<unsigned long long>(gf) * Cc + 16 + j] = acc2 * a.dct_scale_k;
@@ -361,7 +330,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
                 }
             }
         }
-        wave_order_x();
+        wave_order();
         quad = next;
     }
 }
