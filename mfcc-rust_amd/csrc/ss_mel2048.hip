@@ -35,36 +35,6 @@ namespace L = mel2048_layout;
 constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
-// One mel slot: q4 aligned float4s of weights against the same span of the P row (the host rounds a filter's first bin down
-// to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip per four taps.
-__device__ __forceinline__ float mel_slot(const float4 *w4, const float4 *p4, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 4 <= q4; i += 4) {
-        float4 w[4], t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w[u] = w4[i + u];
-            t[u] = p4[i + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = fmaf(w[u].x, t[u].x, acc);
-            acc = fmaf(w[u].y, t[u].y, acc);
-            acc = fmaf(w[u].z, t[u].z, acc);
-            acc = fmaf(w[u].w, t[u].w, acc);
-        }
-    }
-    for (; i < q4; ++i) {
-        const float4 w = w4[i], t = p4[i];
-        acc = fmaf(w.x, t.x, acc);
-        acc = fmaf(w.y, t.y, acc);
-        acc = fmaf(w.z, t.z, acc);
-        acc = fmaf(w.w, t.w, acc);
-    }
-    return acc;
-}
 
 template <int kWavesM, bool STFT>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
@@ -274,7 +244,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     int off = 0;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float m = mel_slot(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                        const float m = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                         off += a.mel_q4[s];
                     }

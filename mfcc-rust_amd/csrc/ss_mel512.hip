@@ -30,37 +30,6 @@ namespace L = mel512_layout;
 constexpr int kSlotFloatsE = 576;  // per row: exchange slot (288 float2); afterwards the P row [260]
 constexpr int kWaveFloatsE = 4 * kSlotFloatsE;
 
-// q4 float4s of weights against the taps that start at p (any bin): two weight / tap groups per LDS wait
-__device__ __forceinline__ float mel_slot_e(const float4 *w4, const float *p, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 2 <= q4; i += 2) {
-        const float4 w0 = w4[i], w1 = w4[i + 1];
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[4 * i + u];
-        acc = fmaf(w0.x, t[0], acc);
-        acc = fmaf(w0.y, t[1], acc);
-        acc = fmaf(w0.z, t[2], acc);
-        acc = fmaf(w0.w, t[3], acc);
-        acc = fmaf(w1.x, t[4], acc);
-        acc = fmaf(w1.y, t[5], acc);
-        acc = fmaf(w1.z, t[6], acc);
-        acc = fmaf(w1.w, t[7], acc);
-    }
-    if (i < q4) {
-        const float4 w0 = w4[i];
-        float t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = p[4 * i + u];
-        acc = fmaf(w0.x, t[0], acc);
-        acc = fmaf(w0.y, t[1], acc);
-        acc = fmaf(w0.z, t[2], acc);
-        acc = fmaf(w0.w, t[3], acc);
-    }
-    return acc;
-}
 
 template <int WAVES, bool STFT>
 __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
@@ -242,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
                 if (a.mel_q4[s] == 0) break;
-                const float m = mel_slot_e(w4 + off, prow + st[s], a.mel_q4[s]);
+                const float m = mel_slot1(w4 + off, prow + st[s], a.mel_q4[s]);
                 if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                 off += a.mel_q4[s];
             }

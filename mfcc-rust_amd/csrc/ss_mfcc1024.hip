@@ -40,35 +40,6 @@ __device__ __forceinline__ void swap_rows(float &a, float &b)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-__device__ __forceinline__ float mel_slot_k(const float4 *w4, const float4 *p4, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 4 <= q4; i += 4) {
-        float4 w[4], t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w[u] = w4[i + u];
-            t[u] = p4[i + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = fmaf(w[u].x, t[u].x, acc);
-            acc = fmaf(w[u].y, t[u].y, acc);
-            acc = fmaf(w[u].z, t[u].z, acc);
-            acc = fmaf(w[u].w, t[u].w, acc);
-        }
-    }
-    for (; i < q4; ++i) {
-        const float4 w = w4[i], t = p4[i];
-        acc = fmaf(w.x, t.x, acc);
-        acc = fmaf(w.y, t.y, acc);
-        acc = fmaf(w.z, t.z, acc);
-        acc = fmaf(w.w, t.w, acc);
-    }
-    return acc;
-}
-
 template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 {
@@ -259,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float m = hscale32 * mel_slot_k(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                float m = hscale32 * mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {
                     if (MFE) {
@@ -504,7 +475,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float m = mel_slot_k(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                const float m = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                 off += a.mel_q4[s];
             }

@@ -33,36 +33,6 @@ constexpr int kHalfFloatsLib = 1288;           // LIB: P row [1028] | ln(mel) ro
 template <bool LIB> constexpr int wave_floats() { return LIB ? 2 * kHalfFloatsLib : kWaveFloatsG; }
 
 
-__device__ __forceinline__ float mel_slot_g(const float4 *w4, const float4 *p4, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 4 <= q4; i += 4) {
-        float4 w[4], t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w[u] = w4[i + u];
-            t[u] = p4[i + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = fmaf(w[u].x, t[u].x, acc);
-            acc = fmaf(w[u].y, t[u].y, acc);
-            acc = fmaf(w[u].z, t[u].z, acc);
-            acc = fmaf(w[u].w, t[u].w, acc);
-        }
-    }
-    for (; i < q4; ++i) {
-        const float4 w = w4[i], t = p4[i];
-        acc = fmaf(w.x, t.x, acc);
-        acc = fmaf(w.y, t.y, acc);
-        acc = fmaf(w.z, t.z, acc);
-        acc = fmaf(w.w, t.w, acc);
-    }
-    return acc;
-}
-
-
 template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a)
 {
@@ -250,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float m = hscale32 * mel_slot_g(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                float m = hscale32 * mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {
                     if (MFE) {

@@ -38,37 +38,6 @@ constexpr int kPRowX = 132;             // bins 0..128 + three zero pad bins
 constexpr float kPairGuard = 1000.f;    // energy ratio (30 dB) beyond which the two frames of a pair are transformed one at a time
 
 
-// q4 float4s of weights against the taps that start at p (any bin): four weight / tap groups per LDS wait
-__device__ __forceinline__ float mel_slot_x(const float4 *w4, const float *p, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 2 <= q4; i += 2) {
-        const float4 w0 = w4[i], w1 = w4[i + 1];
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[4 * i + u];
-        acc = fmaf(w0.x, t[0], acc);
-        acc = fmaf(w0.y, t[1], acc);
-        acc = fmaf(w0.z, t[2], acc);
-        acc = fmaf(w0.w, t[3], acc);
-        acc = fmaf(w1.x, t[4], acc);
-        acc = fmaf(w1.y, t[5], acc);
-        acc = fmaf(w1.z, t[6], acc);
-        acc = fmaf(w1.w, t[7], acc);
-    }
-    if (i < q4) {
-        const float4 w0 = w4[i];
-        float t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = p[4 * i + u];
-        acc = fmaf(w0.x, t[0], acc);
-        acc = fmaf(w0.y, t[1], acc);
-        acc = fmaf(w0.z, t[2], acc);
-        acc = fmaf(w0.w, t[3], acc);
-    }
-    return acc;
-}
 
 // Issues the loads of one oct: vin[e] = (a[n], b[n]), n = j + 16 e, of this lane group's frame pair (zero beyond flen,
 // processing.rs:147-156).  Returns the pair's frame indices within their clips in tA / tB.
@@ -271,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             int off = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                m[k] = hscale32 * mel_slot_x(w4 + off, pr + st[k], a.mel_q4[k]);
+                m[k] = hscale32 * mel_slot1(w4 + off, pr + st[k], a.mel_q4[k]);
                 m[k] = m[k] == 0.f ? kEps * kTwo32 : m[k];
                 off += a.mel_q4[k];
             }

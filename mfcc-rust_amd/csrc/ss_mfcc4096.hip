@@ -46,36 +46,6 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
 }
 
 
-// One mel slot: q4 aligned float4s of weights against the same span of the P row (the host rounds a filter's first bin down
-// to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip per four taps.
-__device__ __forceinline__ float mel_slot_h(const float4 *w4, const float4 *p4, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 4 <= q4; i += 4) {
-        float4 w[4], t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w[u] = w4[i + u];
-            t[u] = p4[i + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = fmaf(w[u].x, t[u].x, acc);
-            acc = fmaf(w[u].y, t[u].y, acc);
-            acc = fmaf(w[u].z, t[u].z, acc);
-            acc = fmaf(w[u].w, t[u].w, acc);
-        }
-    }
-    for (; i < q4; ++i) {
-        const float4 w = w4[i], t = p4[i];
-        acc = fmaf(w.x, t.x, acc);
-        acc = fmaf(w.y, t.y, acc);
-        acc = fmaf(w.z, t.z, acc);
-        acc = fmaf(w.w, t.w, acc);
-    }
-    return acc;
-}
 
 template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
@@ -282,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float m = hscale32 * mel_slot_h(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                float m = hscale32 * mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
                     if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32);  // exact: power of two
@@ -541,7 +511,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float m = mel_slot_h(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                const float m = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                 if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                 off += a.mel_q4[s];
             }

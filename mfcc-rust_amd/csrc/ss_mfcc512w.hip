@@ -31,37 +31,6 @@ constexpr int kWaveFloatsX = 4 * kSlotFloats;
 constexpr int kPRowX = 260;             // bins 0..256 + three zero pad bins
 
 
-// q4 float4s of weights against the taps that start at p (any bin): four weight / tap groups per LDS wait
-__device__ __forceinline__ float mel_slot_x(const float4 *w4, const float *p, int q4)
-{
-    float acc = 0.f;
-    int i = 0;
-    for (; i + 2 <= q4; i += 2) {
-        const float4 w0 = w4[i], w1 = w4[i + 1];
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[4 * i + u];
-        acc = fmaf(w0.x, t[0], acc);
-        acc = fmaf(w0.y, t[1], acc);
-        acc = fmaf(w0.z, t[2], acc);
-        acc = fmaf(w0.w, t[3], acc);
-        acc = fmaf(w1.x, t[4], acc);
-        acc = fmaf(w1.y, t[5], acc);
-        acc = fmaf(w1.z, t[6], acc);
-        acc = fmaf(w1.w, t[7], acc);
-    }
-    if (i < q4) {
-        const float4 w0 = w4[i];
-        float t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = p[4 * i + u];
-        acc = fmaf(w0.x, t[0], acc);
-        acc = fmaf(w0.y, t[1], acc);
-        acc = fmaf(w0.z, t[2], acc);
-        acc = fmaf(w0.w, t[3], acc);
-    }
-    return acc;
-}
 
 // Issues the loads of one quad: vin[e] = (x[2n], x[2n+1]), n = j + 16 e, of this lane group's frame (zero beyond flen,
 // processing.rs:147-156).  Returns the frame's index within its clip.
@@ -256,7 +225,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
             int off = 0;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                m[k] = hscale32 * mel_slot_x(w4 + off, prow + st[k], a.mel_q4[k]);
+                m[k] = hscale32 * mel_slot1(w4 + off, prow + st[k], a.mel_q4[k]);
                 m[k] = m[k] == 0.f ? kEps * kTwo32 : m[k];
                 off += a.mel_q4[k];
             }

@@ -61,5 +61,69 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// One mel slot of a lane: q4 float4s of weights against the same span of the P row, both 16-byte aligned (the host rounds a
+// filter's first bin down to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip
+// per four taps.
+__device__ __forceinline__ float mel_slot4(const float4 *w4, const float4 *p4, int q4)
+{
+    float acc = 0.f;
+    int i = 0;
+    for (; i + 4 <= q4; i += 4) {
+        float4 w[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = w4[i + u];
+            t[u] = p4[i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = fmaf(w[u].x, t[u].x, acc);
+            acc = fmaf(w[u].y, t[u].y, acc);
+            acc = fmaf(w[u].z, t[u].z, acc);
+            acc = fmaf(w[u].w, t[u].w, acc);
+        }
+    }
+    for (; i < q4; ++i) {
+        const float4 w = w4[i], t = p4[i];
+        acc = fmaf(w.x, t.x, acc);
+        acc = fmaf(w.y, t.y, acc);
+        acc = fmaf(w.z, t.z, acc);
+        acc = fmaf(w.w, t.w, acc);
+    }
+    return acc;
+}
+
+// Same for a P row span that starts at any bin (the taps load as single words): two weight / tap groups per LDS wait.
+__device__ __forceinline__ float mel_slot1(const float4 *w4, const float *p, int q4)
+{
+    float acc = 0.f;
+    int i = 0;
+    for (; i + 2 <= q4; i += 2) {
+        const float4 w0 = w4[i], w1 = w4[i + 1];
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[4 * i + u];
+        acc = fmaf(w0.x, t[0], acc);
+        acc = fmaf(w0.y, t[1], acc);
+        acc = fmaf(w0.z, t[2], acc);
+        acc = fmaf(w0.w, t[3], acc);
+        acc = fmaf(w1.x, t[4], acc);
+        acc = fmaf(w1.y, t[5], acc);
+        acc = fmaf(w1.z, t[6], acc);
+        acc = fmaf(w1.w, t[7], acc);
+    }
+    if (i < q4) {
+        const float4 w0 = w4[i];
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = p[4 * i + u];
+        acc = fmaf(w0.x, t[0], acc);
+        acc = fmaf(w0.y, t[1], acc);
+        acc = fmaf(w0.z, t[2], acc);
+        acc = fmaf(w0.w, t[3], acc);
+    }
+    return acc;
+}
+
 }  // namespace wv
 }  // namespace ss
