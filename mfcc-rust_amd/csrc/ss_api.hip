@@ -476,6 +476,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.real_rows = a.real_rows;
         m.scale = a.scale;
         m.tab = cfg->d_mel2048_tab;
+        m.fullp = cfg->mel2048.fullp;
         m.mel_wpitch = cfg->mel2048.wpitch;
         for (int s = 0; s < 4; ++s) m.mel_q4[s] = cfg->mel2048.q4[s];
         m.n_filters = a.n_filters;

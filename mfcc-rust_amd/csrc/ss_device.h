@@ -153,7 +153,7 @@ struct Mel2048Args {
     uint32_t n_filters;
     float *out;       // [batch][n_filters][rows], or (out_stft) [batch][rows][1025][2]
     int32_t out_stft; // 1: write the scaled complex spectrum stft2 returns (functions.rs:86-123) instead of the mel rows
-    int32_t fullp;    // 1024-point kernel only: the bank reaches past (F+1)/2, P rows hold every bin
+    int32_t fullp;    // the bank reaches past (F+1)/2: P rows hold every bin (not in the 4096-point kernel)
 };
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

@@ -686,8 +686,9 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
     f = Mel2048Tables{};
     const size_t M = t.params.num_filters;
     if (t.d.n_fft != 2048 || !t.d.stft_ok || M > 128) return;
-    if (t.bank.last_bin > 513) return;  // the kernel keeps P bins 0..512 (the bank ends at (F+1)/2 when high = sr/2)
-    constexpr int32_t kRow = 516;       // P bins a tap may touch: 0..512 plus three zero pad bins
+    if (t.bank.last_bin > 1025) return;
+    f.fullp = t.bank.last_bin > 513;  // reference banks end at (F+1)/2 (P bins 0..512); others get rows of all 1025 bins
+    const int32_t kRow = f.fullp ? 1028 : 516;  // P bins a tap may touch, including three zero pad bins
     std::vector<int32_t> order(M);
     for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
     // taps are read as aligned float4s of the P row: a filter's span starts at its first bin rounded down to a multiple of 4

@@ -118,6 +118,7 @@ constexpr int kPRow = 520;               // floats per P row: bins 0..512 + zero
 
 struct Mel2048Tables {
     bool ok = false;
+    bool fullp = false;      // the bank reaches past bin 512: P rows of all 1025 bins
     bool stft_only = false;  // the bank does not fit the kernel's mel stage: the block serves the stft build only
     std::vector<float> tab;
     int32_t q4[4] = {0, 0, 0, 0};

@@ -36,7 +36,7 @@ constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange re
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
 
-template <int kWavesM, bool STFT>
+template <int kWavesM, bool STFT, bool FULLP = false>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
     constexpr bool PREFETCH_M = kWavesM <= 8;  // the next unit's samples are requested while the current one is in its second pass
@@ -50,7 +50,9 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     // ---- LDS carve: per-wave regions | table block | unit counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsM;
     float2 *ex = reinterpret_cast<float2 *>(wbase);                 // exchange region (one frame at a time)
-    float *prow = wbase + half * L::kPRow;                          // P[0..512] + zero pad bins, after the exchange
+    // P[0..512] + zero pad bins, after the exchange; all 1025 bins when the bank reaches past (F+1)/2 (two rows of 1028 still
+    // fit the region)
+    float *prow = wbase + half * (FULLP ? 1088 : L::kPRow);
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
@@ -218,6 +220,10 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                             }
                         } else {
                             prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
+                            if (FULLP) {  // bins 513..1024 as well
+                                const float yr = fmaf(2.f, s.x, -xr), yi = fmaf(2.f, s.y, -xi);
+                                prow[1024 - j - 32 * q] = hs * (yr * yr + yi * yi);
+                            }
                         }
                     }
                 }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     unit = next;
                     continue;
                 }
-                if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
+                if (j < 3) prow[(FULLP ? 1025 : 513) + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
                 wave_order();
                 // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are
                 //      adjacent words of out[clip][m][.] ----
@@ -275,7 +281,9 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
         return hipGetLastError();
     };
-    return a.out_stft ? go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>") : go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
+    if (a.out_stft) return go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>");
+    if (a.fullp) return go(ss_mel_c1024<kWavesM, false, true>, "ss_mel_c1024<fullp>");
+    return go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
 }
 
 }  // namespace

@@ -181,6 +181,24 @@ def test_mel_spectrogram_1024_kernel(ss, oracle, sslib):
         np.testing.assert_array_equal(one, got[2])
 
 
+def test_mel_spectrogram_2048_full_spectrum_bank(ss, oracle, sslib):
+    """mel_spectrogram at fft_points = 2048 with banks that reach past (F+1)/2 (Slaney / HTK scale up to fs/2): the fullp build of
+    the cfg3 kernel keeps all 1025 bins of a row."""
+    import torch
+
+    sr = 22050
+    x = _signal(47, (4, sr))
+    for sw, M in ((dict(mel_scale="slaney", mel_norm="slaney"), 128), (dict(mel_scale="htk"), 64)):
+        kw = dict(frame_length=512 / sr, frame_stride=512 / sr, num_filters=M, fft_length=2048)
+        got = ss.mel_spectrogram(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<fullp>", sslib.ss_last_kernel_name()
+        p = oracle.make_params(sample_rate=sr, fft_points=2048, frame_length=512 / sr, frame_stride=512 / sr, num_filters=M, **sw)
+        want = oracle.mel_spectrogram(p, x)
+        assert got.shape == want.shape
+        for b in range(4):
+            assert _rel(got[b], want[b]) <= RTOL, (sw, b)
+
+
 def test_mel_spectrogram_4096_kernel(ss, oracle, sslib):
     """mel_spectrogram at fft_points = 4096 (44.1 kHz, 1024- and 2048-sample chunks, 256 / 128 / 100 mels): one row per wave on
     the 4096-point FFT mapping; partial last chunks, clips shorter than a window."""
