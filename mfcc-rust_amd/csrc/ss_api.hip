@@ -217,10 +217,13 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.dct_scale_00 = a.dct_scale_00;
         f.dc_elimination = a.dc_elimination;
         f.out = out0;
-        hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256_mx");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
+        if (e == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mfcc_c256_mx");
     }
     if (fast_ok && fits32) {
         ss::Fast512Args f{};
@@ -275,19 +278,23 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             }
             f.dbg = nullptr;
         }
-        hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mfcc_c256");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
+        if (e == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mfcc_c256");
     }
     // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra, and the output / window / framing combinations the
-    // headline kernel has no build for (ss_mfcc512w.hip): optional frame window, centred frames, no fused pre-emphasis
+    // headline kernel has no build for (ss_mfcc512w.hip): optional frame window, centred frames, fused pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
-        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) &&
-        a.preemph == 0.0f) {
+        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0))) {
         ss::Mfcc256Args f{};
         f.center = centre;
         f.pad_reflect = a.pad_reflect;
+        f.preemph = a.preemph;
+        f.preemph_shift = a.preemph_shift;
         f.x = d_x;
         f.ld = ld;
         f.n_samples = a.n_samples;
@@ -310,16 +317,20 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out_mfe = out_kind == ss::OUT_MFE;
         f.out = out0;
         f.out_energy = out1;
-        hipError_t e5 = ss::launch_mfcc_c256w(f, stream, cfg->num_cus, &info);
-        if (e5 != hipSuccess) return hip_fail(e5, "launch_mfcc_c256w");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e5 = ss::launch_mfcc_c256w(f, stream, cfg->num_cus, &info);
+        if (e5 == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e5 != hipErrorInvalidValue) return hip_fail(e5, "launch_mfcc_c256w");
     }
-    // fft_points = 256 MFCC / mfe: two frames per complex transform (ss_mfcc256.hip); scalar sample loads, so no alignment
-    // assumptions; optional frame window, no fused pre-emphasis
+    // fft_points = 256 MFCC / mfe: two frames per complex transform (ss_mfcc256.hip); optional frame window, fused pre-emphasis
     if (!force_generic && cfg->mfcc256.ok && static_cast<unsigned long long>(batch) * T + 8 < 0x7fffffffull &&
-        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL && a.preemph == 0.0f && a.flen <= 256) {
+        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL && a.flen <= 256) {
         ss::Mfcc256Args f{};
+        f.preemph = a.preemph;
+        f.preemph_shift = a.preemph_shift;
         f.x = d_x;
         f.ld = ld;
         f.n_samples = a.n_samples;
@@ -342,16 +353,21 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out_mfe = out_kind == ss::OUT_MFE;
         f.out = out0;
         f.out_energy = out1;
-        hipError_t e3 = ss::launch_mfcc_c256x2(f, stream, cfg->num_cus, &info);
-        if (e3 != hipSuccess) return hip_fail(e3, "launch_mfcc_c256x2");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e3 = ss::launch_mfcc_c256x2(f, stream, cfg->num_cus, &info);
+        if (e3 == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e3 != hipErrorInvalidValue) return hip_fail(e3, "launch_mfcc_c256x2");
     }
     // fft_points = 2048 / 1024 MFCC / mfe: two frames per wave (ss_mfcc2048.hip, ss_mfcc1024.hip), optional frame window
     // (both have librosa-compatible builds: centred frames with flen % 4 == 0, banks up to fs/2)
     if (!force_generic && (cfg->mfcc2048.ok || cfg->mfcc1024.ok) && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
-        (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0)) && a.preemph == 0.0f) {
+        (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0))) {
         ss::Mfcc2048Args f{};
+        f.preemph = a.preemph;
+        f.preemph_shift = a.preemph_shift;
         f.x = d_x;
         f.ld = ld;
         f.n_samples = a.n_samples;
@@ -378,15 +394,19 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.fullp = k2048 ? cfg->mfcc2048.fullp : cfg->mfcc1024.fullp;
         f.out = out0;
         f.out_energy = out1;
-        hipError_t e2 = k2048 ? ss::launch_mfcc_c1024(f, stream, cfg->num_cus, &info) : ss::launch_mfcc_c512(f, stream, cfg->num_cus, &info);
-        if (e2 != hipSuccess) return hip_fail(e2, k2048 ? "launch_mfcc_c1024" : "launch_mfcc_c512");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e2 = k2048 ? ss::launch_mfcc_c1024(f, stream, cfg->num_cus, &info) : ss::launch_mfcc_c512(f, stream, cfg->num_cus, &info);
+        if (e2 == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e2 != hipErrorInvalidValue) return hip_fail(e2, k2048 ? "launch_mfcc_c1024" : "launch_mfcc_c512");
     }
-    // fft_points = 4096 MFCC / mfe (even filter count up to 256): the one-frame-per-wave kernel
-    if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL &&
-        a.preemph == 0.0f) {
+    // fft_points = 4096 MFCC / mfe (up to 256 filters): the one-frame-per-wave kernel
+    if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL) {
         ss::Mfcc4096Args f{};
+        f.preemph = a.preemph;
+        f.preemph_shift = a.preemph_shift;
         f.x = d_x;
         f.ld = ld;
         f.n_samples = a.n_samples;
@@ -411,9 +431,11 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.window = a.window;
         static const char *rows_path = std::getenv("SS_DEBUG_ROWS");  // diagnostic only: frame 0's P row and ln(mel) row
         if (rows_path) (void)hipMalloc(reinterpret_cast<void **>(&f.dbg), (1028 + 256 + 4 * 4096) * sizeof(float));
-        hipError_t e4 = ss::launch_mfcc_c2048(f, stream, cfg->num_cus, &info);
-        if (e4 != hipSuccess) return hip_fail(e4, "launch_mfcc_c2048");
-        if (f.dbg) {
+        const hipError_t e4 = ss::launch_mfcc_c2048(f, stream, cfg->num_cus, &info);
+        if (e4 != hipSuccess && f.dbg) (void)hipFree(f.dbg);
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> generic kernel
+        if (e4 != hipSuccess && e4 != hipErrorInvalidValue) return hip_fail(e4, "launch_mfcc_c2048");
+        if (e4 == hipSuccess && f.dbg) {
             std::vector<float> rows(1028 + 256 + 4 * 4096);
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(rows.data(), f.dbg, rows.size() * sizeof(float), hipMemcpyDeviceToHost);
@@ -423,8 +445,10 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
                 std::fclose(fp);
             }
         }
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        if (e4 == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
     }
     hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
     if (e != hipSuccess) return hip_fail(e, "launch_front_generic");
@@ -482,10 +506,13 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.n_filters = a.n_filters;
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
-        hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mel_c1024");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
+        if (e == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mel_c1024");
     }
     // fft_points = 512 mel spectrogram: four rows per wave (ss_mel512.hip), same layout assumptions
     if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel512.ok || (want_stft && cfg->mel512.stft_only)) &&
@@ -507,10 +534,13 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.n_filters = a.n_filters;
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
-        hipError_t e = ss::launch_mel_c256(m, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, "launch_mel_c256");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e = ss::launch_mel_c256(m, stream, cfg->num_cus, &info);
+        if (e == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mel_c256");
     }
     // fft_points = 1024 / 4096 mel spectrogram: two rows / one row per wave (ss_mel_c512 in ss_mfcc1024.hip, ss_mel_c2048 in
     // ss_mfcc4096.hip), same layout assumptions
@@ -535,10 +565,13 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.n_filters = a.n_filters;
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
-        hipError_t e = k1024 ? ss::launch_mel_c512(m, stream, cfg->num_cus, &info) : ss::launch_mel_c2048(m, stream, cfg->num_cus, &info);
-        if (e != hipSuccess) return hip_fail(e, k1024 ? "launch_mel_c512" : "launch_mel_c2048");
-        g_last_kernel = info.kernel_name;
-        return SS_OK;
+        const hipError_t e = k1024 ? ss::launch_mel_c512(m, stream, cfg->num_cus, &info) : ss::launch_mel_c2048(m, stream, cfg->num_cus, &info);
+        if (e == hipSuccess) {
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
+        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
+        if (e != hipErrorInvalidValue) return hip_fail(e, k1024 ? "launch_mel_c512" : "launch_mel_c2048");
     }
     hipError_t e = ss::launch_front_generic(a, h.d.log2c, stream, cfg->num_cus, &info);
     if (e != hipSuccess) return hip_fail(e, "launch_front_generic");

@@ -199,6 +199,8 @@ struct Mfcc2048Args {
     int32_t center;      // librosa center=True framing
     int32_t pad_reflect; // np.pad 'reflect' (else zeros) outside the clip for centred frames
     int32_t fullp;       // the bank reaches past the reference's (F+1)/2: P rows hold every bin up to fft_points/2
+    float preemph;       // fused pre-emphasis coefficient (0 = off) and shift (processing.rs:31-53)
+    uint32_t preemph_shift;
     float *out;
     float *out_energy;
 };
@@ -226,6 +228,8 @@ struct Mfcc256Args {
     int32_t out_mfe;     // 1: write mfe's (features, energy) instead of the cepstra
     int32_t center;      // wide-bank 512-point kernel only: librosa center=True framing (flen % 4 == 0)
     int32_t pad_reflect; // np.pad 'reflect' (else zeros) outside the clip for centred frames
+    float preemph;       // fused pre-emphasis coefficient (0 = off) and shift (processing.rs:31-53)
+    uint32_t preemph_shift;
     uint32_t nf_magic, nf_shift;  // set by the launcher: frame -> (clip, t) by multiply-high
     float *out;
     float *out_energy;
@@ -248,6 +252,8 @@ struct Mfcc4096Args {
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;
+    float preemph;       // fused pre-emphasis coefficient (0 = off) and shift (processing.rs:31-53)
+    uint32_t preemph_shift;
     float *out;          // MFCC [frames x n_ceps], or (out_mfe) mel energies [frames x n_filters]
     float *out_energy;   // out_mfe: frame energies [frames]
     int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)

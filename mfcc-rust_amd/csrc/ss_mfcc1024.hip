@@ -94,6 +94,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
     const int e_hi = min(16, max(0, (static_cast<int>(a.flen) / 2 - jj + 31) >> 5));
     const int half_pairs = static_cast<int>(a.flen) / 2;
     const bool odd_tail = (a.flen & 1) != 0;
+    const bool pre = a.preemph != 0.f;  // fused pre-emphasis (run-time: a uniform branch in the loader)
+    const unsigned psh = a.preemph_shift % a.n_samples;
 
     unsigned unit = u_lo + wave;
     while (unit < u_hi) {
@@ -121,6 +123,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
                 if (e < e_hi) s = src[32 * e];
                 // odd frame length: the last sample is the first half of a pair (its partner is zero padding)
                 if (odd_tail && jj + 32 * e == half_pairs) s = make_float2(xc[s0 + 2 * half_pairs], 0.f);
+                if (pre) {  // fused pre-emphasis (processing.rs:31-53) of the samples that exist
+                    const int pos = s0 + 2 * (jj + 32 * e), rem = static_cast<int>(a.flen) - 2 * (jj + 32 * e);
+                    if (rem >= 1) s.x = fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), s.x);
+                    if (rem >= 2) s.y = fmaf(-a.preemph, preemph_tap(xc, pos + 1, psh, a.n_samples), s.y);
+                }
                 v[e] = s;
             }
         } else {
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
                             if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                             else ok = false;
                         }
-                        if (ok) sv[hh] = xc[pos];
+                        if (ok) sv[hh] = pre ? fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), xc[pos]) : xc[pos];
                     }
                 }
                 v[e] = make_float2(sv[0], sv[1]);

@@ -33,7 +33,7 @@ constexpr int kHalfFloatsLib = 1288;           // LIB: P row [1028] | ln(mel) ro
 template <bool LIB> constexpr int wave_floats() { return LIB ? 2 * kHalfFloatsLib : kWaveFloatsG; }
 
 
-template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false>
+template <bool POW2, bool MFE, bool WIN, int WAVES, bool LIB = false, bool PRE = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -82,6 +82,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
     const int e_hi = min(32, max(0, (static_cast<int>(a.flen) / 2 - j + 31) >> 5));
     const int half_pairs = static_cast<int>(a.flen) / 2;
     const bool odd_tail = (a.flen & 1) != 0;
+    constexpr bool pre = PRE;  // fused pre-emphasis: builds of their own (LIB layout: they also serve centred frames)
+    const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
     unsigned unit = u_lo + wave;
     while (unit < u_hi) {
@@ -109,6 +111,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                 if (e < e_hi) s = src[32 * e];
                 // odd frame length: the last sample is the first half of a pair (its partner is zero padding)
                 if (odd_tail && j + 32 * e == half_pairs) s = make_float2(xc[s0 + 2 * half_pairs], 0.f);
+                if (pre) {  // fused pre-emphasis (processing.rs:31-53) of the samples that exist
+                    const int pos = s0 + 2 * (j + 32 * e), rem = static_cast<int>(a.flen) - 2 * (j + 32 * e);
+                    if (rem >= 1) s.x = fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), s.x);
+                    if (rem >= 2) s.y = fmaf(-a.preemph, preemph_tap(xc, pos + 1, psh, a.n_samples), s.y);
+                }
                 v[e] = s;
             }
         } else {
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
                             if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                             else ok = false;
                         }
-                        if (ok) sv[h] = xc[pos];
+                        if (ok) sv[h] = pre ? fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), xc[pos]) : xc[pos];
                     }
                 }
                 v[e] = make_float2(sv[0], sv[1]);
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
 template <int WAVES>
 hipError_t launch_g(const Mfcc2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const bool lib = a.center != 0 || a.fullp != 0;
+    const bool lib = a.center != 0 || a.fullp != 0 || a.preemph != 0.f;  // the pre-emphasis builds use the LIB layout
     const size_t lds = (static_cast<size_t>(WAVES) * (lib ? wave_floats<true>() : wave_floats<false>()) + L::kMelW + 32 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
@@ -302,6 +309,16 @@ hipError_t launch_g(const Mfcc2048Args &a, hipStream_t stream, int num_cus, Laun
     };
     const bool pow2 = a.spectrum_exponent == 2, win = a.windowed != 0;
 #define SS_G(P, M, W, LB, NAME) go(ss_mfcc_c1024<P, M, W, WAVES, LB>, NAME)
+#define SS_GP(P, M, W, NAME) go(ss_mfcc_c1024<P, M, W, WAVES, true, true>, NAME)
+    if (a.preemph != 0.f) {
+        if (a.out_mfe) {
+            if (pow2) return win ? SS_GP(true, true, true, "ss_mfcc_c1024<pow2,mfe,win,lib,pre>") : SS_GP(true, true, false, "ss_mfcc_c1024<pow2,mfe,lib,pre>");
+            return win ? SS_GP(false, true, true, "ss_mfcc_c1024<mfe,win,lib,pre>") : SS_GP(false, true, false, "ss_mfcc_c1024<mfe,lib,pre>");
+        }
+        if (pow2) return win ? SS_GP(true, false, true, "ss_mfcc_c1024<pow2,win,lib,pre>") : SS_GP(true, false, false, "ss_mfcc_c1024<pow2,lib,pre>");
+        return win ? SS_GP(false, false, true, "ss_mfcc_c1024<win,lib,pre>") : SS_GP(false, false, false, "ss_mfcc_c1024<lib,pre>");
+    }
+#undef SS_GP
     if (lib) {
         if (a.out_mfe) {
             if (pow2) return win ? SS_G(true, true, true, true, "ss_mfcc_c1024<pow2,mfe,win,lib>") : SS_G(true, true, false, true, "ss_mfcc_c1024<pow2,mfe,lib>");

@@ -46,8 +46,10 @@ __device__ __forceinline__ void load_oct(const Mfcc256Args &a, unsigned oct, uns
                                          unsigned &tB)
 {
     const unsigned o8 = oct * 8;  // uniform
-    const float *src[2];
+    const float *src[2], *xcl[2];
     unsigned tt[2];
+    const bool pre = a.preemph != 0.f;  // fused pre-emphasis: the caller then loads at the top of the loop (no prefetch)
+    const unsigned sh = a.preemph_shift % a.n_samples;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const unsigned fl = min(static_cast<unsigned>(2 * f + s), total - 1 - o8);  // lanes past the last frame redo it
@@ -65,13 +67,18 @@ __device__ __forceinline__ void load_oct(const Mfcc256Args &a, unsigned oct, uns
             t = gf - clip * a.n_frames;
         }
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
-        src[s] = a.x + static_cast<unsigned long long>(clip) * a.ld + static_cast<unsigned long long>(t) * a.step + j;
+        xcl[s] = a.x + static_cast<unsigned long long>(clip) * a.ld;
+        src[s] = xcl[s] + static_cast<unsigned long long>(t) * a.step + j;
         tt[s] = t;
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const bool in = j + 16 * e < static_cast<int>(a.flen);
         vin[e] = in ? make_float2(src[0][16 * e], src[1][16 * e]) : make_float2(0.f, 0.f);
+        if (pre && in) {
+            vin[e].x = fmaf(-a.preemph, preemph_tap(xcl[0], static_cast<int>(tt[0] * a.step) + j + 16 * e, sh, a.n_samples), vin[e].x);
+            vin[e].y = fmaf(-a.preemph, preemph_tap(xcl[1], static_cast<int>(tt[1] * a.step) + j + 16 * e, sh, a.n_samples), vin[e].y);
+        }
     }
     tA = tt[0];
     tB = tt[1];
@@ -110,7 +117,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
     unsigned oct = o_lo + wave;
     float2 vin[NE];
     unsigned tA_next = 0, tB_next = 0;
-    if (oct < o_hi) load_oct<NE>(a, oct, total, f, j, vin, tA_next, tB_next);
+    const bool pre = a.preemph != 0.f;  // pre-emphasised samples are formed at load time: no prefetch across the iteration then
+    if (!pre && oct < o_hi) load_oct<NE>(a, oct, total, f, j, vin, tA_next, tB_next);
 
     const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);
         next = __builtin_amdgcn_readfirstlane(next);
+        if (pre) load_oct<NE>(a, oct, total, f, j, vin, tA_next, tB_next);
         const unsigned tA = tA_next, tB = tB_next;
 
         // Guard of the two-for-one transform: its rounding error is relative to the LOUDER frame of a pair, so a frame of
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
 #pragma unroll
         for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         wave_order();
-        if (pass == npass - 1 && next < o_hi) load_oct<NE>(a, next, total, f, j, vin, tA_next, tB_next);  // the input registers are dead now
+        if (!pre && pass == npass - 1 && next < o_hi) load_oct<NE>(a, next, total, f, j, vin, tA_next, tB_next);  // the input registers are dead now
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {

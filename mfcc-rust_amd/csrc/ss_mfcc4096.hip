@@ -47,7 +47,7 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
 
 
 
-template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false>
+template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,6 +101,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
     const bool k1z = k1 == 0;
     const int M = static_cast<int>(a.n_filters), Mh = M / 2;
+    constexpr bool pre = PRE;  // fused pre-emphasis: builds of their own (the taps cost registers the plain builds do not have)
+    const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
     unsigned frame = f_lo + wave;
     while (frame < f_hi) {
@@ -119,6 +121,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             else {  // zero pad, processing.rs:147-156; an odd frame length ends in a half pair
                 const int rem = static_cast<int>(a.flen) - 2 * (lane + 64 * e);
                 v[e] = rem >= 2 ? src[64 * e] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[128 * e] : 0.f, 0.f);
+            }
+            if (pre) {  // fused pre-emphasis (processing.rs:31-53) of the samples that exist
+                const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+                const int pos = static_cast<int>(t * a.step) + 2 * (lane + 64 * e), rem = static_cast<int>(a.flen) - 2 * (lane + 64 * e);
+                if (rem >= 1) v[e].x = fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), v[e].x);
+                if (rem >= 2) v[e].y = fmaf(-a.preemph, preemph_tap(xc, pos + 1, psh, a.n_samples), v[e].y);
             }
         }
         if (WIN) {
@@ -542,7 +550,17 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
         return hipGetLastError();
     };
-    const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096;
+    const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096 && a.preemph == 0.f;
+    if (a.preemph != 0.f) {  // fused pre-emphasis builds (run-time frame length)
+#define SS_HP(P2, MF, WN, NAME) go(ss_mfcc_c2048<false, P2, WAVES, MF, WN, true>, NAME)
+        if (a.window) {
+            if (pow2) return a.out_mfe ? SS_HP(true, true, true, "ss_mfcc_c2048<pow2,mfe,win,pre>") : SS_HP(true, false, true, "ss_mfcc_c2048<pow2,win,pre>");
+            return a.out_mfe ? SS_HP(false, true, true, "ss_mfcc_c2048<mfe,win,pre>") : SS_HP(false, false, true, "ss_mfcc_c2048<win,pre>");
+        }
+        if (pow2) return a.out_mfe ? SS_HP(true, true, false, "ss_mfcc_c2048<pow2,mfe,pre>") : SS_HP(true, false, false, "ss_mfcc_c2048<pow2,pre>");
+        return a.out_mfe ? SS_HP(false, true, false, "ss_mfcc_c2048<mfe,pre>") : SS_HP(false, false, false, "ss_mfcc_c2048<pre>");
+#undef SS_HP
+    }
     if (a.window) {  // windowed builds: MFCC and mfe
         if (pow2) {
             if (a.out_mfe) return exact ? go(ss_mfcc_c2048<true, true, WAVES, true, true>, "ss_mfcc_c2048<exact,pow2,mfe,win>") : go(ss_mfcc_c2048<false, true, WAVES, true, true>, "ss_mfcc_c2048<pow2,mfe,win>");

@@ -53,6 +53,8 @@ __device__ __forceinline__ unsigned load_quad_w(const Mfcc256Args &a, unsigned q
         t = gf - clip * a.n_frames;
     }
     const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+    const bool pre = a.preemph != 0.f;  // fused pre-emphasis: the caller then loads at the top of the loop (no prefetch)
+    const unsigned sh = a.preemph_shift % a.n_samples;
     // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step.  librosa center=True (the
     // `framing` switch): frame t is centred on sample t*step; frames inside the clip load the same way from their (even)
     // start, the few at the clip edges mirror (np.pad 'reflect') or zero their out-of-range samples
@@ -64,6 +66,11 @@ __device__ __forceinline__ unsigned load_quad_w(const Mfcc256Args &a, unsigned q
             // zero pad beyond flen; an odd frame length ends in a half pair
             const int rem = static_cast<int>(a.flen) - 2 * (j + 16 * e);
             vin[e] = rem >= 2 ? src[16 * e] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[32 * e] : 0.f, 0.f);
+            if (pre) {
+                const int pos = s0 + 2 * (j + 16 * e);
+                if (rem >= 1) vin[e].x = fmaf(-a.preemph, preemph_tap(xc, pos, sh, a.n_samples), vin[e].x);
+                if (rem >= 2) vin[e].y = fmaf(-a.preemph, preemph_tap(xc, pos + 1, sh, a.n_samples), vin[e].y);
+            }
         }
     } else {
 #pragma unroll
@@ -79,7 +86,7 @@ __device__ __forceinline__ unsigned load_quad_w(const Mfcc256Args &a, unsigned q
                         if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                         else ok = false;
                     }
-                    if (ok) sv[h] = xc[pos];
+                    if (ok) sv[h] = pre ? fmaf(-a.preemph, preemph_tap(xc, pos, sh, a.n_samples), xc[pos]) : xc[pos];
                 }
             }
             vin[e] = make_float2(sv[0], sv[1]);
@@ -122,7 +129,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
     unsigned quad = q_lo + wave;
     float2 vin[NE];
     unsigned t_next = 0;
-    if (quad < q_hi) t_next = load_quad_w<NE>(a, quad, total, f, j, vin);
+    const bool pre = a.preemph != 0.f;  // pre-emphasised samples are formed at load time: no prefetch across the iteration then
+    if (!pre && quad < q_hi) t_next = load_quad_w<NE>(a, quad, total, f, j, vin);
 
     const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);
         next = __builtin_amdgcn_readfirstlane(next);
+        if (pre) t_next = load_quad_w<NE>(a, quad, total, f, j, vin);
         const unsigned t_cur = t_next;
 
         float2 v[16];
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         wave_order();
-        if (next < q_hi) t_next = load_quad_w<NE>(a, next, total, f, j, vin);
+        if (!pre && next < q_hi) t_next = load_quad_w<NE>(a, next, total, f, j, vin);
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {

@@ -61,6 +61,13 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Fused pre-emphasis (processing.rs:31-53, np.roll semantics over the clip): the tap x[(pos - sh) mod L] of sample `pos`, sh < L
+__device__ __forceinline__ float preemph_tap(const float *xc, int pos, unsigned sh, unsigned len)
+{
+    const unsigned p = static_cast<unsigned>(pos);
+    return xc[p >= sh ? p - sh : p + len - sh];
+}
+
 // One mel slot of a lane: q4 float4s of weights against the same span of the P row, both 16-byte aligned (the host rounds a
 // filter's first bin down to a multiple of 4).  Four float4 pairs are requested per wait, so the loop is not one LDS round trip
 // per four taps.

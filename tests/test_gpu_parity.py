@@ -999,6 +999,50 @@ def test_odd_filter_counts_on_the_symmetric_dct_kernels(ss, oracle, sslib, sr, n
             assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
 
 
+@pytest.mark.parametrize("sr,nfft,flen,step,M,C,kernel", [
+    (8000, 256, 200, 80, 26, 13, b"ss_mfcc_c256x2<"), (16000, 512, 400, 160, 40, 13, b"ss_mfcc_c256w<"), (16000, 512, 401, 160, 80, 20, b"ss_mfcc_c256w<"),
+    (22050, 1024, 883, 221, 64, 20, b"ss_mfcc_c512"), (44100, 2048, 2048, 512, 128, 20, b"ss_mfcc_c1024"), (44100, 4096, 4096, 1024, 256, 40, b"ss_mfcc_c2048"),
+    (44100, 4096, 3001, 1000, 100, 13, b"ss_mfcc_c2048")])
+def test_fused_preemphasis_on_the_dedicated_kernels(ss, oracle, sslib, sr, nfft, flen, step, M, C, kernel):
+    """y[i] = x[i] - c x[(i - shift) mod L] (processing.rs:31-53) fused into the loaders of the dedicated frame kernels: shifts 1
+    and 3, with and without a window, centred frames where the kernel has them; the first frames wrap to the end of the clip."""
+    import torch
+
+    x = _signal(71, (4, flen + 9 * step + 1))
+    xd = torch.from_numpy(x).cuda()
+    kw = dict(frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+    cases = [dict(preemph_coef=0.97), dict(preemph_coef=0.9, preemph_shift=3, mfcc_window="hann", spectrum_exponent=2)]
+    if nfft in (512, 1024, 2048) and flen % 4 == 0:
+        cases.append(dict(preemph_coef=0.97, framing="center", pad_mode="reflect"))
+    for sw in cases:
+        p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, **sw)
+        got = ss.mfcc_batch(xd, sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(kernel), (sslib.ss_last_kernel_name(), sw)
+        for b in (0, 3):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
+        mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
+        feat, en = ss.mfe_batch(xd, sr, **mkw, **sw)
+        wf, we = oracle.mfe(p, x[3])
+        assert _rel(feat[3].cpu().numpy(), wf) <= RTOL and _rel(en[3].cpu().numpy(), we) <= RTOL, sw
+
+
+def test_configuration_that_outgrows_a_dedicated_kernel_falls_back(ss, oracle, sslib):
+    """A windowed 4096-point configuration whose table block (48 long filters, 37 cosine rows, the window) does not fit the
+    dedicated kernel's LDS budget: its launcher declines before launching and the dispatcher moves on to the generic kernel."""
+    import torch
+
+    sr = 22050
+    kw = dict(frame_length=0.13506802721088434, frame_stride=0.029489795918367347, num_cepstral=37, num_filters=48, fft_length=4096)
+    sw = dict(mfcc_window="hann", spectrum_exponent=2)
+    x = _signal(75, (3, 21076))
+    got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_front_generic<11>")
+    p = oracle.make_params(sample_rate=sr, fft_points=4096, frame_length=kw["frame_length"], frame_stride=kw["frame_stride"], num_cepstral=37,
+                           num_filters=48, **sw)
+    for b in range(3):
+        assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL
+
+
 def test_mfcc_256_kernel(ss, oracle, sslib):
     """MFCC / mfe at fft_points = 256 (8 kHz telephony front ends): two frames per complex transform.  20 ms and 25 ms frames,
     odd hops (scalar loads: no alignment assumptions), window, power spectrum, filter counts up to 48, batches whose frame count

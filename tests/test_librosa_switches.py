@@ -136,7 +136,7 @@ def test_librosa_like_front_end_gpu(ss, oracle, sslib):
         got = ss.mfcc_batch(xd, 16000, **args, **sw).cpu().numpy()
         name = sslib.ss_last_kernel_name().decode()
         if kw.get("preemph_coef"):
-            assert name.startswith("ss_front_generic")  # fused pre-emphasis stays on the generic kernel in these modes
+            assert name.startswith("ss_mfcc_c256w<")  # fused pre-emphasis with centred frames: the wide-bank kernel
         else:  # builds of the 512-point kernel with centred frames and / or P rows over the whole spectrum
             assert name.startswith("ss_mfcc_c256<16") and ("center" in name) == (kw.get("framing") == "center") \
                 and ("fullp" in name) == (kw.get("mel_scale", "reference") != "reference"), name
