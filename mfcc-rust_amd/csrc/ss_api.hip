@@ -175,11 +175,11 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool mfe_shape = a.flen == 320 && a.spectrum_exponent != 2 && cfg->fast.q4[0] == 4 && cfg->fast.q4[1] == 2 &&
                            cfg->fast.q4[2] == 1 && a.n_filters <= 40;
     const bool front = a.preemph != 0.0f || a.window != nullptr;  // optional window / fused pre-emphasis: default-bank build only
-    // librosa-compatible variants: centred frames (flen % 4 == 0) and banks over the whole spectrum have MFCC builds of their
-    // own (optional window, no fused pre-emphasis)
+    // librosa-compatible variants: centred frames and banks over the whole spectrum have MFCC builds of their own (optional
+    // window, no fused pre-emphasis)
     const bool centre = a.frame_mode == ss::FRAME_CENTER;
     const bool lib_variant = centre || cfg->fast.fullp;
-    const bool lib_ok = out_kind == ss::OUT_MFCC && a.preemph == 0.0f && (!centre || a.flen % 4 == 0);
+    const bool lib_ok = out_kind == ss::OUT_MFCC && a.preemph == 0.0f;
     // Sample pairs load as 8-byte words at dword alignment (gfx950 global loads need no more: tools/unaligned_probe.py), and an
     // odd frame length ends in a half pair that one lane loads as a single float -- so hops, leading dimensions, base offsets
     // and frame lengths of either parity reach the dedicated kernels.
@@ -289,7 +289,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra, and the output / window / framing combinations the
     // headline kernel has no build for (ss_mfcc512w.hip): optional frame window, centred frames, fused pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
-        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0))) {
+        (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && (a.frame_mode == ss::FRAME_NORMAL || centre)) {
         ss::Mfcc256Args f{};
         f.center = centre;
         f.pad_reflect = a.pad_reflect;
@@ -362,9 +362,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         if (e3 != hipErrorInvalidValue) return hip_fail(e3, "launch_mfcc_c256x2");
     }
     // fft_points = 2048 / 1024 MFCC / mfe: two frames per wave (ss_mfcc2048.hip, ss_mfcc1024.hip), optional frame window
-    // (both have librosa-compatible builds: centred frames with flen % 4 == 0, banks up to fs/2)
+    // (both have librosa-compatible builds: centred frames, banks up to fs/2)
     if (!force_generic && (cfg->mfcc2048.ok || cfg->mfcc1024.ok) && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) &&
-        (a.frame_mode == ss::FRAME_NORMAL || (centre && a.flen % 4 == 0))) {
+        (a.frame_mode == ss::FRAME_NORMAL || centre)) {
         ss::Mfcc2048Args f{};
         f.preemph = a.preemph;
         f.preemph_shift = a.preemph_shift;

@@ -134,11 +134,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float sv[2] = {0.f, 0.f};
-                if (e < e_hi) {
+                {
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         int pos = s0 + 2 * (jj + 32 * e) + hh;
-                        bool ok = true;
+                        bool ok = 2 * (jj + 32 * e) + hh < static_cast<int>(a.flen);  // zero pad; an odd frame length ends in a half pair
                         if (pos < 0 || pos >= ns) {
                             if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                             else ok = false;

@@ -122,11 +122,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
                 float sv[2] = {0.f, 0.f};
-                if (e < e_hi) {
+                {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         int pos = s0 + 2 * (j + 32 * e) + h;
-                        bool ok = true;
+                        bool ok = 2 * (j + 32 * e) + h < static_cast<int>(a.flen);  // zero pad; an odd frame length ends in a half pair
                         if (pos < 0 || pos >= ns) {
                             if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                             else ok = false;

@@ -99,7 +99,7 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         int pos = s0 + 2 * n + h;
-                        bool ok = true;
+                        bool ok = 2 * n + h < static_cast<int>(a.flen);  // an odd frame length ends in a half pair
                         if (pos < 0 || pos >= ns) {
                             if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                             else ok = false;
@@ -539,7 +539,7 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
         if constexpr (WAVES != 12) {
             return hipErrorInvalidValue;
         } else {
-            if (a.out_mfe || a.preemph != 0.0f || (a.center && a.flen % 4 != 0)) return hipErrorInvalidValue;
+            if (a.out_mfe || a.preemph != 0.0f) return hipErrorInvalidValue;
             const bool win = a.win_floats > 0;
 #define SS_LV(P2, FR, FP, CE, NAME) return go(ss_mfcc_c256<16, false, P2, WAVES, false, 12, 0, 0, FR, FP, CE>, NAME)
             if (a.fullp && !a.center) {

@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned load_quad_w(const Mfcc256Args &a, unsigned q
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     int pos = s0 + 2 * n + h;
-                    bool ok = true;
+                    bool ok = 2 * n + h < static_cast<int>(a.flen);  // an odd frame length ends in a half pair
                     if (pos < 0 || pos >= ns) {
                         if (a.pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
                         else ok = false;

@@ -222,3 +222,24 @@ def test_log_mel_80_centred_gpu(ss, oracle, sslib):
     p = oracle.make_params(sample_rate=sr, fft_points=512, frame_length=512 / sr, frame_stride=0.01, num_cepstral=13, num_filters=80, **sw)
     got = ss.mfcc(xs, sr, frame_length=512 / sr, num_filters=80, **sw)
     assert _rel(got, oracle.mfcc(p, xs)) <= RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,nfft,flen,hop,M,C,kernel", [(16000, 512, 401, 160, 40, 13, "ss_mfcc_c256<"), (16000, 512, 322, 161, 80, 13, "ss_mfcc_c256w<"),
+                                                        (22050, 1024, 883, 221, 64, 20, "ss_mfcc_c512<"), (44100, 2048, 1765, 441, 128, 20, "ss_mfcc_c1024<")])
+def test_centred_frames_of_any_length_gpu(ss, oracle, sslib, sr, nfft, flen, hop, M, C, kernel):
+    """Centred frames whose length is odd or not a multiple of four (centre offset flen // 2, frame starts of either parity),
+    reflect and zero padding, on the dedicated kernels; clips short enough that every frame touches an edge included."""
+    import torch
+
+    for n in (flen + 11 * hop + 1, flen // 2 + 3):
+        x = _signal(68, (3, n))
+        for pad in ("reflect", "constant"):
+            sw = dict(framing="center", pad_mode=pad, mfcc_window="hann")
+            kw = dict(frame_length=flen / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+            p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, **sw)
+            got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
+            assert sslib.ss_last_kernel_name().decode().startswith(kernel), sslib.ss_last_kernel_name()
+            assert got.shape[1] == oracle.num_frames(p, n)
+            for b in range(3):
+                assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (n, pad, b)
