@@ -772,7 +772,7 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
     namespace L = mfcc1024_layout;
     f = Mfcc1024Tables{};
     const size_t M = t.params.num_filters, Cc = mel ? 0 : t.params.num_cepstral;
-    if (t.d.n_fft != 1024 || M > 128 || Cc > 32) return;
+    if (t.d.n_fft != 1024 || M > 128 || Cc > 64) return;
     if (mel && (!t.d.stft_ok || t.window_stft.size() != 1024)) return;
     if (t.bank.last_bin > 513) return;
     f.fullp = t.bank.last_bin > 257;  // reference banks end at (F+1)/2 (P bins 0..256); librosa-style ones need all 513
@@ -859,7 +859,7 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
     namespace L = mfcc2048_layout;
     f = Mfcc2048Tables{};
     const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
-    if (t.d.n_fft != 2048 || M > 128 || Cc > 32) return;
+    if (t.d.n_fft != 2048 || M > 128 || Cc > 64) return;
     if (t.bank.last_bin > 1025) return;
     f.fullp = t.bank.last_bin > 513;  // reference banks end at (F+1)/2 (P bins 0..512); librosa-style ones need all 1025
     const int32_t kRow = f.fullp ? 1028 : 516;

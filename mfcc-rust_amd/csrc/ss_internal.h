@@ -192,9 +192,9 @@ constexpr int kTwn = kT2 + 8 * 64;       // [8][32] float2: exp(-2 pi i (k1 + 16
 constexpr int kWin = kTwn + 8 * 64;      // [512] float2: frame window pairs (zero beyond flen); unused without a window
 constexpr int kStart = kWin + 1024;      // [4][32] int32: first P bin (multiple of 4) of the filter owned by (slot, lane)
 constexpr int kFilt = kStart + 128;      // [4][32] int32: filter index of (slot, lane), -1 if none
-constexpr int kCos = kFilt + 128;        // [32][68]: row c: cos(pi c (2m+1) / 2M), m < M/2, zero padded
+constexpr int kCos = kFilt + 128;        // [64][68]: row c: cos(pi c (2m+1) / 2M), m < (M+1)/2, zero padded
 constexpr int kCosPitch = 68;
-constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
+constexpr int kMelW = kCos + 64 * kCosPitch;  // [32][pitch]
 }  // namespace mfcc1024_layout
 
 struct Mfcc1024Tables {
@@ -216,9 +216,9 @@ constexpr int kTwn = kTw2 + 16 * 128;    // [16][32] float2: exp(-2 pi i (j + 32
 constexpr int kWin = kTwn + 16 * 64;     // [1024] float2: frame window pairs (zero beyond flen); unused without a window
 constexpr int kStart = kWin + 2048;      // [4][32] int32: first P bin (multiple of 4) of the filter owned by (slot, lane)
 constexpr int kFilt = kStart + 128;      // [4][32] int32: filter index of (slot, lane), -1 if none
-constexpr int kCos = kFilt + 128;        // [32][68]: row c: cos(pi c (2m+1) / 2M), m < M/2 (the other half by symmetry), zero padded
+constexpr int kCos = kFilt + 128;        // [64][68]: row c: cos(pi c (2m+1) / 2M), m < (M+1)/2 (the other half by symmetry), zero padded
 constexpr int kCosPitch = 68;
-constexpr int kMelW = kCos + 32 * kCosPitch;  // [32][pitch]
+constexpr int kMelW = kCos + 64 * kCosPitch;  // [32][pitch]
 }  // namespace mfcc2048_layout
 
 struct Mfcc2048Tables {

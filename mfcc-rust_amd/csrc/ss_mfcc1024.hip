@@ -274,21 +274,40 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
         }
         wave_order();
         if (jj < Cc) {
+            const int c = jj;
             const float4 *r4 = reinterpret_cast<const float4 *>((jj & 1) ? drow : srow);
-            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + jj * L::kCosPitch);
+            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + c * L::kCosPitch);
             float acc = 0.f;
             const int nq = (Mc + 3) / 4;
             for (int i = 0; i < nq; ++i) {
-                const float4 r = r4[i], c = c4[i];
-                acc = fmaf(r.x, c.x, acc);
-                acc = fmaf(r.y, c.y, acc);
-                acc = fmaf(r.z, c.z, acc);
-                acc = fmaf(r.w, c.w, acc);
+                const float4 r = r4[i], cw = c4[i];
+                acc = fmaf(r.x, cw.x, acc);
+                acc = fmaf(r.y, cw.y, acc);
+                acc = fmaf(r.z, cw.z, acc);
+                acc = fmaf(r.w, cw.w, acc);
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (jj == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-            if (live) a.out[static_cast<unsigned long long>(gf) * Cc + jj] = o;
+            if (c == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (live) a.out[static_cast<unsigned long long>(gf) * Cc + c] = o;
+        }
+        if (Cc > 32) {  // 33..64 cepstra: the lane also forms coefficient c + 32 (same parity: same row)
+            wave_order();
+            if (jj + 32 < Cc) {
+                const int c = jj + 32;
+                const float4 *r4 = reinterpret_cast<const float4 *>((jj & 1) ? drow : srow);
+                const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + c * L::kCosPitch);
+                float acc = 0.f;
+                const int nq = (Mc + 3) / 4;
+                for (int i = 0; i < nq; ++i) {
+                    const float4 r = r4[i], cw = c4[i];
+                    acc = fmaf(r.x, cw.x, acc);
+                    acc = fmaf(r.y, cw.y, acc);
+                    acc = fmaf(r.z, cw.z, acc);
+                    acc = fmaf(r.w, cw.w, acc);
+                }
+                if (live) a.out[static_cast<unsigned long long>(gf) * Cc + c] = acc * a.dct_scale_k;
+            }
         }
         wave_order();
         unit = next;

@@ -265,21 +265,40 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
         }
         wave_order();
         if (j < Cc) {
+            const int c = j;
             const float4 *r4 = reinterpret_cast<const float4 *>((j & 1) ? drow : srow);
-            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * L::kCosPitch);
+            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + c * L::kCosPitch);
             float acc = 0.f;
             const int nq = (Mc + 3) / 4;  // the rows are zero-padded to a multiple of 4 by the host table / the loop below
             for (int i = 0; i < nq; ++i) {
-                const float4 r = r4[i], c = c4[i];
-                acc = fmaf(r.x, c.x, acc);
-                acc = fmaf(r.y, c.y, acc);
-                acc = fmaf(r.z, c.z, acc);
-                acc = fmaf(r.w, c.w, acc);
+                const float4 r = r4[i], cw = c4[i];
+                acc = fmaf(r.x, cw.x, acc);
+                acc = fmaf(r.y, cw.y, acc);
+                acc = fmaf(r.z, cw.z, acc);
+                acc = fmaf(r.w, cw.w, acc);
             }
             // scaling + column-0 replacement (feature.rs:126-146)
             float o = acc * a.dct_scale_k;
-            if (j == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-            if (live) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
+            if (c == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+            if (live) a.out[static_cast<unsigned long long>(gf) * Cc + c] = o;
+        }
+        if (Cc > 32) {  // 33..64 cepstra: the lane also forms coefficient c + 32 (same parity: same row)
+            wave_order();
+            if (j + 32 < Cc) {
+                const int c = j + 32;
+                const float4 *r4 = reinterpret_cast<const float4 *>((j & 1) ? drow : srow);
+                const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + c * L::kCosPitch);
+                float acc = 0.f;
+                const int nq = (Mc + 3) / 4;  // the rows are zero-padded to a multiple of 4 by the host table / the loop below
+                for (int i = 0; i < nq; ++i) {
+                    const float4 r = r4[i], cw = c4[i];
+                    acc = fmaf(r.x, cw.x, acc);
+                    acc = fmaf(r.y, cw.y, acc);
+                    acc = fmaf(r.z, cw.z, acc);
+                    acc = fmaf(r.w, cw.w, acc);
+                }
+                if (live) a.out[static_cast<unsigned long long>(gf) * Cc + c] = acc * a.dct_scale_k;
+            }
         }
         wave_order();
         unit = next;

@@ -1043,6 +1043,22 @@ def test_configuration_that_outgrows_a_dedicated_kernel_falls_back(ss, oracle, s
         assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL
 
 
+@pytest.mark.parametrize("sr,nfft,hop,M,C,kernel", [(22050, 1024, 256, 64, 40, b"ss_mfcc_c512"), (44100, 2048, 512, 128, 64, b"ss_mfcc_c1024"),
+                                                    (44100, 2048, 512, 127, 33, b"ss_mfcc_c1024")])
+def test_more_than_32_cepstra_on_the_1024_and_2048_point_kernels(ss, oracle, sslib, sr, nfft, hop, M, C, kernel):
+    """33..64 cepstra: lane c also forms coefficient c + 32."""
+    import torch
+
+    x = _signal(77, (3, nfft + 9 * hop))
+    kw = dict(frame_length=nfft / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
+    for sw in ({}, dict(dct_norm="ortho", dc_elimination=False, mfcc_window="hann")):
+        p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=nfft / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, **sw)
+        got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
+        assert sslib.ss_last_kernel_name().startswith(kernel), sslib.ss_last_kernel_name()
+        for b in range(3):
+            assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL, (sw, b)
+
+
 def test_mfcc_256_kernel(ss, oracle, sslib):
     """MFCC / mfe at fft_points = 256 (8 kHz telephony front ends): two frames per complex transform.  20 ms and 25 ms frames,
     odd hops (scalar loads: no alignment assumptions), window, power spectrum, filter counts up to 48, batches whose frame count
