@@ -573,7 +573,7 @@ void build_mfcc256(const HostTables &t, Mfcc256Tables &f)
     namespace L = mfcc256_layout;
     f = Mfcc256Tables{};
     const size_t M = t.params.num_filters, Cc = t.params.num_cepstral;
-    if (t.d.n_fft != 256 || M > 48 || Cc > 16) return;
+    if (t.d.n_fft != 256 || M > 48 || Cc > 32) return;
     if (t.bank.last_bin > 129) return;
     constexpr int32_t kRow = 132;  // P bins a tap may touch: 0..128 plus three zero pad bins
     // order filters by tap count (longest first) and deal them 16 per slot

@@ -169,8 +169,8 @@ void build_mel512(const HostTables &t, Mel512Tables &f);
 // Table block of the fft_points = 256 MFCC / mfe kernel (ss_mfcc256.hip), float offsets; global layout == LDS layout.
 namespace mfcc256_layout {
 constexpr int kTw2 = 0;                  // [8][16] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 256); last .zw unused
-constexpr int kCos = kTw2 + 8 * 64;      // [16][52]: row c: cos(pi c (2m+1) / 2M) in (slot, lane) order, zero where no filter
-constexpr int kStart = kCos + 16 * 52;   // [3][16] int32: first P bin of the filter owned by (slot, lane)
+constexpr int kCos = kTw2 + 8 * 64;      // [32][52]: row c: cos(pi c (2m+1) / 2M) in (slot, lane) order, zero where no filter
+constexpr int kStart = kCos + 32 * 52;   // [3][16] int32: first P bin of the filter owned by (slot, lane)
 constexpr int kFilt = kStart + 48;       // [3][16] int32: filter index of (slot, lane), -1 if none
 constexpr int kMelW = kFilt + 48;        // [16][pitch]; an optional frame window [256] follows
 }  // namespace mfcc256_layout

@@ -289,6 +289,28 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             float o = acc * a.dct_scale_k;
             if (j == 0) o = a.dc_elimination ? ln_scaled(en[s]) : acc * ((s ? tB : tA) == 0 ? a.dct_scale_00 : a.dct_scale_0);
             if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
+            if (Cc > 16) {  // 17..32 cepstra: the lane also forms coefficient 16 + j (small batches: next to the prefetch registers)
+                wave_order();
+                const float4 *d4 = c4 + 16 * (52 / 4);
+                float acc2 = 0.f;
+#pragma unroll 1
+                for (int h = 0; h < 6; ++h) {
+                    float4 lq[2], dq[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        lq[i] = *reinterpret_cast<const float4 *>(&frow[4 * (2 * h + i)]);
+                        dq[i] = d4[2 * h + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc2 = fmaf(lq[i].x, dq[i].x, acc2);
+                        acc2 = fmaf(lq[i].y, dq[i].y, acc2);
+                        acc2 = fmaf(lq[i].z, dq[i].z, acc2);
+                        acc2 = fmaf(lq[i].w, dq[i].w, acc2);
+                    }
+                }
+                if (16 + j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + 16 + j] = acc2 * a.dct_scale_k;
+            }
         }
         wave_order();
         }

@@ -1069,6 +1069,7 @@ def test_mfcc_256_kernel(ss, oracle, sslib):
     x = _signal(31, (11, 2 * sr))
     xd = torch.from_numpy(x).cuda()
     for flen, step, M, C, sw in ((160, 80, 40, 13, {}), (200, 80, 26, 13, dict(mfcc_window="vorbis")), (256, 81, 48, 16, dict(spectrum_exponent=2)),
+                                 (160, 80, 40, 20, {}), (200, 80, 48, 32, dict(mfcc_window="hann", dc_elimination=False)),
                                  (161, 77, 23, 12, dict(mfcc_window="hann", dct_norm="ortho", dc_elimination=False)),
                                  (160, 80, 40, 13, dict(mel_scale="slaney", mel_norm="slaney"))):
         kw = dict(frame_length=flen / sr, frame_stride=step / sr, num_cepstral=C, num_filters=M, fft_length=256)
