@@ -88,7 +88,9 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const int n = j + 16 * e;
-                vin[e] = 2 * n < static_cast<int>(a.flen) ? srcc[n] : make_float2(0.f, 0.f);
+                // zero pad beyond flen; an odd frame length ends in a half pair
+                const int rem = static_cast<int>(a.flen) - 2 * n;
+                vin[e] = rem >= 2 ? srcc[n] : make_float2(rem == 1 ? reinterpret_cast<const float *>(srcc)[2 * n] : 0.f, 0.f);
             }
         } else {
 #pragma unroll

@@ -234,8 +234,8 @@ def test_centred_frames_of_any_length_gpu(ss, oracle, sslib, sr, nfft, flen, hop
 
     for n in (flen + 11 * hop + 1, flen // 2 + 3):
         x = _signal(68, (3, n))
-        for pad in ("reflect", "constant"):
-            sw = dict(framing="center", pad_mode=pad, mfcc_window="hann")
+        for pad, win in (("reflect", "hann"), ("constant", "hann"), ("reflect", "rect"), ("constant", "rect")):
+            sw = dict(framing="center", pad_mode=pad, mfcc_window=win)  # (a window hides the sample behind an odd frame)
             kw = dict(frame_length=flen / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, fft_length=nfft)
             p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=hop / sr, num_cepstral=C, num_filters=M, **sw)
             got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
