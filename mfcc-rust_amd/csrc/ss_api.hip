@@ -258,22 +258,26 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             dbg_done = true;
             const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
             DeviceBuf db;
-            int rc2 = db.alloc(nwaves * 4 * sizeof(unsigned long long));
+            int rc2 = db.alloc(nwaves * 6 * sizeof(unsigned long long));
             if (rc2) return rc2;
-            for (int rep = 0; rep < 3; ++rep) {  // the last repetition is the warm one
-                SS_HIP(hipMemsetAsync(db.p, 0, nwaves * 4 * sizeof(unsigned long long), stream));
+            DeviceBuf flush;  // larger than the Infinity Cache: the stamped launch reads its samples from HBM like a bench step
+            rc2 = flush.alloc(512ull << 20);
+            if (rc2) return rc2;
+            for (int rep = 0; rep < 3; ++rep) {  // the last repetition has warm code / tables and cold samples
+                SS_HIP(hipMemsetAsync(flush.p, rep, 512ull << 20, stream));
+                SS_HIP(hipMemsetAsync(db.p, 0, nwaves * 6 * sizeof(unsigned long long), stream));
                 f.dbg = db.as<unsigned long long>();
                 hipError_t e2 = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
                 if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c256");
                 SS_HIP(hipStreamSynchronize(stream));
             }
-            std::vector<unsigned long long> hb(nwaves * 4);
+            std::vector<unsigned long long> hb(nwaves * 6);
             SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE *fp = std::fopen(dbg_path, "w")) {
                 for (size_t w = 0; w < nwaves; ++w)
-                    if (hb[4 * w + 2])
-                        std::fprintf(fp, "%zu %llu %llu %llu %llu %llu\n", w, hb[4 * w], hb[4 * w + 1], hb[4 * w + 2],
-                                     hb[4 * w + 3] >> 32, hb[4 * w + 3] & 0xffffffffull);
+                    if (hb[6 * w + 2])
+                        std::fprintf(fp, "%zu %llu %llu %llu %llu %llu %llu %llu\n", w, hb[6 * w], hb[6 * w + 1], hb[6 * w + 2],
+                                     hb[6 * w + 3] >> 32, hb[6 * w + 3] & 0xffffffffull, hb[6 * w + 4], hb[6 * w + 5]);
                 std::fclose(fp);
             }
             f.dbg = nullptr;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 
 namespace ss {
 
@@ -406,20 +407,61 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     int32_t off = 0;
     for (int s = 0; s < 3; ++s) {
         const int32_t span = 4 * f.q4[s];
+        // The 16 lanes of a slot read tap i of their filters in one ds_read_b32 group together with the 16 lanes of the
+        // neighbouring frame, whose P row sits 16 banks further (144 floats): the group is conflict-free when the lanes'
+        // first bins differ mod 16.  A filter shorter than the slot's span may start up to span - len bins early (zero
+        // weights in front), so the first bins are chosen by a bipartite matching lanes -> residues (Kuhn's algorithm).
+        int32_t lo[16], hi[16], chosen[16];  // admissible first bins [lo, hi] per lane
         for (int j = 0; j < 16; ++j) {
             const size_t q = static_cast<size_t>(s) * 16 + j;
-            start[q] = 0;
+            lo[j] = hi[j] = 0;
+            if (q >= M) continue;
+            const int32_t m = order[q], st = t.bank.start[m], len = t.bank.len[m];
+            hi[j] = std::min(st, kRow - span);          // the lock-step loop reads `span` taps: st + span stays inside the row
+            lo[j] = std::max<int32_t>(0, st + len - span);  // the filter's last tap stays inside the span
+            if (lo[j] > hi[j]) lo[j] = hi[j];
+        }
+        {
+            int32_t owner[16];  // residue -> lane
+            for (int r = 0; r < 16; ++r) owner[r] = -1;
+            for (int j = 0; j < 16; ++j) chosen[j] = hi[j];
+            if (!f.fullp) {
+                std::function<bool(int, std::vector<char> &)> place = [&](int j, std::vector<char> &seen) -> bool {
+                    for (int32_t b = hi[j]; b >= lo[j]; --b) {
+                        const int r = b & 15;
+                        if (seen[r]) continue;
+                        seen[r] = 1;
+                        if (owner[r] < 0 || place(owner[r], seen)) {
+                            owner[r] = j;
+                            chosen[j] = b;
+                            return true;
+                        }
+                    }
+                    return false;
+                };
+                for (int j = 0; j < 16; ++j) {
+                    if (static_cast<size_t>(s) * 16 + j >= M) continue;
+                    std::vector<char> seen(16, 0);
+                    place(j, seen);  // unmatched lanes keep their latest admissible first bin
+                }
+                // an unused (slot, lane) reads the same words as a used one (same address: a broadcast, never a conflict)
+                int used = -1;
+                for (int j = 0; j < 16; ++j)
+                    if (static_cast<size_t>(s) * 16 + j < M) used = j;
+                for (int j = 0; j < 16; ++j)
+                    if (static_cast<size_t>(s) * 16 + j >= M && used >= 0) chosen[j] = chosen[used];
+            }
+        }
+        for (int j = 0; j < 16; ++j) {
+            const size_t q = static_cast<size_t>(s) * 16 + j;
+            start[q] = chosen[j];
             filt[q] = -1;
             if (q >= M) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
             const int32_t m = order[q];
             filt[q] = m;
-            int32_t st = t.bank.start[m];
             const int32_t len = t.bank.len[m];
-            // the lock-step loop reads `span` taps: keep st + span inside the 132-bin row
-            int32_t shift = 0;
-            if (st + span > kRow) shift = st + span - kRow;
-            st -= shift;
-            start[q] = st;
+            const int32_t st = chosen[j];
+            const int32_t shift = t.bank.start[m] - st;  // zero weights in front of the filter's first tap
             for (int32_t i = 0; i < len; ++i)
                 f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
             for (size_t c = 0; c < Cc; ++c) f.tab[L::kCos + c * 52 + q] = t.dct[c * M + m];

@@ -44,6 +44,20 @@
 
 #include <cstdlib>
 
+// Timing-attribution builds (tools/ablate.sh): each bit removes one stage; results are then wrong by design.
+//   1 partner fetch (ds_bpermute)   2 mel + ln + DCT   4 LDS exchange   8 square roots   16 sample loads in the loop
+//   32 DCT only   64 second radix-16 pass
+//   128 all sample loads from clip 0 (L2-resident: removes the HBM misses)
+#ifndef SS_ABLATE
+#define SS_ABLATE 0
+#endif
+// Experiment switches (tools/ablate.sh with OPT=<bits>), results stay correct:
+//   1 untangle partner by DPP row_mirror (lanes relabelled so that lane l and 15 - l hold columns j and 16 - j)
+//   2 the claimed quad number is read where it is first needed   4 touch-prefetch of the quad one round ahead
+#ifndef SS_OPT
+#define SS_OPT 0
+#endif
+
 namespace ss {
 
 namespace {
@@ -115,6 +129,7 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
         return t;
     }
     // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
+    if (SS_ABLATE & 128) clip = 0;
     const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -180,7 +195,12 @@ template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RE
           bool CENTER = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 {
-    constexpr bool PREFETCH = WAVES <= 12;
+    constexpr bool PREFETCH = true;
+    // more than 12 waves per CU (4 per SIMD, <= 128 VGPRs): the P / ln / sum-difference rows live inside the frame's own
+    // exchange slot (9216 B per wave) and no table stays in registers
+    constexpr bool ALIAS = WAVES > 12;
+    constexpr bool TABREG = WAVES <= 12;
+    constexpr int WF = ALIAS ? 4 * kZStride * 2 : kWaveFloats;
     constexpr bool MFE = OUTK == 1, PWR = OUTK == 2;  // output: 0 MFCC, 1 mfe's (features, energy), 2 the power_spectrum rows
     constexpr bool WIN = (FRONT & 1) != 0, PRE = (FRONT & 2) != 0;  // optional frame window / fused pre-emphasis  // a 4-waves-per-SIMD build has no registers for the prefetch / resident twiddles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -189,16 +209,20 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const int lane = tid & 63;
     const unsigned long long t_start = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int f = lane >> 4;  // frame within the quad
-    const int j = lane & 15;  // lane within the frame (DPP row)
+    // column of the frame's 16 x 16 point matrix owned by this lane of the DPP row.  The untangle pairs column j with
+    // column 16 - j: lanes l and 15 - l hold such a pair (1..7 <-> 15..9), lanes 0 and 15 the self-paired columns 0 and 8,
+    // so the partner arrives by DPP row_mirror instead of an LDS round trip.
+    const int l16 = lane & 15;
+    const int j = (SS_OPT & 1) ? (l16 < 8 ? l16 : (l16 == 15 ? 8 : l16 + 1)) : l16;
 
     // ---- LDS carve: per-wave regions, then the shared read-only table block, then the quad counter ----
-    float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloats;
+    float *wbase = reinterpret_cast<float *>(smem) + wave * WF;
     float2 *zh = reinterpret_cast<float2 *>(wbase) + f * kZStride;        // this frame's exchange slot
     // P row: bins 0..128 + zero pad bins behind the exchange slots; FULLP: all 257 bins (+ pad) inside the frame's own
     // exchange slot, with the ln(mel) row behind it
-    float *prow = FULLP ? wbase + f * (2 * kZStride) : wbase + kPOff + f * kPRow;
-    float *frow = FULLP ? prow + 264 : wbase + f * 48;  // ln(mel) in (slot, lane) order (after the exchange)
-    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * kWaveFloats;
+    float *prow = (FULLP || ALIAS) ? wbase + f * (2 * kZStride) : wbase + kPOff + f * kPRow;
+    float *frow = FULLP ? prow + 264 : ALIAS ? prow + 144 : wbase + f * 48;  // ln(mel) in (slot, lane) order (after the exchange)
+    float *s_tab = reinterpret_cast<float *>(smem) + WAVES * WF;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
     const float *s_cos = s_tab + L::kCos;
@@ -213,29 +237,50 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const unsigned q_lo = static_cast<unsigned>(static_cast<unsigned long long>(quads) * blockIdx.x / gridDim.x);
     const unsigned q_hi = static_cast<unsigned>(static_cast<unsigned long long>(quads) * (blockIdx.x + 1) / gridDim.x);
 
-    // the table block arrives as float4s, global layout == LDS layout
-    {
-        const int n4 = (L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0)) / 4;
-        for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
-        if (tid == 0) *s_next = q_lo + WAVES;
-        if (!FULLP && j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
+    // The table block (global layout == LDS layout) is fetched by the workgroup's first two waves only, before they ask
+    // for their samples: behind the sample loads of the other waves (HBM misses that fill the CU's miss queue) a table load
+    // takes 3-4 us instead of 1, and the barrier below waits for the slowest one.
+    constexpr int kTabWaves = 2;
+    const int n4 = (L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0)) / 4;
+    unsigned long long t_tab = 0ull;
+    if (wave < kTabWaves) {
+        constexpr int kBatch = 6;  // loads in flight per lane (768 float4s cover every 512-point table block with <= 80 floats per mel row)
+        for (int base = 0; base < n4; base += kBatch * kTabWaves * 64) {
+            float4 tv[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) tv[k] = reinterpret_cast<const float4 *>(a.tab)[min(base + tid + k * (kTabWaves * 64), n4 - 1)];
+            // (pinned: the compiler otherwise sinks each load next to its store, one memory round trip per float4)
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) asm volatile("" : "+v"(tv[k].x), "+v"(tv[k].y), "+v"(tv[k].z), "+v"(tv[k].w));
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int idx = base + tid + k * (kTabWaves * 64);
+                if (idx < n4) reinterpret_cast<float4 *>(s_tab)[idx] = tv[k];
+            }
+        }
+        if (a.dbg) t_tab = __builtin_amdgcn_s_memrealtime();
     }
-    // first quad of this wave; its loads are in flight across the barrier
+    // first quad of this wave; its loads are in flight across the barrier (a wave without a quad loads the block's last
+    // one: no branch around the loads)
     unsigned quad = q_lo + wave;
     float2 vin[NE];
     float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
-    if (quad < q_hi) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
+    t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
+    {
+        if (tid == 0) *s_next = q_lo + WAVES;
+        if (!FULLP && !ALIAS && j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
+    }
 
     const int paddr = ((lane & 48) | ((16 - j) & 15)) << 2;  // lane holding Z[256 - k]
     const int wbase1 = 34 * (j >> 1) + (j & 1);              // exchange write base (float2 units)
     const int Cc = static_cast<int>(a.n_ceps);
     // |X| = (1/2)|...|: the 1/2 of the untangle is folded into the scale (1/4 for the squared form)
     const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
-    __syncthreads();
+    wg_barrier_lds();  // the tables are in LDS; the wave's first samples stay in flight across it
     // first P bin of this lane's three filters, as float indices into LDS; opaque so that the full address stays in a
     // register (the compiler otherwise re-adds the P-row offset in front of every ds_read2)
-    const int pbase = wave * kWaveFloats + (FULLP ? f * (2 * kZStride) : kPOff + f * kPRow);
+    const int pbase = wave * WF + ((FULLP || ALIAS) ? f * (2 * kZStride) : kPOff + f * kPRow);
     int st0 = pbase + s_start[j];
     int st1 = pbase + s_start[16 + j];
     int st2 = pbase + s_start[32 + j];
@@ -245,18 +290,18 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     constexpr bool SYM = (RES & 4) != 0;  // 40 filters: DCT against sum/difference rows with the half cosine row in registers
     const int fidx0 = (MFE || SYM) ? s_filt[j] : 0, fidx1 = (MFE || SYM) ? s_filt[16 + j] : 0, fidx2 = (MFE || SYM) ? s_filt[32 + j] : 0;
     float4 ch[SYM ? 5 : 1];
-    if (SYM) {
+    if (SYM && TABREG) {
         const float4 *h4 = reinterpret_cast<const float4 *>(s_tab + L::kCosH + j * 20);
 #pragma unroll
         for (int i = 0; i < 5; ++i) ch[i] = h4[i];
     }
     // SYM: where this lane's three ln(mel) values go in the natural-order row (slots without a filter go to the pad entries)
     float *fr0 = frow + (fidx0 >= 0 ? fidx0 : 47), *fr1 = frow + (fidx1 >= 0 ? fidx1 : 47), *fr2 = frow + (fidx2 >= 0 ? fidx2 : 47);
-    float *sd = wbase + 192 + f * 40;  // s[20] = L[m] + L[39-m], d[20] = L[m] - L[39-m] of this frame
+    float *sd = ALIAS ? prow + 192 : wbase + 192 + f * 40;  // s[20] = L[m] + L[39-m], d[20] = L[m] - L[39-m] of this frame
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
     float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512): resident when the register budget allows (<= 3 waves per SIMD)
-    if (PREFETCH) {
+    if (TABREG) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) twn[r] = s_twn[r * 16 + j];
     }
@@ -273,17 +318,25 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     }
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
+    float touch = 0.f;
+    unsigned long long t_first = 0ull, t_last = 0ull;
 
     while (quad < q_hi) {
         // claim the next quad now so that its samples can be prefetched during this one
-        unsigned next = 0;
-        if (lane == 0) next = atomicAdd(s_next, 1u);
-        next = __builtin_amdgcn_readfirstlane(next);
+        unsigned next = 0, next_v = 0;
+        if (lane == 0) next_v = atomicAdd(s_next, 1u);
+        if (!(SS_OPT & 2)) next = __builtin_amdgcn_readfirstlane(next_v);
         ++n_done;
+        if (a.dbg) t_last = __builtin_amdgcn_s_memrealtime();
 
         if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
         const unsigned t_cur = t_next;
         float2 v[16];
+        if (a.dbg && n_done == 1) {
+            // diagnostic runs: when this wave's first samples have arrived
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_first = __builtin_amdgcn_s_memrealtime();
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float2 s = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
@@ -297,15 +350,32 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
         fft16_reg(v);
+        if (!(SS_ABLATE & 4)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
+            for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
+        }
         wave_order();
+        if (SS_OPT & 2) next = __builtin_amdgcn_readfirstlane(next_v);
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
-        if (PREFETCH && next < q_hi) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
+        if (SS_OPT & 4) asm volatile("" ::"v"(touch));
+        if (PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
+        if ((SS_OPT & 4) && next + WAVES < q_hi && lane < 26) {
+            // pull the lines of a quad this CU claims about one round from now into L2 (the sample loads then hit)
+            const unsigned q4t = (next + WAVES) * 4;
+            const unsigned clip_t = a.nf_magic ? __umulhi(q4t, a.nf_magic) >> a.nf_shift : q4t / a.n_frames;
+            const float *pt = a.x + static_cast<unsigned long long>(clip_t) * a.ld + (q4t - clip_t * a.n_frames) * a.step + lane * 32;
+            const float *last = a.x + static_cast<unsigned long long>(a.batch - 1) * a.ld + a.n_samples - 1;
+            touch = *(pt < last ? pt : last);
+        }
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
+            if (SS_ABLATE & 4) {
+                u[2 * p] = v[2 * p];
+                u[2 * p + 1] = v[2 * p + 1];
+                continue;
+            }
             const float4 t4 = *reinterpret_cast<const float4 *>(&zh[34 * p + 2 * j]);
             u[2 * p] = make_float2(t4.x, t4.y);
             u[2 * p + 1] = make_float2(t4.z, t4.w);
@@ -317,13 +387,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
         }
-        fft16_reg(u);  // u[r] = Z[j + 16 r]
+        if (!(SS_ABLATE & 64)) fft16_reg(u);  // u[r] = Z[j + 16 r]
 
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // all 16 partner fetches (register 15 - r of lane 16 - j) go out back to back: one LDS wait
         float2 zcs[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
+        for (int r = 0; r < 8; ++r) {
+            if (SS_OPT & 1) continue;  // fetched by DPP where it is used
+            zcs[r] = (SS_ABLATE & 1) ? u[15 - r] : make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
+        }
         float esum = 0.f;
         // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
         // per register and frame on either side of the spectrum
@@ -337,8 +410,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         for (int r = 0; r < 8; ++r) {
             const float2 zk = u[r];
             // lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
-            const float2 zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
-            const float2 w = PREFETCH ? twn[r] : s_twn[r * 16 + j];
+            float2 zc;
+            if (SS_OPT & 1) {
+                // columns 0 and 8 pair with themselves: Z[256 - 16 r] = register (16 - r) & 15, Z[248 - 16 r] = register 15 - r
+                const float2 own = j == 0 ? u[(16 - r) & 15] : u[15 - r];
+                const float2 mir = make_float2(dpp<0x140>(u[15 - r].x), dpp<0x140>(u[15 - r].y));  // row_mirror
+                zc = (j == 0 || j == 8) ? own : mir;
+            } else {
+                zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
+            }
+            const float2 w = TABREG ? twn[r] : s_twn[r * 16 + j];
             const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
             const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
             // 2 X[k] = s - i w d, 2 conj X[256-k] = s + i w d = 2 s - 2 X[k]: six FMAs instead of a product and four adds
@@ -346,8 +427,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             const float xa_i = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
             const float xb_r = fmaf(2.f, s.x, -xa_r), xb_i = fmaf(2.f, s.y, -xa_i);
             const float na = xa_r * xa_r + xa_i * xa_i, nb = xb_r * xb_r + xb_i * xb_i;
-            const float pa = POW2 ? na : __builtin_amdgcn_sqrtf(na);  // unscaled; hscale is applied to the sums below
-            const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
+            const float pa = (POW2 || (SS_ABLATE & 8)) ? na : __builtin_amdgcn_sqrtf(na);  // unscaled; hscale is applied to the sums below
+            const float pb = (POW2 || (SS_ABLATE & 8)) ? nb : __builtin_amdgcn_sqrtf(nb);
             if (PWR) {
                 if (pw_row) {
                     pw_row[j + 16 * r] = hs_pw * pa;
@@ -371,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 esum += p128;
             }
         }
-        if (FULLP && j < 3) prow[257 + j] = 0.f;  // pad bins (the slot was overwritten by the exchange)
+        if ((FULLP || ALIAS) && j < 3) prow[(FULLP ? 257 : 129) + j] = 0.f;  // pad bins (the slot was overwritten by the exchange)
         if (PWR) {
             wave_order();
             quad = next;
@@ -383,6 +464,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
         float m0, m1, m2;
+        if (SS_ABLATE & 2) {
+            const unsigned gf = quad * 4 + f;
+            if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = energy;
+            wave_order();
+            quad = next;
+            continue;
+        }
         if (BANK421) {
             m0 = mel_slot_fixed<4>(w4, smem_f + st0);
             m1 = mel_slot_fixed<2>(w4 + 4, smem_f + st1);
@@ -415,7 +503,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         m1 *= hscale32;
         m2 *= hscale32;
         float acc = 0.f;
-        if (SYM) {
+        if (SS_ABLATE & 32) {
+            acc = ln_scaled(m0 + m1 + m2);
+        } else if (SYM) {
             // ---- DCT-II with cos(pi c (2(39-m)+1)/80) = (-1)^c cos(pi c (2m+1)/80): natural-order row, then the sum and
             // difference rows once per frame; an even coefficient is a 20-term product with s, an odd one with d ----
             fr0[0] = ln_scaled(m0 == 0.f ? kEps * kTwo32 : m0);
@@ -436,6 +526,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             float4 rq[5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) rq[i] = r4[i];
+            if (!TABREG) {
+                const float4 *h4 = reinterpret_cast<const float4 *>(s_tab + L::kCosH + j * 20);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) ch[i] = h4[i];
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 acc = fmaf(rq[i].x, ch[i].x, acc);
@@ -485,10 +580,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         quad = next;
     }
     if (a.dbg && lane == 0) {
-        unsigned long long *d = a.dbg + 4ull * (blockIdx.x * WAVES + wave);
+        unsigned long long *d = a.dbg + 6ull * (blockIdx.x * WAVES + wave);
         d[0] = t_start;
         d[1] = t_pro;
         d[2] = __builtin_amdgcn_s_memrealtime();
+        d[4] = t_first;
+        d[5] = t_tab;
         d[3] = (static_cast<unsigned long long>(n_done) << 32) | __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // XCC_ID
     }
 }
@@ -513,7 +610,7 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             a.nf_shift = l - 1;
         }
     }
-    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloats + L::kMelW + 16 * a.mel_wpitch + (a.win_floats > 0 ? a.win_floats : 0)) * sizeof(float) + 16;
+    const size_t lds = (static_cast<size_t>(WAVES) * (WAVES > 12 ? 4 * kZStride * 2 : kWaveFloats) + L::kMelW + 16 * a.mel_wpitch + (a.win_floats > 0 ? a.win_floats : 0)) * sizeof(float) + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
     if (total == 0) return hipSuccess;
@@ -580,7 +677,8 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
         }
         if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 1>, "ss_mfcc_c256<10,exact,bank421,mfe>");
-        if (WAVES <= 12 && res == 6 && a.n_filters == 40) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 6>, "ss_mfcc_c256<10,exact,bank421,sym>");
+        if (res == 6 && a.n_filters == 40)
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, WAVES <= 12 ? 6 : 4>, WAVES <= 12 ? "ss_mfcc_c256<10,exact,bank421,sym>" : "ss_mfcc_c256<10,exact,bank421,sym,w16>");
         if (res == 6) res = 2;  // the symmetric DCT is written for exactly 40 filters
         if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
         if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
@@ -620,6 +718,7 @@ hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cu
     // 12 waves per CU (3 per SIMD, <= 168 VGPRs, 138 KB of LDS): measured equal to 14 and 16 and 8 % faster than 8
     static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
     if (w && std::atoi(w) == 8 && !a.fullp && !a.center) return launch_w<8>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 16 && !a.fullp && !a.center) return launch_w<16>(a, stream, num_cus, info);
     return launch_w<12>(a, stream, num_cus, info);
 }
 

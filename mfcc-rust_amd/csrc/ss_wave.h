@@ -16,6 +16,13 @@ __device__ __forceinline__ void wave_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also drains the wave's outstanding global loads
+// (s_waitcnt vmcnt(0) in front of s_barrier), which would make every wave wait for the slowest wave's first samples.
+__device__ __forceinline__ void wg_barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ds_bpermute_b32: every lane reads `v` of the lane whose number is addr / 4 (LDS crossbar, no memory round trip)
 __device__ __forceinline__ float bperm(int addr, float v)
 {
