@@ -369,6 +369,62 @@ static HostTables without_bank(const HostTables &t)
     return e;
 }
 
+
+// Bank-conflict-free placement of one tap slot's filters for kernels that read taps as aligned float4s of a P row
+// (ds_read_b128).  A wave64 ds_read_b128 is served in four groups of 16 lanes (MI355X guide, LDS section); 64 banks hold 16
+// float4 slots, so a group is conflict-free when its lanes' first float4 slots differ mod 16.  `lanes` (32 or 64) lanes share
+// one P row; filter q may start at any float4 slot in [lo4[q], hi4[q]] (earlier starts mean zero weights in front).  A
+// bipartite matching (Kuhn) assigns filters to (group, residue) cells; lane_of[q] / start4_of[q] return the placement, and
+// start4_idle[lane] a harmless first slot for lanes without a filter.  Filters that cannot be matched take a free cell at
+// their latest start (a conflict costs time, never correctness).
+static void place_taps_b128(int lanes, const std::vector<int32_t> &lo4, const std::vector<int32_t> &hi4, std::vector<int32_t> &lane_of,
+                            std::vector<int32_t> &start4_of, std::vector<int32_t> &start4_idle)
+{
+    static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int n = static_cast<int>(lo4.size()), groups = lanes / 16, cells = groups * 16;
+    std::vector<int> owner(cells, -1);  // cell = group * 16 + residue -> filter
+    std::vector<int> cell_of(n, -1);
+    lane_of.assign(n, 0);
+    start4_of.assign(n, 0);
+    std::function<bool(int, std::vector<char> &)> place = [&](int q, std::vector<char> &seen) -> bool {
+        for (int32_t b = hi4[q]; b >= lo4[q] && b > hi4[q] - 16; --b) {
+            for (int g = 0; g < groups; ++g) {
+                const int c = g * 16 + (b & 15);
+                if (seen[c]) continue;
+                seen[c] = 1;
+                if (owner[c] < 0 || place(owner[c], seen)) {
+                    owner[c] = q;
+                    cell_of[q] = c;
+                    start4_of[q] = b;
+                    return true;
+                }
+            }
+        }
+        return false;
+    };
+    for (int q = 0; q < n && q < cells; ++q) {
+        std::vector<char> seen(cells, 0);
+        place(q, seen);
+    }
+    for (int q = 0; q < n && q < cells; ++q) {
+        if (cell_of[q] >= 0) continue;
+        for (int c = 0; c < cells; ++c)
+            if (owner[c] < 0) {
+                owner[c] = q;
+                cell_of[q] = c;
+                start4_of[q] = hi4[q];
+                break;
+            }
+    }
+    auto lane_of_cell = [&](int c) { return kGroup[(c / 16) & 1][c & 15] + 32 * (c / 32); };
+    start4_idle.assign(lanes, 0);
+    for (int c = 0; c < cells; ++c) {
+        if (owner[c] >= 0) lane_of[owner[c]] = lane_of_cell(c);
+        else start4_idle[lane_of_cell(c)] = c & 15;  // its own residue: no conflict with the group's other lanes
+    }
+}
+
 void build_fast512(const HostTables &t, Fast512Tables &f)
 {
     namespace L = fast512_layout;
@@ -763,21 +819,28 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
     int32_t off = 0;
     for (int s = 0; s < 4; ++s) {
         const int32_t span = 4 * f.q4[s];
+        // the slot's filters go to lanes and first float4 slots that keep the lock-step ds_read_b128 tap reads conflict-free
+        // (32 lanes share a P row: two read groups of 16 lanes)
+        std::vector<int32_t> lo4, hi4, lane_of, start4_of, idle;
         for (int j = 0; j < 32; ++j) {
             const size_t q = static_cast<size_t>(s) * 32 + j;
-            start[q] = 0;
-            filt[q] = -1;
-            if (q >= M) continue;
-            const int32_t m = order[q];
-            filt[q] = m;
-            const int32_t len = t.bank.len[m];
-            int32_t shift = len ? (t.bank.start[m] & 3) : 0;
-            int32_t st = len ? t.bank.start[m] - shift : 0;
-            if (st + span > kRow) {  // keep the span inside the row (both are multiples of 4)
-                shift += st + span - kRow;
-                st = kRow - span;
-            }
-            start[q] = st;
+            if (q >= M) break;
+            const int32_t m = order[q], len = t.bank.len[m], st = len ? t.bank.start[m] : 0;
+            hi4.push_back(len ? std::min(st, kRow - span) / 4 : (kRow - span) / 4);  // an empty filter may read anywhere
+            lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
+            if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
+        }
+        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle);
+        for (int j = 0; j < 32; ++j) {
+            start[s * 32 + j] = 4 * idle[j];
+            filt[s * 32 + j] = -1;
+        }
+        for (size_t k = 0; k < lo4.size(); ++k) {
+            const size_t q = static_cast<size_t>(s) * 32 + k;
+            const int32_t m = order[q], len = t.bank.len[m], j = lane_of[k], st = 4 * start4_of[k];
+            const int32_t shift = len ? t.bank.start[m] - st : 0;  // zero weights in front of the filter's first tap
+            start[s * 32 + j] = st;
+            filt[s * 32 + j] = m;
             for (int32_t i = 0; i < len; ++i)
                 f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
         }
@@ -1011,21 +1074,27 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
     int32_t off = 0;
     for (int s = 0; s < 4; ++s) {
         const int32_t span = 4 * f.q4[s];
+        // the slot's filters go to lanes and first float4 slots that keep the lock-step ds_read_b128 tap reads conflict-free
+        std::vector<int32_t> lo4, hi4, lane_of, start4_of, idle;
         for (int j = 0; j < 64; ++j) {
             const size_t q = static_cast<size_t>(s) * 64 + j;
-            start[q] = 0;
-            filt[q] = -1;
-            if (q >= M) continue;
-            const int32_t m = order[q];
-            filt[q] = m;
-            const int32_t len = t.bank.len[m];
-            int32_t shift = len ? (t.bank.start[m] & 3) : 0;
-            int32_t st = len ? t.bank.start[m] - shift : 0;
-            if (st + span > kRow) {  // keep the span inside the row (both are multiples of 4)
-                shift += st + span - kRow;
-                st = kRow - span;
-            }
-            start[q] = st;
+            if (q >= M) break;
+            const int32_t m = order[q], len = t.bank.len[m], st = len ? t.bank.start[m] : 0;
+            hi4.push_back(len ? std::min(st, kRow - span) / 4 : (kRow - span) / 4);  // an empty filter may read anywhere
+            lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
+            if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
+        }
+        place_taps_b128(64, lo4, hi4, lane_of, start4_of, idle);
+        for (int j = 0; j < 64; ++j) {
+            start[s * 64 + j] = 4 * idle[j];
+            filt[s * 64 + j] = -1;
+        }
+        for (size_t k = 0; k < lo4.size(); ++k) {
+            const size_t q = static_cast<size_t>(s) * 64 + k;
+            const int32_t m = order[q], len = t.bank.len[m], j = lane_of[k], st = 4 * start4_of[k];
+            const int32_t shift = len ? t.bank.start[m] - st : 0;  // zero weights in front of the filter's first tap
+            start[s * 64 + j] = st;
+            filt[s * 64 + j] = m;
             for (int32_t i = 0; i < len; ++i)
                 f.tab[melw0 + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
         }

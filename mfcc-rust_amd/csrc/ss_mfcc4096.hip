@@ -24,6 +24,10 @@
 
 #include <cstdlib>
 
+#ifndef SS_TOUCH
+#define SS_TOUCH 1
+#endif
+
 namespace ss {
 
 namespace {
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
     unsigned frame = f_lo + wave;
+    float touch = 0.f;
     while (frame < f_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);
@@ -128,6 +133,19 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 if (rem >= 1) v[e].x = fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), v[e].x);
                 if (rem >= 2) v[e].y = fmaf(-a.preemph, preemph_tap(xc, pos + 1, psh, a.n_samples), v[e].y);
             }
+        }
+        if (SS_TOUCH) {
+            // The frames of a workgroup's range are claimed in order, so frame next + WAVES is asked for about one iteration
+            // from now by a wave of this CU; of its samples only the last `step` are new to the CU's caches.  One load per
+            // 128-byte line pulls them into L2 now (issued behind this frame's own loads: loads return in order), so that
+            // the sample loads at the top of an iteration hit instead of waiting for HBM.
+            asm volatile("" ::"v"(touch));  // the previous touch has long returned; keeps its register live until here
+            // (no branch around the load: behind a conditional load the compiler has to wait for vmcnt(0), i.e. for the touch)
+            const unsigned tf = min(next + WAVES, total - 1);
+            const unsigned clip_t = tf / a.n_frames, t_t = tf - clip_t * a.n_frames;
+            const float *pt = a.x + static_cast<unsigned long long>(clip_t) * a.ld + t_t * a.step + (a.flen > a.step ? a.flen - a.step : 0u) + (lane & 31) * 32;
+            const float *last = a.x + static_cast<unsigned long long>(a.batch - 1) * a.ld + a.n_samples - 1;
+            touch = *(pt < last ? pt : last);
         }
         if (WIN) {
             // optional frame window (mfcc_window switch): sample pairs from the copy in LDS

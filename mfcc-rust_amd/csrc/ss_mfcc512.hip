@@ -54,6 +54,7 @@
 // Experiment switches (tools/ablate.sh with OPT=<bits>), results stay correct:
 //   1 untangle partner by DPP row_mirror (lanes relabelled so that lane l and 15 - l hold columns j and 16 - j)
 //   2 the claimed quad number is read where it is first needed   4 touch-prefetch of the quad one round ahead
+//   8 the waves of a SIMD ask for their first samples one after the other (the CU cannot keep 12 quads of misses in flight)
 #ifndef SS_OPT
 #define SS_OPT 0
 #endif
@@ -266,6 +267,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     float2 vin[NE];
     float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
+    if (SS_OPT & 8) {
+        if (wave >= 8) __builtin_amdgcn_s_sleep(20);
+        else if (wave >= 4) __builtin_amdgcn_s_sleep(10);
+    }
     t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
     {
         if (tid == 0) *s_next = q_lo + WAVES;

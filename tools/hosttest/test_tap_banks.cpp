@@ -21,6 +21,25 @@ static int group_cycles(const int32_t *start, int slot, int prow_pitch)
     return static_cast<int>(worst);
 }
 
+// ds_read_b128 tap reads: four groups of 16 lanes; a group takes as many LDS cycles as its busiest float4 bank slot has
+// distinct addresses.  Returns the cycles of all groups of the slot.
+static int b128_cycles(const int32_t *start, int slot, int lanes)
+{
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int total = 0;
+    for (int g = 0; g < lanes / 16; ++g) {
+        std::map<int, std::set<int>> slots;
+        for (int k = 0; k < 16; ++k) {
+            const int lane = grp[g & 1][k] + 32 * (g / 2), a4 = start[slot * lanes + lane] / 4;
+            slots[a4 & 15].insert(a4);
+        }
+        int worst = 0;
+        for (auto &b : slots) worst = std::max<int>(worst, static_cast<int>(b.second.size()));
+        total += worst;
+    }
+    return total;  // LDS cycles of one tap chunk of the slot; lanes / 16 when conflict-free
+}
+
 int main()
 {
     struct Case { const char *name; uint32_t sr, filters; float len; };
@@ -46,6 +65,40 @@ int main()
             const int cyc = group_cycles(start, s, f.fullp ? 576 : 144);
             std::printf("   -> %d LDS cycle(s) per tap group\n", cyc);
             if (!f.fullp && cyc != 1 && c.filters == 40) rc = 1;
+        }
+    }
+    {   // cfg5: 44.1 kHz, fft 4096, 256 filters (one P row per wave, 64 lanes)
+        ss_params p;
+        ss_params_default(&p, 44100);
+        p.fft_points = 4096; p.frame_length = 4096.f / 44100.f; p.frame_stride = 1024.f / 44100.f; p.num_cepstral = 40; p.num_filters = 256;
+        ss::HostTables t;
+        ss::Mfcc4096Tables f;
+        if (ss::build_tables(p, t) == 0) ss::build_mfcc4096(t, f);
+        if (!f.ok) { std::printf("cfg5: no table\n"); rc = 1; }
+        else {
+            const int32_t *start = reinterpret_cast<const int32_t *>(f.tab.data() + ss::mfcc4096_layout::kStart);
+            for (int s = 0; s < 4; ++s) {
+                const int cyc = b128_cycles(start, s, 64);
+                std::printf("cfg5 slot %d (q4 %d): %d LDS cycles per tap chunk (4 conflict-free)\n", s, f.q4[s], cyc);
+                if (cyc > 6) rc = 1;
+            }
+        }
+    }
+    {   // cfg3: 16 kHz, fft 2048, 128 filters (32 lanes per P row)
+        ss_params p;
+        ss_params_default(&p, 16000);
+        p.fft_points = 2048; p.frame_length = 0.032f; p.frame_stride = 0.032f; p.num_filters = 128; p.high_frequency = 8000.f;
+        ss::HostTables t;
+        ss::Mel2048Tables f;
+        if (ss::build_tables(p, t) == 0) ss::build_mel2048(t, f);
+        if (!f.ok) { std::printf("cfg3: no table\n"); rc = 1; }
+        else {
+            const int32_t *start = reinterpret_cast<const int32_t *>(f.tab.data() + ss::mel2048_layout::kStart);
+            for (int s = 0; s < 4; ++s) {
+                const int cyc = b128_cycles(start, s, 32);
+                std::printf("cfg3 slot %d (q4 %d): %d LDS cycles per tap chunk (2 conflict-free)\n", s, f.q4[s], cyc);
+                if (cyc > 4) rc = 1;
+            }
         }
     }
     return rc;
