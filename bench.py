@@ -9,11 +9,14 @@ cfg2 = 1024 x 1 s clips @16 kHz, SpeechConfig defaults (n_fft 512, hop 160, 40 m
 one fused kernel launch per step.  To keep the 256 MiB Infinity Cache from serving the input,
 steps rotate over enough distinct input batches to exceed it (8 x 65.5 MB for cfg2).
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  Clips are independent,
-so every rank processes its own batch of the same size (weak scaling) and there is no data-path
-collective; --gather adds an RCCL all-gather of the [frames x n_mfcc] blocks, overlapped on a
-side stream, for the north-star's "gather over xGMI" variant.  cfg4 (the 100 h corpus, 360 000
-clips) is the one strong-scaling workload: the corpus is split into contiguous clip shards
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  `python bench.py --gpus N`
+starts the N ranks itself (fresh child processes, spawned before this process touches the GPU); under
+torch.distributed.run it uses the ranks it is given.  Clips are independent, so every rank processes its
+own batch of the same size (weak scaling) with no collective inside the path; the north-star's "RCCL
+gather over xGMI of the final [n_frames x n_mfcc] blocks" is part of every N > 1 step: the blocks of
+--gather-every consecutive steps form one bucket that is all-gathered on a side stream while the next
+steps' kernels run (--no-gather switches it off).  cfg4 (the 100 h corpus, 360 000 clips) is the one
+strong-scaling workload: the corpus is split into contiguous clip shards
 (speechsauce_amd.distributed.shard_bounds), one per rank, one launch per shard per step.
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (4 B per input
@@ -36,6 +39,9 @@ for _p in (os.path.join(ROOT, "mfcc-rust_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 64 FLOP/clk/SIMD
+# algorithmic flop per output row (FFT 2.5 N log2 N + magnitudes + mel taps + logs + DCT)
+ALGO_FLOP_PER_ROW = {"cfg2": 14.2e3, "cfg4": 14.2e3, "cfg3": 63.0e3, "cfg5": 157.0e3}
 
 WORKLOADS = {
     # name: (description, params kwargs, clip samples, clips per GPU, kind)
@@ -125,18 +131,53 @@ def cpu_baseline_all_cores(kind, pkw, n_samples, budget_s=6.0):
             "sample": f"{clips} clips in {el:.1f} s on {cores} threads (one per logical core), same port as cpu_baseline"}
 
 
-def load_traffic(kernel_name, workload):
-    """HBM bytes per launch from the committed PMC profile of this kernel+workload (or None)."""
+def load_profile(kernel_name, workload, headline):
+    """Stored PMC figures of this kernel + workload from profiles/pmc_traffic.json (written by tools/make_traffic_json.py
+    from a rocprofv3 --pmc run of this same command; NOT measured in this run).  A headline configuration whose kernel is
+    not the profiled one fails loudly instead of reporting null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        e = d.get(workload)
-        if e and kernel_name.split("<")[0] in e.get("kernel_full", ""):
-            return e.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
-    return None
+    none = {"traffic": None, "traffic_source": "none (this configuration has no stored PMC profile)"}
+    if not headline:
+        return none
+    with open(path) as f:
+        d = json.load(f)
+    e = d.get(workload)
+    if not e:
+        return none
+    if kernel_name.split("<")[0] not in e.get("kernel_full", ""):
+        raise SystemExit(f"bench.py: profiles/pmc_traffic.json holds {e.get('kernel_full')!r} for {workload}, but the launch ran "
+                         f"{kernel_name!r}: re-run tools/profile.sh + tools/make_traffic_json.py")
+    out = {"traffic": e.get("hbm_bytes_per_launch"),
+           "traffic_source": "profiles/pmc_traffic.json (stored: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                             f"{e.get('profiled', 'round 1')}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"}
+    for k in ("valu_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac", "lds_busy_frac"):
+        if k in e:
+            out[k] = e[k]
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE set) and
+    relay rank 0's JSON line.  Runs before this process imports torch or touches the GPU; nothing is re-exec'd."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -146,7 +187,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the workload's)")
-    ap.add_argument("--gather", action="store_true", help="add an overlapped RCCL all-gather of the outputs")
+    ap.add_argument("--gather", action="store_true", help="(default for --gpus > 1) overlapped RCCL all-gather of the output blocks")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1 without the collective: independent shards only")
+    ap.add_argument("--gather-every", type=int, default=8, help="steps per all-gather bucket (fewer, larger collectives)")
+    ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed launches before the warm-up steps, to leave the idle power state")
     ap.add_argument("--streams", type=int, default=1, help="issue successive steps round-robin on this many HIP streams "
                     "(independent batches in flight: one launch's tail overlaps the next one's head); the roofline block "
                     "is then per-step wall time, not a kernel duration -- not the headline setting")
@@ -155,6 +199,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -166,24 +213,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if n_dev == 0:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    if os.environ.get("SS_BENCH_ONE_DEVICE"):  # test aid: several ranks on one GPU (exercises the multi-rank control flow)
-        local_rank = 0
+    shared_device = world > n_dev or bool(os.environ.get("SS_BENCH_ONE_DEVICE"))  # several ranks per GPU: control-flow check only
+    local_rank = 0 if os.environ.get("SS_BENCH_ONE_DEVICE") else local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver)
-        try:
-            dist.init_process_group(backend="nccl", device_id=device)  # RCCL
-        except Exception as e:  # the control plane (barrier, max over ranks) also works over gloo; --gather needs RCCL
-            if args.gather:
-                raise
-            print(f"[bench] rank {rank}: RCCL init failed ({e}); using gloo for the barriers", file=sys.stderr, flush=True)
+        if not shared_device:
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL; a failure here is fatal, not papered over
+            backend = "nccl"
+        else:  # RCCL refuses two ranks on one device: the control flow (sharding, buckets, barriers) runs over gloo
             dist.init_process_group(backend="gloo")
+            backend = "gloo"
+            print(f"[bench] rank {rank}: {world} ranks share {n_dev} device(s): gloo instead of RCCL, timings are not a scaling result",
+                  file=sys.stderr, flush=True)
+    do_gather = world > 1 and not args.no_gather
 
     desc, pkw, n_samples, clips, kind = WORKLOADS[args.workload]
     if args.params:
@@ -222,8 +272,44 @@ def main():
     sptrs = [sptr] + [C.c_void_p(st.cuda_stream) for st in extra_streams]
     outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(max(2, 2 * args.streams))]
 
+    # The gather (north-star: "RCCL gather over xGMI of the final [n_frames x n_mfcc] blocks"): the outputs of
+    # `gather_every` consecutive steps land in one bucket [G, clips, rows, ceps]; a full bucket is all-gathered into
+    # [world, G, ...] on a side stream while the following steps compute into the other bucket.
+    from speechsauce_amd.distributed import all_gather_into
+
+    G = 1 if strong else max(1, args.gather_every)  # a corpus shard's block is already a large message
+    buckets = gathered = comm_stream = None
+    bucket_done = [None, None]
+    if do_gather:
+        buckets = [torch.empty((G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
+        gathered = [torch.empty((world * G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
+        comm_stream = torch.cuda.Stream(device=device)
+        outs = None  # steps write straight into the bucket slots
+
+    def out_for(i):
+        if buckets is None:
+            return outs[i % len(outs)]
+        b = (i // G) % 2
+        if i % G == 0 and bucket_done[b] is not None:  # the bucket's previous gather must have read it
+            stream.wait_event(bucket_done[b])
+        return buckets[b][i % G]
+
+    def after_step(i, last):
+        """Launch the all-gather of a bucket once its last step has been issued."""
+        if buckets is None or not ((i + 1) % G == 0 or last):
+            return
+        b = (i // G) % 2
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev)
+            all_gather_into(gathered[b], buckets[b])
+            done = torch.cuda.Event()
+            done.record(comm_stream)
+        bucket_done[b] = done
+
     def step(i):
-        x, o, sp = xs[i % n_buf], outs[i % len(outs)], sptrs[i % len(sptrs)]
+        x, o, sp = xs[i % n_buf], out_for(i), sptrs[i % len(sptrs)]
         if kind == "mfcc":
             rc = lib.ss_mfcc_batch_device(cfg.handle, x.data_ptr(), clips, n_samples, n_samples, o.data_ptr(), sp)
         else:
@@ -232,28 +318,20 @@ def main():
             _lib.check(rc)
         return o
 
-    gather_bufs, comm_stream, pending = None, None, []
-    if args.gather and world > 1:
-        gather_bufs = [torch.empty((world,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
-        comm_stream = torch.cuda.Stream(device=device)
-
-    def gather(i, o):
-        # all-gather of step i's block on a side stream; overlaps the next step's kernel
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ev)
-            dist.all_gather_into_tensor(gather_bufs[i % 2], o)
-            done = torch.cuda.Event()
-            done.record(comm_stream)
-        pending.append(done)
-        if len(pending) > 1:  # the buffer pair is reused two steps later
-            stream.wait_event(pending.pop(0))
-
+    if args.prewarm_ms > 0:  # leave the idle power state before the (possibly few) warm-up steps
+        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+        k = 0
+        while time.perf_counter() < t_end:
+            for _ in range(50):
+                step(k)
+                k += 1
+            torch.cuda.synchronize()
     for i in range(args.warmup):
-        o = step(i)
-        if gather_bufs is not None:
-            gather(i, o)
+        step(i)
+        after_step(i, i + 1 == args.warmup)
+    if comm_stream is not None:
+        comm_stream.synchronize()
+    bucket_done = [None, None]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -266,9 +344,8 @@ def main():
     t0 = time.perf_counter()
     e0.record(stream)
     for i in range(args.steps):
-        o = step(i)
-        if gather_bufs is not None:
-            gather(i, o)
+        step(i)
+        after_step(i, i + 1 == args.steps)
         if args.streams == 1 and (i + 1) % seg_every == 0 and i + 1 < args.steps:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(stream)
@@ -288,7 +365,7 @@ def main():
     dev_ms = e0.elapsed_time(e1)  # HIP events on the launch stream over the timed region
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -319,9 +396,16 @@ def main():
                 "clips_per_gpu": clips,
                 "samples_per_clip": n_samples,
                 "frames_per_clip": rows,
-                "parallelism": f"clip-sharded x{world}" + (" + RCCL all-gather (overlapped)" if gather_bufs is not None else ", no collective")
+                "parallelism": f"clip-sharded x{world}" + (f" + all-gather of the output blocks over {backend} in buckets of {G} steps, overlapped"
+                                                              if do_gather else ", no collective")
                                + (f", {args.streams} streams" if args.streams > 1 else ""),
             },
+            "backend": backend,
+            "rccl_ranks": world if backend == "nccl" else 0,
+            "ranks_share_a_device": bool(shared_device) if world > 1 else False,
+            "gather": ({"collective": "all_gather_into_tensor", "bucket_steps": G, "bytes_per_rank_per_step": 4 * out_elems,
+                        "bytes_received_per_rank_per_step": 4 * out_elems * (world - 1)} if do_gather else None),
+            "prewarm_ms": args.prewarm_ms,
             "real_time_factor": value / rows * (n_samples / pkw["sample_rate"]),
             "roofline": {
                 "bound": "hbm",
@@ -330,11 +414,17 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(kernel, args.workload),
+                **load_profile(kernel, args.workload, headline=not (args.params or args.kind or args.clips)),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launch_us_median_min_max_over_tenths": [segs[len(segs) // 2], segs[0], segs[-1]],
                 "frames_per_sec_kernel_only": frames_per_launch / avg_launch_s,
+                # secondary ceiling: FP32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s) against the algorithmic flop count of SURVEY 8d
+                "valu": ({"algorithmic_flop_per_launch": ALGO_FLOP_PER_ROW[args.workload] * frames_per_launch,
+                          "achieved_tflops": ALGO_FLOP_PER_ROW[args.workload] * frames_per_launch / avg_launch_s / 1e12,
+                          "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                          "frac": ALGO_FLOP_PER_ROW[args.workload] * frames_per_launch / avg_launch_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
+                         if not (args.params or args.kind) else None),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -102,6 +102,8 @@ struct DeviceBuf {
     T *as() { return static_cast<T *>(p); }
 };
 
+int check_device(const ss_config *cfg);
+
 void fill_common(const ss_config *cfg, ss::FrontArgs &a)
 {
     const ss::HostTables &h = cfg->host;
@@ -126,10 +128,16 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
                   float *out0, float *out1, hipStream_t stream)
 {
     if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (batch == 0) return SS_OK;  // an empty batch has no buffers (a zero-row tensor's data pointer is null)
     if (!d_x || !out0) return ss::fail(SS_ERR_ARG, "null buffer");
     if (ld < n) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
-    if (batch == 0) return SS_OK;
     if (n > 0x7fffffffull || batch > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "clip too long / batch too large");
+    {
+        // the tables live on the device the config was created on: a launch from another current device would hand this
+        // device pointers into that one's memory
+        const int drc = check_device(cfg);
+        if (drc) return drc;
+    }
     const ss::HostTables &h = cfg->host;
     size_t T = 0;
     int rc = ss::num_frames(h.params, n, T);
@@ -465,10 +473,14 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
                 float *out0, hipStream_t stream)
 {
     if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (channels == 0) return SS_OK;  // nothing to do, and no buffers to check
     if (!d_x || !out0) return ss::fail(SS_ERR_ARG, "null buffer");
     if (ld < n) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
-    if (channels == 0) return SS_OK;
     if (n == 0 || n > 0x7fffffffull || channels > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "bad clip length / channel count");
+    {
+        const int drc = check_device(cfg);  // see launch_frames
+        if (drc) return drc;
+    }
     const ss::HostTables &h = cfg->host;
     size_t R = 0, Rreal = 0;
     int rc = ss::stft_rows(h.params, n, R, Rreal);
@@ -859,7 +871,13 @@ int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t bat
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     SS_HIP(hipEventCreate(&e0));
-    SS_HIP(hipEventCreate(&e1));
+    {
+        const hipError_t ec = hipEventCreate(&e1);
+        if (ec != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return hip_fail(ec, "hipEventCreate");
+        }
+    }
     int rc = ss_mfcc_batch_device(cfg, d_x, batch, n_samples, ld, d_out, stream);  // warm-up
     if (rc == SS_OK) {
         (void)hipEventRecord(e0, s);
@@ -883,7 +901,13 @@ int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     SS_HIP(hipEventCreate(&e0));
-    SS_HIP(hipEventCreate(&e1));
+    {
+        const hipError_t ec = hipEventCreate(&e1);
+        if (ec != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return hip_fail(ec, "hipEventCreate");
+        }
+    }
     int rc = ss_mel_spectrogram_device(cfg, d_x, channels, n_samples, ld, d_out, stream);
     if (rc == SS_OK) {
         (void)hipEventRecord(e0, s);

@@ -74,10 +74,34 @@ def _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral,
 @lru_cache(maxsize=32)
 def _get_speech_config(sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13, num_filters=40,
                        fft_length=512, low_frequency=0, high_frequency: Optional[float] = None,
-                       dc_elimination=True, switches: tuple = ()) -> SpeechConfig:
-    """Memoised config factory (py-speechsauce/speechsauce/__init__.py:8-34)."""
+                       dc_elimination=True, switches: tuple = (), device: int = -1) -> SpeechConfig:
+    """Memoised config factory (py-speechsauce/speechsauce/__init__.py:8-34).
+
+    ``device`` is part of the key: a config owns tables in the memory of the HIP device that was current when it was
+    created, so each device gets its own (-1 = whichever device is current, the host-array path)."""
+    if device >= 0:
+        import torch
+
+        with torch.cuda.device(device):
+            return _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                                  low_frequency, dc_elimination, high_frequency, **dict(switches))
     return _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
                           low_frequency, dc_elimination, high_frequency, **dict(switches))
+
+
+def _device_key(signal) -> int:
+    """Index of the ROCm device a tensor lives on; -1 for host arrays (the library's current device)."""
+    if _is_torch(signal) and signal.is_cuda:
+        return signal.device.index if signal.device.index is not None else -1
+    if not _is_torch(signal):
+        try:  # host arrays run on the current device: key the config by it, so that a later ss_set_device gets its own
+            import torch
+
+            if torch.cuda.is_initialized():
+                return torch.cuda.current_device()
+        except Exception:
+            pass
+    return -1
 
 
 def _require_f32(signal, ndims: tuple[int, ...], what: str):
@@ -177,9 +201,10 @@ def _internal_mel_spectrogram(signal, config: SpeechConfig):
 # ---- public API (py-speechsauce/speechsauce/__init__.py:37-132) ------------------------------------
 
 def _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length, low_frequency,
-         high_frequency, dc_elimination, switches) -> SpeechConfig:
+         high_frequency, dc_elimination, switches, signal=None) -> SpeechConfig:
     return _get_speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
-                              low_frequency, high_frequency, dc_elimination, tuple(sorted(switches.items())))
+                              low_frequency, high_frequency, dc_elimination, tuple(sorted(switches.items())),
+                              _device_key(signal) if signal is not None else -1)
 
 
 def mfcc(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13, num_filters=40,
@@ -192,7 +217,7 @@ def mfcc(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_
     """
     sig = _require_f32(signal, (1,), "mfcc")
     config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
-                  low_frequency, high_frequency, dc_elimination, switches)
+                  low_frequency, high_frequency, dc_elimination, switches, sig)
     return _internal_mfcc_batch(sig[None, :], config)[0]
 
 
@@ -201,7 +226,7 @@ def mfcc_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.0
     """Batch form: [B, L] float32 -> [B, num_frames, num_cepstral] in one launch."""
     sig = _require_f32(signals, (2,), "mfcc_batch")
     config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
-                  low_frequency, high_frequency, dc_elimination, switches)
+                  low_frequency, high_frequency, dc_elimination, switches, sig)
     return _internal_mfcc_batch(sig, config)
 
 
@@ -210,7 +235,7 @@ def mfe(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_f
     """Mel filterbank energies and frame energies (feature.rs:200-233): ((T, num_filters), (T,))."""
     sig = _require_f32(signal, (1,), "mfe")
     config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
-                  low_frequency, high_frequency, True, switches)
+                  low_frequency, high_frequency, True, switches, sig)
     feat, en = _internal_mfe_batch(sig[None, :], config)
     return feat[0], en[0]
 
@@ -219,7 +244,7 @@ def mfe_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.01
               low_frequency=0, high_frequency=None, **switches):
     sig = _require_f32(signals, (2,), "mfe_batch")
     config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
-                  low_frequency, high_frequency, True, switches)
+                  low_frequency, high_frequency, True, switches, sig)
     return _internal_mfe_batch(sig, config)
 
 
@@ -235,7 +260,7 @@ def mel_spectrogram(signal, sampling_frequency, frame_length=0.020, frame_stride
     """
     sig = _require_f32(signal, (1, 2), "mel_spectrogram")
     config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
-                  low_frequency, high_frequency, dc_elimination, switches)
+                  low_frequency, high_frequency, dc_elimination, switches, sig)
     return _internal_mel_spectrogram(sig, config)
 
 

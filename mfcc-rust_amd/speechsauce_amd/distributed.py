@@ -24,6 +24,31 @@ def shard_sizes(n_items: int, world: int):
     return [shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0] for r in range(world)]
 
 
+def _backend(group=None) -> str:
+    import torch.distributed as dist
+
+    return str(dist.get_backend(group)).lower()
+
+
+def all_gather_into(out, block, group=None):
+    """One all-gather of equal blocks: `out` [world * B, ...] <- `block` [B, ...] of every rank.
+
+    RCCL (backend "nccl") moves device tensors directly over xGMI.  Under gloo (the CPU tests, or several ranks sharing one
+    GPU, which RCCL refuses) device blocks are staged through host memory: same result, no claim about speed."""
+    import torch
+    import torch.distributed as dist
+
+    if _backend(group) == "nccl" or not block.is_cuda:
+        dist.all_gather_into_tensor(out, block, group=group)
+        return out
+    world = dist.get_world_size(group)
+    host = block.detach().cpu()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host, group=group)
+    out.copy_(torch.cat(parts, dim=0).to(out.device, non_blocking=False))
+    return out
+
+
 def all_gather_features(local, n_total: int, group=None):
     """local: [B_rank, ...] feature block of this rank's shard -> [n_total, ...] on every rank.
 
@@ -45,7 +70,7 @@ def all_gather_features(local, n_total: int, group=None):
         padded = torch.zeros((bmax,) + tail, dtype=local.dtype, device=local.device)
         padded[: local.shape[0]] = local
     out = torch.empty((world * bmax,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    all_gather_into(out, padded, group=group)
     if all(s == bmax for s in sizes):
         return out
     return torch.cat([out[r * bmax: r * bmax + sizes[r]] for r in range(world)], dim=0)
