@@ -1,0 +1,118 @@
+"""The three mirrors of the C ABI -- the ctypes structure of the Python front, the oracle's parameter structure and the
+`#[repr(C)]` structure + `extern "C"` block of the Rust shim (shipped uncompiled: the image has no rustc) -- are checked
+against include/speechsauce_amd.h by parsing the sources: field order, field types, size, and for every function the Rust shim
+declares, its name, arity and argument kinds."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "speechsauce_amd.h")
+SHIM = os.path.join(ROOT, "mfcc-rust_amd", "rust-shim", "src", "lib.rs")
+
+C_TO_KIND = {"uint32_t": "u32", "int32_t": "i32", "float": "f32", "int": "i32", "long": "long", "size_t": "usize"}
+RUST_TO_KIND = {"u32": "u32", "i32": "i32", "f32": "f32", "c_int": "i32", "c_long": "long", "usize": "usize"}
+CTYPES_TO_KIND = {C.c_uint32: "u32", C.c_int32: "i32", C.c_float: "f32"}
+
+
+def _strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def header_struct():
+    text = _strip_c_comments(open(HEADER).read())
+    body = re.search(r"typedef struct ss_params \{(.*?)\} ss_params;", text, flags=re.S).group(1)
+    return [(C_TO_KIND[t], n) for t, n in re.findall(r"(\w+)\s+(\w+)\s*;", body)]
+
+
+def header_functions():
+    text = _strip_c_comments(open(HEADER).read())
+    out = {}
+    for ret, name, args in re.findall(r"^\s*(const char \*|int|void)\s*(ss_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S | re.M):
+        kinds = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                kinds.append("ptr")
+            else:
+                kinds.append(C_TO_KIND[a.replace("const ", "").split()[0]])
+        out[name] = (ret.strip(), kinds)
+    return out
+
+
+def rust_struct():
+    text = open(SHIM).read()
+    body = re.search(r"#\[repr\(C\)\][^{]*?pub struct SsParams \{(.*?)\n\}", text, flags=re.S).group(1)
+    body = re.sub(r"//[^\n]*", "", body)
+    return [(RUST_TO_KIND[t], n) for n, t in re.findall(r"pub (\w+):\s*(\w+)\s*,", body)]
+
+
+def rust_externs():
+    text = open(SHIM).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', text, flags=re.S).group(1)
+    out = {}
+    for name, args, ret in re.findall(r"fn (\w+)\((.*?)\)\s*(->\s*[^;]+)?;", block, flags=re.S):
+        kinds = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",") if x.strip()]:
+            ty = a.split(":", 1)[1].strip()
+            kinds.append("ptr" if ty.startswith("*") else RUST_TO_KIND[ty])
+        out[name] = (ret.replace("->", "").strip(), kinds)
+    return out
+
+
+def test_ctypes_structure_matches_the_header():
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "mfcc-rust_amd"))
+    from speechsauce_amd._lib import SsParams
+
+    want = header_struct()
+    got = [(CTYPES_TO_KIND[t], n) for n, t in SsParams._fields_]
+    assert got == want
+    assert C.sizeof(SsParams) == 4 * len(want)  # every field is 4 bytes wide, no padding
+    for i, (_, n) in enumerate(want):
+        assert getattr(SsParams, n).offset == 4 * i
+
+
+def test_oracle_structure_matches_the_header():
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle_c import OrcParams
+
+    assert [(CTYPES_TO_KIND[t], n) for n, t in OrcParams._fields_] == header_struct()
+
+
+def test_rust_shim_structure_matches_the_header():
+    want = header_struct()
+    assert rust_struct() == want
+    assert 4 * len(want) == 4 * len(rust_struct())
+
+
+def test_rust_shim_externs_match_the_header():
+    hdr = header_functions()
+    ext = rust_externs()
+    assert len(ext) >= 10
+    for name, (ret, kinds) in ext.items():
+        assert name in hdr, f"{name} is not declared in include/speechsauce_amd.h"
+        hret, hkinds = hdr[name]
+        assert kinds == hkinds, (name, kinds, hkinds)
+        if hret == "int":
+            assert ret == "c_int", name
+        elif hret == "void":
+            assert ret == "", name
+        else:
+            assert ret.startswith("*const c_char"), name
+
+
+def test_struct_size_is_announced_by_the_library(sslib):
+    """ss_params_default writes struct_size = sizeof(ss_params): the compiled library agrees with the parsed header."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "mfcc-rust_amd"))
+    from speechsauce_amd._lib import SsParams
+
+    p = SsParams()
+    assert sslib.ss_params_default(C.byref(p), 16000) == 0
+    assert p.struct_size == C.sizeof(SsParams) == 4 * len(header_struct())
