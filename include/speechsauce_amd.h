@@ -43,7 +43,7 @@ typedef enum ss_status {
     SS_ERR_UNSUPPORTED = 5   /* valid in the reference but not built here (fft_points > 8192, or > 2730 and not a power of two) */
 } ss_status;
 
-enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1, SS_FRAMING_CENTER = 2 };
+enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1, SS_FRAMING_CENTER = 2, SS_FRAMING_PADDED = 3 };
 enum { SS_DCT_REFERENCE = 0, SS_DCT_ORTHO = 1 };
 enum { SS_WINDOW_RECT = 0, SS_WINDOW_HANN = 1 /* periodic, functions.rs:349-357 */, SS_WINDOW_VORBIS = 2 };
 /* librosa-compatible variants (the reference's stated goal, README.md:3,44) */
@@ -76,7 +76,10 @@ typedef struct ss_params {
                                    contract (processing.rs:55-64).  SS_FRAMING_LITERAL: the exact_chunks copy as
                                    written (processing.rs:110-120), which leaves every frame zero for > 2 frames.
                                    SS_FRAMING_CENTER: librosa center=True -- frame t covers
-                                   x[t*step - flen/2 : t*step + flen/2), 1 + n/step frames, edges per pad_mode */
+                                   x[t*step - flen/2 : t*step + flen/2), 1 + n/step frames, edges per pad_mode.
+                                   SS_FRAMING_PADDED: stack_frames(zero_padding = true), processing.rs:85-97 --
+                                   ceil((L - flen) / step) frames, the last ones reading appended zeros (what the
+                                   reference's test_stack_frames calls, lib.rs:50-68) */
     int32_t  spectrum_exponent; /* 1: |X|/N as written (processing.rs:168,180); 2: |X|^2/N (speechpy) */
     int32_t  dct_norm;          /* SS_DCT_REFERENCE: scaling as written (feature.rs:126-131); SS_DCT_ORTHO */
     float    dct2_gain;         /* SS_DCT2_GAIN */
@@ -187,6 +190,19 @@ int ss_extract_derivative_feature_device(const float *d_feat, size_t rows, size_
 
 /* stage outputs (parity triage; pub fns of the reference too):
  * power_spectrum (processing.rs:179-181) over the frames of each clip: [batch x n_frames x (fft_points/2+1)] */
+/* lmfe (feature.rs:242-245, README.md:14 "log mel filterbank energies"): ln of mfe's zero-handled energies, [frames x
+ * num_filters].  d_energy may be NULL (the frame energies mfe also produces are then kept in a stream-ordered temporary). */
+int ss_lmfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat);
+int ss_lmfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *feat);
+int ss_lmfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                         float *d_feat, float *d_energy, void *stream);
+/* in-place natural logarithm of n device floats (the element-wise pass of lmfe; util.rs:372-381) */
+int ss_ln_device(float *d_x, size_t n, void *stream);
+/* librosa.power_to_db (the reference's stated remaining work, README.md:44-46): 10 log10(max(amin, S)) - 10 log10(max(amin,
+ * |ref|)), then floored at max(result) - top_db; top_db < 0 switches the floor off.  amin > 0. */
+int ss_power_to_db(const float *s, size_t n, float ref, float amin, float top_db, float *out);
+int ss_power_to_db_device(const float *d_s, size_t n, float ref, float amin, float top_db, float *d_out, void *stream);
+
 int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,
                                    size_t ld, float *d_P, void *stream);
 /* stft2 (functions.rs:86-123): interleaved re,im  [channels x rows x (fft_points/2+1) x 2] */

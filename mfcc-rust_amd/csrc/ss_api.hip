@@ -31,8 +31,6 @@ struct ss_config {
     // fft_points = 512 MFCC kernel tables (ss_mfcc512.hip)
     ss::Fast512Tables fast;
     float *d_fast_tab = nullptr;
-    ss::Fast512MTables fastm;
-    float *d_fastm_tab = nullptr;
     // fft_points = 2048 mel-spectrogram kernel tables (ss_mel2048.hip)
     ss::Mel2048Tables mel2048;
     float *d_mel2048_tab = nullptr;
@@ -154,6 +152,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // processing.rs:110-120 as written: nothing is copied for > 2 frames, x[0..flen] into every row otherwise
     if (h.params.framing == SS_FRAMING_LITERAL) a.frame_mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
     else if (h.params.framing == SS_FRAMING_CENTER) a.frame_mode = ss::FRAME_CENTER;  // librosa center=True (generic kernel only)
+    else if (h.params.framing == SS_FRAMING_PADDED) a.frame_mode = ss::FRAME_PADDED;  // zero_padding = true (generic kernel only)
     else a.frame_mode = ss::FRAME_NORMAL;
     a.pad_reflect = h.params.pad_mode == SS_PAD_REFLECT;
     a.preemph = h.params.preemph_coef;
@@ -194,45 +193,9 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     const bool fast_ok = !force_generic && cfg->fast.ok &&
                          (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape) || (out_kind == ss::OUT_POWER && mfe_shape && !front)) &&
                          (lib_variant ? lib_ok : (!front || mfe_shape)) && (a.frame_mode == ss::FRAME_NORMAL || centre);
-    // SS_MFCC512_VARIANT=mfma selects the block-sparse f32-MFMA mel+DCT build (ss_mfcc512_mfma.hip) for A/B runs
-    static const char *variant = std::getenv("SS_MFCC512_VARIANT");
-    const bool want_mfma = variant && std::strcmp(variant, "mfma") == 0;
     const bool fits32 = static_cast<unsigned long long>(batch) * T < 0xffffffffull;
     static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only: per-wave realtime stamps of ONE launch
     static bool dbg_done = false;
-    if (fast_ok && fits32 && cfg->fastm.ok && want_mfma && out_kind == ss::OUT_MFCC && !front && !lib_variant && (a.flen % 2 == 0) &&
-        (a.step % 2 == 0) && (ld % 2 == 0) && (reinterpret_cast<uintptr_t>(d_x) % 8 == 0)) {  // the A/B build keeps the old layout assumptions
-        ss::Fast512MArgs f{};
-        f.x = d_x;
-        f.ld = ld;
-        f.n_samples = a.n_samples;
-        f.batch = a.batch;
-        f.flen = a.flen;
-        f.step = a.step;
-        f.n_frames = a.n_frames;
-        f.scale = a.scale;
-        f.spectrum_exponent = a.spectrum_exponent;
-        f.tab = cfg->d_fastm_tab;
-        for (int s = 0; s < 3; ++s) {
-            f.ks_lo[s] = cfg->fastm.ks_lo[s];
-            f.ks_hi[s] = cfg->fastm.ks_hi[s];
-        }
-        f.n_mm = cfg->fastm.n_mm;
-        f.n_filters = a.n_filters;
-        f.n_ceps = a.n_ceps;
-        f.dct_scale_k = a.dct_scale_k;
-        f.dct_scale_0 = a.dct_scale_0;
-        f.dct_scale_00 = a.dct_scale_00;
-        f.dc_elimination = a.dc_elimination;
-        f.out = out0;
-        const hipError_t e = ss::launch_mfcc_c256_mx(f, stream, cfg->num_cus, &info);
-        if (e == hipSuccess) {
-            g_last_kernel = info.kernel_name;
-            return SS_OK;
-        }
-        // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
-        if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mfcc_c256_mx");
-    }
     if (fast_ok && fits32) {
         ss::Fast512Args f{};
         f.x = d_x;
@@ -685,10 +648,6 @@ int ss_config_create(const ss_params *p, ss_config **out)
     if (c->mel4096.ok || c->mel4096.stft_only) SS_UP(d_mel4096_tab, c->mel4096.tab);
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok || c->mel2048.stft_only) SS_UP(d_mel2048_tab, c->mel2048.tab);
-    ss::build_fast512m(h, c->fastm);
-    if (c->fastm.ok) {
-        SS_UP(d_fastm_tab, c->fastm.tab);
-    }
 #undef SS_UP
     *out = cfg.release();
     return SS_OK;
@@ -699,7 +658,7 @@ void ss_config_destroy(ss_config *cfg)
     if (!cfg) return;
     void *ptrs[] = {cfg->d_window_mfcc, cfg->d_window_stft, cfg->d_tw_c, cfg->d_tw_n, cfg->d_blu_c, cfg->d_blu_b, cfg->d_f_start,
                     cfg->d_f_len,       cfg->d_f_off,       cfg->d_f_w,  cfg->d_dct,
-                    cfg->d_fast_tab,    cfg->d_fastm_tab,   cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mfcc512w_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
+                    cfg->d_fast_tab,    cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mfcc512w_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete cfg;
@@ -725,6 +684,56 @@ int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, si
 {
     if (!d_energy) return ss::fail(SS_ERR_ARG, "null buffer");
     return launch_frames(cfg, ss::OUT_MFE, d_x, batch, n_samples, ld, d_feat, d_energy, static_cast<hipStream_t>(stream));
+}
+
+// lmfe (feature.rs:242-245): ln of mfe's zero-handled filterbank energies.  The frame energies mfe also returns are
+// dropped, as in the reference; a caller that has room for them passes d_energy, otherwise a stream-ordered temporary is used.
+int ss_lmfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                         float *d_feat, float *d_energy, void *stream)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (batch == 0) return SS_OK;
+    size_t T = 0;
+    int rc = ss::num_frames(cfg->host.params, n_samples, T);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *tmp = nullptr;
+    if (!d_energy) {
+        SS_HIP(hipMallocAsync(reinterpret_cast<void **>(&tmp), batch * T * sizeof(float), st));
+        d_energy = tmp;
+    }
+    rc = launch_frames(cfg, ss::OUT_MFE, d_x, batch, n_samples, ld, d_feat, d_energy, st);
+    if (rc == SS_OK) rc = ss_ln_device(d_feat, batch * T * cfg->host.params.num_filters, stream);
+    if (tmp) {
+        const hipError_t e = hipFreeAsync(tmp, st);
+        if (e != hipSuccess && rc == SS_OK) rc = hip_fail(e, "hipFreeAsync");
+    }
+    return rc;
+}
+
+int ss_lmfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *feat)
+{
+    if (!cfg || !x || !feat) return ss::fail(SS_ERR_ARG, "null argument");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    size_t T = 0;
+    int rc = ss::num_frames(cfg->host.params, n_samples, T);
+    if (rc) return rc;
+    if (batch == 0) return SS_OK;
+    rc = check_device(cfg);
+    if (rc) return rc;
+    const size_t in_elems = (batch - 1) * ld + n_samples, feat_elems = batch * T * cfg->host.params.num_filters;
+    DeviceBuf dx, dfeat;
+    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dfeat.alloc(feat_elems * sizeof(float)))) return rc;
+    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
+    rc = ss_lmfe_batch_device(cfg, dx.as<float>(), batch, n_samples, ld, dfeat.as<float>(), nullptr, nullptr);
+    if (rc) return rc;
+    SS_HIP(hipMemcpy(feat, dfeat.p, feat_elems * sizeof(float), hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+int ss_lmfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat)
+{
+    return ss_lmfe_batch(cfg, x, 1, n_samples, n_samples, feat);
 }
 
 int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,

@@ -15,7 +15,7 @@ enum OutKind : int32_t {
     OUT_STFT = 4    // [clips x R x F x 2]                        functions.rs:86-123
 };
 
-enum FrameMode : int32_t { FRAME_NORMAL = 0, FRAME_ZERO = 1, FRAME_FIRST = 2, FRAME_CENTER = 3 };
+enum FrameMode : int32_t { FRAME_NORMAL = 0, FRAME_ZERO = 1, FRAME_FIRST = 2, FRAME_CENTER = 3, FRAME_PADDED = 4 };
 
 struct FrontArgs {
     // input: `batch` clips of `n_samples`, row stride `ld` elements
@@ -112,32 +112,6 @@ struct Fast512Args {
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 // whether the kernel has an mfe-output / windowed / pre-emphasised build for this shape (the default bank at flen 320)
 bool mfcc_c256_has_mfe(const Fast512Args &a);
-
-// Arguments of the second-generation fft_points = 512 MFCC kernel (ss_mfcc512_mfma.hip).
-struct Fast512MArgs {
-    const float *x;
-    unsigned long long ld;
-    uint32_t n_samples, batch, flen, step, n_frames;
-    float scale;
-    int32_t spectrum_exponent;
-    // one table block, copied verbatim into LDS (layout: ss::fast512m_layout in ss_internal.h):
-    //   tw2 [15][16] float2  exp(-2 pi i j r / 256), r = 1..15
-    //   twn [8][16]  float2  exp(-2 pi i (j + 16 r) / 512)
-    //   ct  [12][64]         DCT MFMA A operands: cos(pi c (2m+1) / 2M), c = lane & 15, m = 16 tl + 4 (lane >> 4) + i
-    //   wt  [n_mm][64]       mel MFMA A operands: W[16 tl + (lane & 15)][4 s + (lane >> 4)], tile-major over the
-    //                        k-steps ks_lo[tl] <= s < ks_hi[tl] (4 bins each) that hold a non-zero weight
-    const float *tab;
-    int32_t ks_lo[3], ks_hi[3];
-    int32_t n_mm;
-    uint32_t n_filters, n_ceps;
-    float dct_scale_k, dct_scale_0, dct_scale_00;
-    int32_t dc_elimination;
-    float *out;
-    unsigned long long *dbg;  // diagnostic runs only: per-wave {start, after prologue, end} s_memrealtime stamps, or null
-    int32_t ablate;           // diagnostic runs only (SS_ABLATE): skip parts of the pipeline to price them; 0 in production
-};
-
-hipError_t launch_mfcc_c256_mx(const Fast512MArgs &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
 // Arguments of the fft_points = 2048 mel-spectrogram kernel (ss_mel2048.hip).
 struct Mel2048Args {

@@ -82,7 +82,7 @@ int validate(const ss_params &p)
         return fail(SS_ERR_BAD_CONFIG, "High frequency cannot be greater than half of the sampling frequency!");
     if (!(p.low_frequency >= 0.0f))  // feature.rs:51
         return fail(SS_ERR_BAD_CONFIG, "low frequency cannot be less than zero!");
-    if (p.framing < SS_FRAMING_CONTRACT || p.framing > SS_FRAMING_CENTER) return fail(SS_ERR_BAD_CONFIG, "framing switch");
+    if (p.framing < SS_FRAMING_CONTRACT || p.framing > SS_FRAMING_PADDED) return fail(SS_ERR_BAD_CONFIG, "framing switch");
     if (p.mel_scale < SS_MEL_REFERENCE || p.mel_scale > SS_MEL_HTK) return fail(SS_ERR_BAD_CONFIG, "mel_scale switch");
     if (p.mel_norm != SS_MEL_NORM_NONE && p.mel_norm != SS_MEL_NORM_SLANEY) return fail(SS_ERR_BAD_CONFIG, "mel_norm switch");
     if (p.mel_norm == SS_MEL_NORM_SLANEY && p.mel_scale == SS_MEL_REFERENCE)
@@ -120,6 +120,12 @@ int num_frames(const ss_params &p, size_t n, size_t &t)
     }
     // processing.rs:101: ((len - flen) as f32 / step as f32).floor() as usize; len < flen underflows.
     if (n < d.flen) return fail(SS_ERR_SHORT_SIGNAL, "signal shorter than one frame");
+    if (p.framing == SS_FRAMING_PADDED) {
+        // stack_frames(zero_padding = true), processing.rs:91-92: ceil in f32; frames past the signal read appended zeros
+        t = static_cast<size_t>(ceilf(static_cast<float>(n - d.flen) / static_cast<float>(d.step)));
+        if (t == 0) return fail(SS_ERR_SHORT_SIGNAL, "signal yields zero frames");
+        return SS_OK;
+    }
     const float q = floorf(static_cast<float>(n - d.flen) / static_cast<float>(d.step));
     t = static_cast<size_t>(q);
     // processing.rs:105: (numframes - 1) underflows for numframes == 0.
@@ -727,55 +733,6 @@ void build_mfcc256(const HostTables &t, Mfcc256Tables &f)
     f.ok = true;
 }
 
-void build_fast512m(const HostTables &t, Fast512MTables &f)
-{
-    namespace L = fast512m_layout;
-    f = Fast512MTables{};
-    const int M = static_cast<int>(t.params.num_filters), Cc = static_cast<int>(t.params.num_cepstral);
-    const int F = static_cast<int>(t.d.n_bins);
-    if (t.d.n_fft != 512 || M > 48 || Cc > 16) return;
-    if (t.bank.last_bin > 129) return;  // the P tile keeps bins 0..128 (the bank ends at (F+1)/2 when high = sr/2)
-    std::vector<float> wt;
-    for (int tl = 0; tl < 3; ++tl) {
-        int lo = 1 << 30, hi = 0;
-        for (int r = 0; r < 16; ++r) {
-            const int m = 16 * tl + r;
-            if (m >= M || t.bank.len[m] == 0) continue;
-            lo = std::min(lo, t.bank.start[m] / 4);
-            hi = std::max(hi, (t.bank.start[m] + t.bank.len[m] + 3) / 4);
-        }
-        if (hi == 0) lo = 0;
-        f.ks_lo[tl] = lo;
-        f.ks_hi[tl] = hi;
-        for (int s = lo; s < hi; ++s) {
-            for (int lane = 0; lane < 64; ++lane) {
-                const int m = 16 * tl + (lane & 15), bin = 4 * s + (lane >> 4);
-                wt.push_back(m < M && bin < F ? t.fb_dense[static_cast<size_t>(m) * F + bin] : 0.0f);
-            }
-            ++f.n_mm;
-        }
-    }
-    if (f.n_mm > 56) return;  // LDS budget of the kernel
-    f.tab.assign(static_cast<size_t>(L::kWt) + wt.size(), 0.0f);
-    for (int r = 1; r < 16; ++r)
-        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i j r / 256) = tw_c[j r]
-            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2] = t.tw_c[2 * (j * r)];
-            f.tab[L::kTw2 + ((r - 1) * 16 + j) * 2 + 1] = t.tw_c[2 * (j * r) + 1];
-        }
-    for (int r = 0; r < 8; ++r)
-        for (int j = 0; j < 16; ++j) {  // exp(-2 pi i (j + 16 r) / 512) = tw_n[j + 16 r]
-            f.tab[L::kTwn + (r * 16 + j) * 2] = t.tw_n[2 * (j + 16 * r)];
-            f.tab[L::kTwn + (r * 16 + j) * 2 + 1] = t.tw_n[2 * (j + 16 * r) + 1];
-        }
-    for (int tl = 0; tl < 3; ++tl)
-        for (int i = 0; i < 4; ++i)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int c = lane & 15, m = 16 * tl + 4 * (lane >> 4) + i;
-                if (c < Cc && m < M) f.tab[L::kCt + (tl * 4 + i) * 64 + lane] = t.dct[static_cast<size_t>(c) * M + m];
-            }
-    std::copy(wt.begin(), wt.end(), f.tab.begin() + L::kWt);
-    f.ok = true;
-}
 
 
 static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)

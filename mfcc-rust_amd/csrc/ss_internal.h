@@ -87,23 +87,6 @@ struct Fast512Tables {
 };
 void build_fast512(const HostTables &t, Fast512Tables &f);
 
-// Table block of the MFMA variant (ss_mfcc512_mfma.hip), float offsets; global layout == LDS layout.
-namespace fast512m_layout {
-constexpr int kTw2 = 0;                 // [15][16] float2
-constexpr int kTwn = kTw2 + 15 * 32;    // [8][16] float2
-constexpr int kCt = kTwn + 8 * 32;      // [12][64]
-constexpr int kWt = kCt + 12 * 64;      // [n_mm][64]
-}  // namespace fast512m_layout
-
-// The banded mel bank cut into 16-filter x 4-bin blocks (only the non-zero ones are kept), the DCT
-// cosines in MFMA A layout and the two twiddle tables, as ONE block.
-struct Fast512MTables {
-    bool ok = false;
-    std::vector<float> tab;
-    int32_t ks_lo[3] = {0, 0, 0}, ks_hi[3] = {0, 0, 0};
-    int32_t n_mm = 0;
-};
-void build_fast512m(const HostTables &t, Fast512MTables &f);
 
 // Table block of the fft_points = 2048 mel-spectrogram kernel (ss_mel2048.hip), float offsets.
 namespace mel2048_layout {

@@ -265,14 +265,15 @@ __global__ __launch_bounds__(kBlock) void ss_front_generic(const FrontArgs a)
             const unsigned t = active ? gf32 - clip * a.n_frames : 0u;
             const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
             // stack_frames (processing.rs:65-129, contract framing) + zero pad to N (:147-156)
-            const unsigned base = a.frame_mode == FRAME_NORMAL ? t * a.step : 0u;
+            const unsigned base = (a.frame_mode == FRAME_NORMAL || a.frame_mode == FRAME_PADDED) ? t * a.step : 0u;
             const unsigned lim = a.frame_mode == FRAME_ZERO ? 0u : (a.frame_mode == FRAME_FIRST ? (a.flen & ~1u) : a.flen);
             // sample i of the frame after framing, fused pre-emphasis and the optional window (zero beyond the frame)
             auto sample = [&](unsigned i) -> float {
                 float val = 0.0f;
                 if (active && i < lim) {
                     unsigned idx = base + i;
-                    bool inside = true;
+                    // FRAME_PADDED (stack_frames zero_padding = true, processing.rs:85-97): zeros past the signal
+                    bool inside = a.frame_mode != FRAME_PADDED || idx < a.n_samples;
                     if (a.frame_mode == FRAME_CENTER) {
                         // librosa center=True: the frame is centred on t*step; outside the clip np.pad 'reflect'
                         // (mirror without repeating the edge sample) or zeros

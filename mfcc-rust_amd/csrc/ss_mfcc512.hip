@@ -21,8 +21,8 @@
 //     ds_read_b128, all fetches of a stage issue back to back before the FMAs (LDS latency under load
 //     is several hundred cycles).  Not MFMA: on gfx950 v_mfma_f32_* shares the FP32 datapath with
 //     the VALU (measured: a VALU wave and an f32-MFMA wave on one SIMD take the SUM of their times),
-//     so a block-dense product costs 8x the sparse one (tools/ubench/mfma_valu_overlap.hip; the
-//     MFMA build of this kernel is kept as ss_mfcc512_mfma.hip for the A/B).
+//     so a block-dense product costs 8x the sparse one (tools/ubench/mfma_valu_overlap.hip; the retired
+//     MFMA build of this kernel is tools/experiments/ss_mfcc512_mfma.hip).
 //   * DCT-II: with 40 filters the log-mel row is written in filter order, each frame forms s[m] = L[m] + L[39-m]
 //     and d[m] = L[m] - L[39-m] once, and lane c < n_ceps multiplies 20 terms of s (even c) or d (odd c) with its
 //     half cosine row held in registers (template RES bit 2).  Other filter counts: 48-entry (slot, lane)-ordered
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
     float touch = 0.f;
-    unsigned long long t_first = 0ull, t_last = 0ull;
+    unsigned long long t_first = 0ull;
 
     while (quad < q_hi) {
         // claim the next quad now so that its samples can be prefetched during this one
@@ -332,7 +332,6 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         if (lane == 0) next_v = atomicAdd(s_next, 1u);
         if (!(SS_OPT & 2)) next = __builtin_amdgcn_readfirstlane(next_v);
         ++n_done;
-        if (a.dbg) t_last = __builtin_amdgcn_s_memrealtime();
 
         if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
         const unsigned t_cur = t_next;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 
 namespace ss {
@@ -46,6 +47,43 @@ struct SymWalk {
         }
     }
 };
+
+// ---- element-wise logarithms: lmfe's ln (feature.rs:242-245 -> util.rs:372-381) and librosa's power_to_db ----
+__global__ __launch_bounds__(256) void ss_ln_kernel(float *__restrict__ x, unsigned long long n)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g < n) x[g] = logf(x[g]);
+}
+
+// floats as ordered integers, so that atomicMax on an int finds the largest float (negative values included)
+__device__ __forceinline__ int float_key(float v)
+{
+    const int b = __float_as_int(v);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float key_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// 10 log10(max(amin, S)) - 10 log10(max(amin, ref)); the block maxima go to one word for the top_db clamp
+__global__ __launch_bounds__(256) void ss_power_to_db_kernel(const float *__restrict__ s, float *__restrict__ out, unsigned long long n, float amin,
+                                                            float ref_db, int *__restrict__ max_key)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    float db = -INFINITY;
+    if (g < n) {
+        db = 10.0f * log10f(fmaxf(amin, s[g])) - ref_db;
+        out[g] = db;
+    }
+    if (max_key) {
+        for (int m = 1; m < 64; m <<= 1) db = fmaxf(db, __shfl_xor(db, m, 64));
+        if ((threadIdx.x & 63) == 0 && db > -INFINITY) atomicMax(max_key, float_key(db));
+    }
+}
+
+__global__ __launch_bounds__(256) void ss_db_floor_kernel(float *__restrict__ out, unsigned long long n, float top_db, const int *__restrict__ max_key)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g < n) out[g] = fmaxf(out[g], key_float(*max_key) - top_db);
+}
 
 // ---- cmvn: column statistics in two kernels, no atomics (bit-reproducible) ----
 // partial sums of x and x^2 over a chunk of rows; thread = (clip, chunk, column), columns fastest
@@ -367,6 +405,52 @@ int ss_extract_derivative_feature(const float *feat, size_t rows, size_t cols, f
     return ss::via_device(feat, rows * cols, cube, 3 * rows * cols, [&](const float *di, float *dout) {
         int r = ss_extract_derivative_feature_device(di, rows, cols, dout, nullptr);
         if (r == SS_OK && hipDeviceSynchronize() != hipSuccess) r = ss::fail(SS_ERR_HIP, "ss_extract_derivative_feature: device error");
+        return r;
+    });
+}
+
+int ss_ln_device(float *d_x, size_t n, void *stream)
+{
+    if (n == 0) return SS_OK;
+    if (!d_x) return ss::fail(SS_ERR_ARG, "null buffer");
+    hipLaunchKernelGGL(ss::ss_ln_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_x, static_cast<unsigned long long>(n));
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_ln_kernel");
+}
+
+int ss_power_to_db_device(const float *d_s, size_t n, float ref, float amin, float top_db, float *d_out, void *stream)
+{
+    if (n == 0) return SS_OK;
+    if (!d_s || !d_out) return ss::fail(SS_ERR_ARG, "null buffer");
+    if (!(amin > 0.0f)) return ss::fail(SS_ERR_ARG, "amin must be strictly positive");  // librosa.power_to_db raises the same
+    if (!(ref > 0.0f) && ref != 0.0f) return ss::fail(SS_ERR_ARG, "ref must be non-negative");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float ref_db = 10.0f * std::log10(std::max(amin, std::fabs(ref)));
+    int *d_max = nullptr;
+    if (top_db >= 0.0f) {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&d_max), sizeof(int), st);
+        if (e != hipSuccess) return ss::hip_err(e, "hipMallocAsync");
+        e = hipMemsetAsync(d_max, 0x80, sizeof(int), st);  // 0x80808080: below the key of every finite float
+        if (e != hipSuccess) return ss::hip_err(e, "hipMemsetAsync");
+    }
+    hipLaunchKernelGGL(ss::ss_power_to_db_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, st, d_s, d_out, static_cast<unsigned long long>(n), amin,
+                       ref_db, d_max);
+    if (d_max) {
+        hipLaunchKernelGGL(ss::ss_db_floor_kernel, dim3(ss::blocks_for(n)), dim3(256), 0, st, d_out, static_cast<unsigned long long>(n), top_db, d_max);
+        const hipError_t e = hipFreeAsync(d_max, st);
+        if (e != hipSuccess) return ss::hip_err(e, "hipFreeAsync");
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : ss::hip_err(e, "ss_power_to_db kernels");
+}
+
+int ss_power_to_db(const float *s, size_t n, float ref, float amin, float top_db, float *out)
+{
+    if (n == 0) return SS_OK;
+    if (!s || !out) return ss::fail(SS_ERR_ARG, "null buffer");
+    return ss::via_device(s, n, out, n, [&](const float *di, float *dout) {
+        int r = ss_power_to_db_device(di, n, ref, amin, top_db, dout, nullptr);
+        if (r == SS_OK && hipDeviceSynchronize() != hipSuccess) r = ss::fail(SS_ERR_HIP, "ss_power_to_db: device error");
         return r;
     });
 }

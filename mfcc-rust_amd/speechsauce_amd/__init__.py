@@ -21,7 +21,7 @@ from . import _lib
 from ._lib import SpeechSauceError, SsParams, make_params  # noqa: F401
 
 __all__ = ["mfcc", "mel_spectrogram", "preemphasis", "cmvn", "cmvnw", "derivative_extraction", "extract_derivative_feature",
-           "mfe", "mfcc_batch", "mfe_batch", "SpeechConfig",
+           "mfe", "mfcc_batch", "mfe_batch", "lmfe", "lmfe_batch", "power_to_db", "SpeechConfig",
            "SpeechSauceError"]
 
 
@@ -246,6 +246,69 @@ def mfe_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.01
     config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
                   low_frequency, high_frequency, True, switches, sig)
     return _internal_mfe_batch(sig, config)
+
+
+def _internal_lmfe_batch(signal, config: SpeechConfig):
+    lib = _lib.lib()
+    B, L = signal.shape
+    T = config.num_frames(L)
+    M = config.params.num_filters
+    if _is_torch(signal):
+        import torch
+
+        x = signal if signal.stride(1) == 1 else signal.contiguous()
+        feat = torch.empty((B, T, M), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_lmfe_batch_device(config.handle, x.data_ptr(), B, L, x.stride(0) if B > 1 else L,
+                                                feat.data_ptr(), None, _stream_ptr()))
+        return feat
+    x = np.ascontiguousarray(signal)
+    feat = np.empty((B, T, M), dtype=np.float32)
+    _lib.check(lib.ss_lmfe_batch(config.handle, x.ctypes.data, B, L, L, feat.ctypes.data))
+    return feat
+
+
+def lmfe(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_filters=40, fft_length=512,
+         low_frequency=0, high_frequency=None, **switches):
+    """Log mel-filterbank energies (feature.rs:242-245; README.md:14): ln of mfe's features, (T, num_filters)."""
+    sig = _require_f32(signal, (1,), "lmfe")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
+                  low_frequency, high_frequency, True, switches, sig)
+    return _internal_lmfe_batch(sig[None, :], config)[0]
+
+
+def lmfe_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_filters=40, fft_length=512,
+               low_frequency=0, high_frequency=None, **switches):
+    sig = _require_f32(signals, (2,), "lmfe_batch")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, min(13, num_filters), num_filters, fft_length,
+                  low_frequency, high_frequency, True, switches, sig)
+    return _internal_lmfe_batch(sig, config)
+
+
+def power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0):
+    """librosa.power_to_db: 10 log10(max(amin, S)) - 10 log10(max(amin, |ref|)), floored at max - top_db (None: no floor).
+    The reference lists librosa's mel-spectrogram conventions as its remaining work (README.md:44-46).  numpy in -> numpy
+    out; a ROCm tensor stays on the device (current stream)."""
+    lib = _lib.lib()
+    td = -1.0 if top_db is None else float(top_db)
+    if top_db is not None and top_db < 0:
+        raise ValueError("top_db must be non-negative")
+    if _is_torch(S) and S.is_cuda:
+        import torch
+
+        if S.dtype != torch.float32:
+            raise TypeError("power_to_db: expected float32")
+        x = S.contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_power_to_db_device(x.data_ptr(), x.numel(), float(ref), float(amin), td, out.data_ptr(), _stream_ptr()))
+        return out
+    arr = np.ascontiguousarray(S.numpy() if _is_torch(S) else S)
+    if arr.dtype != np.float32:
+        raise TypeError("power_to_db: expected float32")
+    out = np.empty_like(arr)
+    _lib.check(lib.ss_power_to_db(arr.ctypes.data, arr.size, float(ref), float(amin), td, out.ctypes.data))
+    return out
 
 
 def mel_spectrogram(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13,

@@ -15,7 +15,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
 
 SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED = range(6)
-FRAMING = {"contract": 0, "literal": 1, "center": 2}
+FRAMING = {"contract": 0, "literal": 1, "center": 2, "padded": 3}
 MEL_SCALE = {"reference": 0, "slaney": 1, "htk": 2}
 MEL_NORM = {"none": 0, "slaney": 1}
 PAD_MODE = {"reflect": 0, "constant": 1}
@@ -88,6 +88,12 @@ PROTOTYPES = {
     "ss_mfe_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp, C.c_void_p]),
     "ss_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_preemphasis_device": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp, C.c_void_p]),
+    "ss_lmfe": (C.c_int, [_cfg, _fp, C.c_size_t, _fp]),
+    "ss_lmfe_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp]),
+    "ss_lmfe_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp, C.c_void_p]),
+    "ss_ln_device": (C.c_int, [_fp, C.c_size_t, C.c_void_p]),
+    "ss_power_to_db": (C.c_int, [_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp]),
+    "ss_power_to_db_device": (C.c_int, [_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp, C.c_void_p]),
     "ss_power_spectrum_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_stft_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_cmvn": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_int, _fp]),

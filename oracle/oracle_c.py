@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libss_oracle.so")
 
 ORC_OK, ORC_ERR_SHORT_SIGNAL, ORC_ERR_BAD_CONFIG, ORC_ERR_ARG = 0, 1, 2, 3
-FRAMING = {"contract": 0, "literal": 1, "center": 2}
+FRAMING = {"contract": 0, "literal": 1, "center": 2, "padded": 3}
 MEL_SCALE = {"reference": 0, "slaney": 1, "htk": 2}
 MEL_NORM = {"none": 0, "slaney": 1}
 PAD_MODE = {"reflect": 0, "constant": 1}

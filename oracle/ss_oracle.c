@@ -79,6 +79,15 @@ int orc_num_frames(const orc_params *p, size_t n, size_t *n_frames)
         return ORC_OK;
     }
     if (n < flen) return ORC_ERR_SHORT_SIGNAL;
+    if (p->framing == ORC_FRAMING_PADDED) {
+        /* stack_frames(zero_padding = true), processing.rs:85-97: ceil instead of floor; the frames that reach past the
+         * signal read the appended zeros (contract framing otherwise).  What the reference's test_stack_frames calls
+         * (lib.rs:50-68: 3124 frames for 1e6 samples, 20 ms / 20 ms @16 kHz). */
+        size_t tp = (size_t)ceilf((float)(n - flen) / (float)step);
+        if (tp == 0) return ORC_ERR_SHORT_SIGNAL;
+        *n_frames = tp;
+        return ORC_OK;
+    }
     float q = floorf((float)(n - flen) / (float)step);
     size_t t = (size_t)q;
     if (t == 0) return ORC_ERR_SHORT_SIGNAL;
@@ -475,7 +484,8 @@ int orc_power_spectrum(const orc_params *p, const float *x, size_t n, double *P)
                 buf[i] = sample_at(p, x, n, (size_t)pos);
             }
         } else {
-            for (size_t i = 0; i < flen; ++i) buf[i] = sample_at(p, x, n, t * step + i);
+            /* ORC_FRAMING_PADDED: samples past the signal are the appended zeros (processing.rs:93-96) */
+            for (size_t i = 0; i < flen; ++i) buf[i] = t * step + i < n ? sample_at(p, x, n, t * step + i) : 0.0;
         }
         if (win) for (size_t i = 0; i < flen; ++i) buf[i] *= (double)win[i];
         rfft_f64(buf, N, re, im, wre, wim);
@@ -720,7 +730,8 @@ int port_mfe_f32(const orc_params *p, const float *x, size_t n, float *feat, flo
         if (p->framing == ORC_FRAMING_LITERAL) {
             if (T <= 2) memcpy(frames + t * flen, src, (flen & ~(size_t)1) * sizeof(float));
         } else {
-            memcpy(frames + t * flen, src + t * step, flen * sizeof(float));
+            const size_t have = t * step >= n ? 0 : (n - t * step < flen ? n - t * step : flen); /* PADDED: zeros past the signal */
+            memcpy(frames + t * flen, src + t * step, have * sizeof(float));
         }
     }
     if (p->mfcc_window != ORC_WINDOW_RECT) {

@@ -45,7 +45,7 @@ extern "C" {
 #define ORC_DCT2_GAIN 2.0f
 
 enum { ORC_OK = 0, ORC_ERR_SHORT_SIGNAL = 1, ORC_ERR_BAD_CONFIG = 2, ORC_ERR_ARG = 3 };
-enum { ORC_FRAMING_CONTRACT = 0, ORC_FRAMING_LITERAL = 1, ORC_FRAMING_CENTER = 2 };
+enum { ORC_FRAMING_CONTRACT = 0, ORC_FRAMING_LITERAL = 1, ORC_FRAMING_CENTER = 2, ORC_FRAMING_PADDED = 3 };
 enum { ORC_MEL_REFERENCE = 0, ORC_MEL_SLANEY = 1, ORC_MEL_HTK = 2 };   /* librosa-compatible variants, SURVEY 8f-4 */
 enum { ORC_MEL_NORM_NONE = 0, ORC_MEL_NORM_SLANEY = 1 };
 enum { ORC_PAD_REFLECT = 0, ORC_PAD_CONSTANT = 1 };

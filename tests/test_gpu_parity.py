@@ -1100,8 +1100,8 @@ def test_mfcc_256_kernel(ss, oracle, sslib):
 
 
 def test_kernel_variants_agree(ss):
-    """The generic kernel, the MFMA build and the production kernel compute the same MFCCs (separate processes:
-    the variant is chosen once per process from the environment)."""
+    """The generic kernel and the production kernel compute the same MFCCs (separate processes: the variant is chosen once
+    per process from the environment)."""
     import subprocess
     import sys
 
@@ -1115,12 +1115,12 @@ def test_kernel_variants_agree(ss):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs, names = [], []
     with tempfile.TemporaryDirectory() as td:
-        for env in ({}, {"SS_MFCC512_VARIANT": "mfma"}, {"SS_FORCE_GENERIC": "1"}):
+        for env in ({}, {"SS_FORCE_GENERIC": "1"}):
             path = os.path.join(td, f"o{len(outs)}.npy")
             r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env={**os.environ, **env},
                                capture_output=True, text=True, check=True)
             names.append(r.stdout.strip().splitlines()[-1])
             outs.append(np.load(path))
-    assert names[0].startswith("ss_mfcc_c256<") and "mx" in names[1] and names[2].startswith("ss_front_generic")
+    assert names[0].startswith("ss_mfcc_c256<") and names[1].startswith("ss_front_generic")
     for o in outs[1:]:
         assert _rel(o, outs[0]) <= 2e-5
