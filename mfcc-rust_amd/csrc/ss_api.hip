@@ -3,6 +3,7 @@
 // stream.  There is no CPU compute path here: without a HIP device these return SS_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +59,17 @@ struct ss_config {
     // fft_points = 4096 mel-spectrogram kernel tables (ss_mel_c2048 in ss_mfcc4096.hip)
     ss::Mfcc4096Tables mel4096;
     float *d_mel4096_tab = nullptr;
+    // Host-pointer entry points (ss_mfcc_batch, ...): two private streams and two sets of device buffers, kept with the
+    // config so that a call costs no hipMalloc / hipFree and never touches the null stream.  One host call at a time per
+    // config (the mutex); calls on different configs, and device-pointer calls, run concurrently.
+    struct HostPipe {
+        std::mutex mu;
+        hipStream_t stream[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        void *d_in[2] = {nullptr, nullptr}, *d_out0[2] = {nullptr, nullptr}, *d_out1[2] = {nullptr, nullptr};
+        size_t cap_in = 0, cap_out0 = 0, cap_out1 = 0;
+    };
+    mutable HostPipe pipe;
 };
 
 namespace {
@@ -566,6 +578,67 @@ int check_device(const ss_config *cfg)
     return SS_OK;
 }
 
+// ---- host-pointer pipeline ---------------------------------------------------------------------
+// The reference's callers hand over host arrays (feature.rs:99 takes an ArrayView1, py lib.rs:167-177 a numpy array).
+// `units` rows of `n` samples (row stride `ld`) are cut into chunks of a few MB; chunk k uses buffer set k % 2 on its own
+// stream: H2D copy, kernel launch, D2H copy, all asynchronous, so the copy of chunk k + 1 runs while chunk k computes and
+// returns (PCIe is full duplex).  Pinned caller memory (hipHostMalloc / hipHostRegister / torch pin_memory) is DMA'd directly;
+// for pageable memory the runtime stages the copy and hipMemcpyAsync returns once the staging is done.
+// launch(d_x, units_in_chunk, d_out0, d_out1, stream) issues the kernels for one chunk.
+template <typename Launch>
+int host_pipeline(const ss_config *cfg, const float *x, size_t units, size_t n, size_t ld, float *out0, size_t out0_per_unit,
+                  float *out1, size_t out1_per_unit, Launch launch)
+{
+    ss_config::HostPipe &hp = cfg->pipe;
+    std::lock_guard<std::mutex> lock(hp.mu);
+    static const size_t chunk_bytes = [] {
+        const char *e = std::getenv("SS_HOST_CHUNK_MB");
+        const long mb = e ? std::atol(e) : 16;
+        return static_cast<size_t>(mb > 0 ? mb : 16) << 20;
+    }();
+    size_t cu = chunk_bytes / (ld * sizeof(float));
+    if (cu == 0) cu = 1;
+    if (cu > units) cu = units;
+    const size_t in_cap = ((cu - 1) * ld + n) * sizeof(float), o0_cap = cu * out0_per_unit * sizeof(float), o1_cap = cu * out1_per_unit * sizeof(float);
+    for (int b = 0; b < 2; ++b) {
+        if (!hp.stream[b]) {
+            SS_HIP(hipStreamCreateWithFlags(&hp.stream[b], hipStreamNonBlocking));
+            SS_HIP(hipEventCreateWithFlags(&hp.done[b], hipEventDisableTiming));
+        }
+    }
+    auto grow = [&](void *(&buf)[2], size_t &cap, size_t need) -> int {
+        if (need <= cap) return SS_OK;
+        for (int b = 0; b < 2; ++b) {
+            SS_HIP(hipStreamSynchronize(hp.stream[b]));
+            if (buf[b]) (void)hipFree(buf[b]);
+            buf[b] = nullptr;
+            SS_HIP(hipMalloc(&buf[b], need));
+        }
+        cap = need;
+        return SS_OK;
+    };
+    int rc;
+    if ((rc = grow(hp.d_in, hp.cap_in, in_cap)) || (rc = grow(hp.d_out0, hp.cap_out0, o0_cap))) return rc;
+    if (out1 && (rc = grow(hp.d_out1, hp.cap_out1, o1_cap))) return rc;
+    size_t k = 0;
+    for (size_t u0 = 0; u0 < units; u0 += cu, ++k) {
+        const int b = static_cast<int>(k & 1);
+        const size_t c = std::min(cu, units - u0);
+        hipStream_t st = hp.stream[b];
+        // the stream orders this chunk behind the previous use of the same buffer set
+        SS_HIP(hipMemcpyAsync(hp.d_in[b], x + u0 * ld, ((c - 1) * ld + n) * sizeof(float), hipMemcpyHostToDevice, st));
+        rc = launch(static_cast<const float *>(hp.d_in[b]), c, static_cast<float *>(hp.d_out0[b]), static_cast<float *>(hp.d_out1[b]), st);
+        if (rc) break;
+        SS_HIP(hipMemcpyAsync(out0 + u0 * out0_per_unit, hp.d_out0[b], c * out0_per_unit * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (out1) SS_HIP(hipMemcpyAsync(out1 + u0 * out1_per_unit, hp.d_out1[b], c * out1_per_unit * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    for (int b = 0; b < 2; ++b) {
+        const hipError_t e = hipStreamSynchronize(hp.stream[b]);
+        if (e != hipSuccess && rc == SS_OK) rc = hip_fail(e, "host pipeline");
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -661,6 +734,13 @@ void ss_config_destroy(ss_config *cfg)
                     cfg->d_fast_tab,    cfg->d_mel2048_tab, cfg->d_mfcc4096_tab, cfg->d_mfcc2048_tab, cfg->d_mfcc1024_tab, cfg->d_mfcc256_tab, cfg->d_mfcc512w_tab, cfg->d_mel512_tab, cfg->d_mel1024_tab, cfg->d_mel4096_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (int b = 0; b < 2; ++b) {
+        if (cfg->pipe.stream[b]) (void)hipStreamSynchronize(cfg->pipe.stream[b]);
+        for (void *p : {cfg->pipe.d_in[b], cfg->pipe.d_out0[b], cfg->pipe.d_out1[b]})
+            if (p) (void)hipFree(p);
+        if (cfg->pipe.done[b]) (void)hipEventDestroy(cfg->pipe.done[b]);
+        if (cfg->pipe.stream[b]) (void)hipStreamDestroy(cfg->pipe.stream[b]);
+    }
     delete cfg;
 }
 
@@ -721,14 +801,10 @@ int ss_lmfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_s
     if (batch == 0) return SS_OK;
     rc = check_device(cfg);
     if (rc) return rc;
-    const size_t in_elems = (batch - 1) * ld + n_samples, feat_elems = batch * T * cfg->host.params.num_filters;
-    DeviceBuf dx, dfeat;
-    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dfeat.alloc(feat_elems * sizeof(float)))) return rc;
-    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
-    rc = ss_lmfe_batch_device(cfg, dx.as<float>(), batch, n_samples, ld, dfeat.as<float>(), nullptr, nullptr);
-    if (rc) return rc;
-    SS_HIP(hipMemcpy(feat, dfeat.p, feat_elems * sizeof(float), hipMemcpyDeviceToHost));
-    return SS_OK;
+    return host_pipeline(cfg, x, batch, n_samples, ld, feat, T * cfg->host.params.num_filters, nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_lmfe_batch_device(cfg, d_x, c, n_samples, ld, d_o0, nullptr, st);
+                         });
 }
 
 int ss_lmfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat)
@@ -778,14 +854,10 @@ int ss_mfcc_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_s
     if (batch == 0) return SS_OK;
     rc = check_device(cfg);
     if (rc) return rc;
-    const size_t in_elems = (batch - 1) * ld + n_samples, out_elems = batch * T * cfg->host.params.num_cepstral;
-    DeviceBuf dx, dout;
-    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dout.alloc(out_elems * sizeof(float)))) return rc;
-    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
-    rc = ss_mfcc_batch_device(cfg, dx.as<float>(), batch, n_samples, ld, dout.as<float>(), nullptr);
-    if (rc) return rc;
-    SS_HIP(hipMemcpy(out, dout.p, out_elems * sizeof(float), hipMemcpyDeviceToHost));
-    return SS_OK;
+    return host_pipeline(cfg, x, batch, n_samples, ld, out, T * cfg->host.params.num_cepstral, nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_mfcc_batch_device(cfg, d_x, c, n_samples, ld, d_o0, st);
+                         });
 }
 
 int ss_mfcc(const ss_config *cfg, const float *x, size_t n_samples, float *out)
@@ -803,18 +875,10 @@ int ss_mfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_sa
     if (batch == 0) return SS_OK;
     rc = check_device(cfg);
     if (rc) return rc;
-    const size_t in_elems = (batch - 1) * ld + n_samples;
-    const size_t feat_elems = batch * T * cfg->host.params.num_filters, en_elems = batch * T;
-    DeviceBuf dx, dfeat, den;
-    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dfeat.alloc(feat_elems * sizeof(float))) ||
-        (rc = den.alloc(en_elems * sizeof(float))))
-        return rc;
-    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
-    rc = ss_mfe_batch_device(cfg, dx.as<float>(), batch, n_samples, ld, dfeat.as<float>(), den.as<float>(), nullptr);
-    if (rc) return rc;
-    SS_HIP(hipMemcpy(feat, dfeat.p, feat_elems * sizeof(float), hipMemcpyDeviceToHost));
-    SS_HIP(hipMemcpy(energy, den.p, en_elems * sizeof(float), hipMemcpyDeviceToHost));
-    return SS_OK;
+    return host_pipeline(cfg, x, batch, n_samples, ld, feat, T * cfg->host.params.num_filters, energy, T,
+                         [&](const float *d_x, size_t c, float *d_o0, float *d_o1, hipStream_t st) {
+                             return ss_mfe_batch_device(cfg, d_x, c, n_samples, ld, d_o0, d_o1, st);
+                         });
 }
 
 int ss_mfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat, float *energy)
@@ -832,14 +896,10 @@ int ss_mel_spectrogram(const ss_config *cfg, const float *x, size_t channels, si
     if (n_samples == 0) return ss::fail(SS_ERR_ARG, "empty signal");
     rc = check_device(cfg);
     if (rc) return rc;
-    const size_t in_elems = channels * n_samples, out_elems = channels * cfg->host.params.num_filters * R;
-    DeviceBuf dx, dout;
-    if ((rc = dx.alloc(in_elems * sizeof(float))) || (rc = dout.alloc(out_elems * sizeof(float)))) return rc;
-    SS_HIP(hipMemcpy(dx.p, x, in_elems * sizeof(float), hipMemcpyHostToDevice));
-    rc = ss_mel_spectrogram_device(cfg, dx.as<float>(), channels, n_samples, n_samples, dout.as<float>(), nullptr);
-    if (rc) return rc;
-    SS_HIP(hipMemcpy(out, dout.p, out_elems * sizeof(float), hipMemcpyDeviceToHost));
-    return SS_OK;
+    return host_pipeline(cfg, x, channels, n_samples, n_samples, out, cfg->host.params.num_filters * R, nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_mel_spectrogram_device(cfg, d_x, c, n_samples, n_samples, d_o0, st);
+                         });
 }
 
 int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, float *y)

@@ -36,6 +36,11 @@ constexpr int kSlotFloats = 576;        // per frame pair: exchange slot (288 fl
 constexpr int kWaveFloatsX = 4 * kSlotFloats;
 constexpr int kPRowX = 132;             // bins 0..128 + three zero pad bins
 constexpr float kPairGuard = 1000.f;    // energy ratio (30 dB) beyond which the two frames of a pair are transformed one at a time
+// A pair transform leaves rounding noise of ~3e-7 of the pair's largest bin in EVERY bin of both frames.  A bin below
+// kTinyBin of that maximum (squared form: kTinyBin^2) -- in particular a bin that cancels exactly in a transform of its own
+// (full-scale square wave, pure tones on bin centres: the reference then has an exact 0 -> f32::EPSILON, functions.rs:66-71) --
+// would come out with a visible relative error, so an oct in which any pair has such a bin is run again, each frame alone.
+constexpr float kTinyBin = 1e-4f;
 
 
 
@@ -146,10 +151,18 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         for (int e = 0; e < NE; ++e) wn[e] = s_win[j + 16 * e];
     }
 
+    constexpr unsigned kNone = 0xffffffffu;
+    unsigned held = kNone;  // an oct this wave has claimed but postponed, because the current one is run a second time
+    bool alone = false;     // run the current oct one frame per transform (set by the tiny-bin check of its first run)
     while (oct < o_hi) {
         unsigned next = 0;
-        if (lane == 0) next = atomicAdd(s_next, 1u);
-        next = __builtin_amdgcn_readfirstlane(next);
+        if (held != kNone) {
+            next = held;
+            held = kNone;
+        } else {
+            if (lane == 0) next = atomicAdd(s_next, 1u);
+            next = __builtin_amdgcn_readfirstlane(next);
+        }
         if (pre) load_oct<NE>(a, oct, total, f, j, vin, tA_next, tB_next);
         const unsigned tA = tA_next, tB = tB_next;
 
@@ -166,7 +179,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         }
         ea = row16_sum(ea);
         eb = row16_sum(eb);
-        const int npass = __any(fmaxf(ea, eb) > kPairGuard * fminf(ea, eb)) ? 2 : 1;
+        const int npass = (alone || __any(fmaxf(ea, eb) > kPairGuard * fminf(ea, eb))) ? 2 : 1;
+        alone = false;
+        bool redo = false;
         for (int pass = 0; pass < npass; ++pass) {
         float2 v[16];
 #pragma unroll
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         for (int r = 0; r < 8; ++r) zcs[r] = make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         float *prA = slot, *prB = slot + kPRowX;
         float esA = 0.f, esB = 0.f;
+        float pmin = 3.0e38f, pmax = 0.f;  // smallest and largest bin of the pair (both frames)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float2 zk = u[r];
@@ -218,6 +234,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             prB[j + 16 * r] = pb;
             esA += pa;
             esB += pb;
+            pmin = fminf(pmin, fminf(pa, pb));
+            pmax = fmaxf(pmax, fmaxf(pa, pb));
         }
         if (j == 0) {
             // bin 128 pairs with itself: 2 A[128] = 2 Re Z[128], 2 B[128] = 2 Im Z[128]
@@ -229,6 +247,18 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             prB[128] = pb;
             esA += pa;
             esB += pb;
+            pmin = fminf(pmin, fminf(pa, pb));
+            pmax = fmaxf(pmax, fmaxf(pa, pb));
+        }
+        if (npass == 1) {
+            // tiny-bin check over the 16 lanes of the pair (see kTinyBin); an all-zero pair has nothing to protect
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                pmin = fminf(pmin, __shfl_xor(pmin, m, 64));
+                pmax = fmaxf(pmax, __shfl_xor(pmax, m, 64));
+            }
+            redo = __any(pmin < (POW2 ? kTinyBin * kTinyBin : kTinyBin) * pmax);
+            if (redo) break;  // wave-uniform: nothing of this run is kept
         }
         if (j < 3) {  // pad bins read (with zero weight) by the mel stage
             prA[129 + j] = 0.f;
@@ -313,6 +343,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
             }
         }
         wave_order();
+        }
+        if (redo) {
+            // same oct again, one frame per transform; the samples that were prefetched for `next` are fetched again later
+            wave_order();
+            held = next;
+            alone = true;
+            if (!pre) load_oct<NE>(a, oct, total, f, j, vin, tA_next, tB_next);
+            continue;
         }
         oct = next;
     }

@@ -380,9 +380,9 @@ def test_edge_signals_every_frame_kernel(ss, oracle, sslib, sr, nfft, flen, hop,
     imp = np.zeros(n, np.float32)
     imp[::hop] = 1.0
     mkw = {k: v for k, v in kw.items() if k != "num_cepstral"}
-    # (the 256-point kernel transforms two frames at once: bins that cancel exactly in a packed real transform come out as
-    # rounding noise of the pair there, so the square wave -- exact zeros in most bands -- is left to the other kernels)
-    for x in (zero, imp) if nfft == 256 else (zero, sq, imp):
+    # (the 256-point kernel transforms two frames at once; bins that cancel exactly -- the square wave has exact zeros in most
+    # bands -- trip its tiny-bin check and the oct is run again one frame per transform: no signal class is left out)
+    for x in (zero, sq, imp):
         got = ss.mfcc(x, sr, **kw)
         assert not sslib.ss_last_kernel_name().startswith(b"ss_front_generic")
         want = oracle.mfcc(p, x)
