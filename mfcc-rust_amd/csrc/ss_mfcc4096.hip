@@ -27,6 +27,10 @@
 #ifndef SS_TOUCH
 #define SS_TOUCH 1
 #endif
+// timing-attribution builds (tools/ablate.sh, results wrong by design): 1 no DCT, 2 no mel + DCT, 4 no partner fetch, 8 no exchange
+#ifndef SS_ABL5
+#define SS_ABL5 0
+#endif
 
 namespace ss {
 
@@ -163,6 +167,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         }
         // ---- transpose (two 32 x 32 problems: even and odd n1), in two register halves ----
         float2 u[32];
+        if (SS_ABL5 & 8) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) u[k] = v[k];
+        } else {
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
         wave_order();
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             }
         }
         wave_order();
+        }
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 1 * 4096)[lane * 32 + e] = u[e];
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int q = 0; q < 8; ++q) {
                 const int i = 8 * hb + q;
                 const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
-                zcs[q] = make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
+                zcs[q] = (SS_ABL5 & 4) ? sv : make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -273,6 +282,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
 
+        if (SS_ABL5 & 2) {
+            if (lane < Cc) a.out[static_cast<unsigned long long>(frame) * Cc + lane] = energy;
+            wave_order();
+            frame = next;
+            continue;
+        }
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
         {
             int off = 0;
@@ -299,6 +314,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             for (int i = lane; i < 256; i += 64) a.dbg[1028 + i] = frow[i];
         }
 
+        if (SS_ABL5 & 1) {
+            if (lane < Cc) a.out[static_cast<unsigned long long>(frame) * Cc + lane] = frow[lane] + energy;
+            wave_order();
+            frame = next;
+            continue;
+        }
         // ---- DCT-II (feature.rs:120-123) with cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M = 256:
         // the wave first forms s[m] = L[m] + L[255-m] and d[m] = L[m] - L[255-m] once (2 + 2 values per lane); an even
         // coefficient is then a 128-term product with s, an odd one with d -- half the FMAs and half the LDS reads ----
