@@ -26,6 +26,20 @@ for arg in sys.argv[1:]:
         "hbm_bytes_per_launch": 2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024,
         "correction": "2 x FETCH_SIZE (gfx950 coalesced-read under-count) + WRITE_SIZE, KiB -> bytes",
         "avg_ns_profiled": d.get("avg_ns"),
+        "profiled": os.environ.get("SS_PROFILE_TAG", "round 2"),
     }
+    # SQ counters.  SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles summed over the waves: their ratios are
+    # shares of the waves' lifetime.  SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count LDS-array cycles summed over the CUs.
+    if d.get("SQ_WAVE_CYCLES"):
+        out[wl]["valu_insts_per_launch"] = d.get("SQ_INSTS_VALU")
+        out[wl]["lds_insts_per_launch"] = d.get("SQ_INSTS_LDS")
+        out[wl]["wave_time_shares"] = {k: d.get(k, 0.0) / d["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS")}
+        # VALU issue floor measured in tools/ubench/valu_issue.hip: 2.14 cycles per instruction per SIMD with >= 2 waves
+        if d.get("avg_ns"):
+            out[wl]["valu_floor_frac_at_2p4ghz"] = d.get("SQ_INSTS_VALU", 0.0) / 1024.0 * 2.14 / (d["avg_ns"] * 2.4)
+    if d.get("SQ_LDS_IDX_ACTIVE"):
+        out[wl]["lds_bank_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+        if d.get("avg_ns"):
+            out[wl]["lds_busy_frac_at_2p4ghz"] = d["SQ_LDS_IDX_ACTIVE"] / 256.0 / (d["avg_ns"] * 2.4)
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out, indent=1))
