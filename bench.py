@@ -355,6 +355,8 @@ def main():
         ev.record(st)
         stream.wait_event(ev)
     e1.record(stream)
+    while not e1.query():  # poll instead of sleeping in the driver: the blocking wait's wake-up latency is tens of microseconds,
+        pass               # which is several steps' worth when only a few steps are timed
     if comm_stream is not None:
         comm_stream.synchronize()
     torch.cuda.synchronize()

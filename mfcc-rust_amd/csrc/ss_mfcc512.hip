@@ -51,10 +51,9 @@
 #ifndef SS_ABLATE
 #define SS_ABLATE 0
 #endif
-// Experiment switches (tools/ablate.sh with OPT=<bits>), results stay correct:
-//   1 untangle partner by DPP row_mirror (lanes relabelled so that lane l and 15 - l hold columns j and 16 - j)
-//   2 the claimed quad number is read where it is first needed   4 touch-prefetch of the quad one round ahead
-//   8 the waves of a SIMD ask for their first samples one after the other (the CU cannot keep 12 quads of misses in flight)
+// Experiment switch (tools/ablate.sh "-DSS_OPT=1"), results stay correct: the untangle partner by DPP row_mirror instead of
+// ds_bpermute (lanes relabelled so that lane l and 15 - l hold columns j and 16 - j).  Measured equal within noise once the mel
+// tap reads were made conflict-free (16 LDS instructions traded for 32 VALU ones): off.
 #ifndef SS_OPT
 #define SS_OPT 0
 #endif
@@ -267,10 +266,6 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     float2 vin[NE];
     float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
-    if (SS_OPT & 8) {
-        if (wave >= 8) __builtin_amdgcn_s_sleep(20);
-        else if (wave >= 4) __builtin_amdgcn_s_sleep(10);
-    }
     t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
     {
         if (tid == 0) *s_next = q_lo + WAVES;
@@ -323,14 +318,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     }
     const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned n_done = 0;
-    float touch = 0.f;
     unsigned long long t_first = 0ull;
 
     while (quad < q_hi) {
         // claim the next quad now so that its samples can be prefetched during this one
-        unsigned next = 0, next_v = 0;
-        if (lane == 0) next_v = atomicAdd(s_next, 1u);
-        if (!(SS_OPT & 2)) next = __builtin_amdgcn_readfirstlane(next_v);
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(s_next, 1u);
+        next = __builtin_amdgcn_readfirstlane(next);
         ++n_done;
 
         if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
@@ -359,19 +353,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         }
         wave_order();
-        if (SS_OPT & 2) next = __builtin_amdgcn_readfirstlane(next_v);
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
-        if (SS_OPT & 4) asm volatile("" ::"v"(touch));
         if (PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
-        if ((SS_OPT & 4) && next + WAVES < q_hi && lane < 26) {
-            // pull the lines of a quad this CU claims about one round from now into L2 (the sample loads then hit)
-            const unsigned q4t = (next + WAVES) * 4;
-            const unsigned clip_t = a.nf_magic ? __umulhi(q4t, a.nf_magic) >> a.nf_shift : q4t / a.n_frames;
-            const float *pt = a.x + static_cast<unsigned long long>(clip_t) * a.ld + (q4t - clip_t * a.n_frames) * a.step + lane * 32;
-            const float *last = a.x + static_cast<unsigned long long>(a.batch - 1) * a.ld + a.n_samples - 1;
-            touch = *(pt < last ? pt : last);
-        }
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
