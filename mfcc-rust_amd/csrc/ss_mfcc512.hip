@@ -27,14 +27,17 @@
 //     and d[m] = L[m] - L[39-m] once, and lane c < n_ceps multiplies 20 terms of s (even c) or d (odd c) with its
 //     half cosine row held in registers (template RES bit 2).  Other filter counts: 48-entry (slot, lane)-ordered
 //     row against the lane's cosine row in LDS (pitch 52 floats: conflict-free).
-//   * The kernel is bound by VALU issue (one instruction per 4 cycles per SIMD; 96 % busy), so the code is
-//     written for instruction count: twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2
-//     twiddles in registers (RES bit 1), ln on values pre-scaled by 2^32, scalar frame -> (clip, t) division.
+//   * What bounds it (round 2): a SIMD issues one VALU instruction per 2.1 cycles when two of its waves have
+//     one ready (tools/ubench/valu_issue.hip), which puts the VALU floor of a 1024-clip launch at ~16 us of its 32-36; the
+//     LDS array is ~40 % busy.  Neither is saturated -- LDS round trips that three waves per SIMD do not cover and the
+//     per-launch start / tail make up the rest -- but both matter, so the code is still written for instruction count:
+//     twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2 twiddles in registers (RES bit 1), ln on values
+//     pre-scaled by 2^32, scalar frame -> (clip, t) division, conflict-free LDS accesses throughout.
 //   * Builds (template OUTK / FRONT): MFCC; mfe's (features, energy); power_spectrum rows; each optionally with a
 //     frame window and fused pre-emphasis on load.
 //   * HBM traffic: samples once (the 50 % frame overlap is served by L1/L2), n_ceps floats per frame out.
-// Compiled with -fno-slp-vectorize: v_pk_*_f32 issues at half the rate of the scalar forms on gfx950
-// (tools/ubench/valu_rate.hip), so packing buys nothing and costs registers.
+// Compiled with -fno-slp-vectorize: v_pk_fma_f32 takes the issue slots of two scalar FMAs on gfx950
+// (tools/ubench/valu_issue.hip: 5.1 against 2 x 2.5 cycles), so packing buys nothing and costs registers.
 //
 // Reference semantics: feature.rs:99-148 (mfcc), :200-233 (mfe), processing.rs:65-181.
 #include "ss_device.h"

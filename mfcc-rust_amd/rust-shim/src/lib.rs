@@ -57,6 +57,7 @@ extern "C" {
     fn ss_stft_rows(p: *const SsParams, n_samples: usize, rows: *mut usize, real_rows: *mut usize) -> c_int;
     fn ss_mfcc(cfg: *const SsConfig, x: *const f32, n: usize, out: *mut f32) -> c_int;
     fn ss_mfe(cfg: *const SsConfig, x: *const f32, n: usize, feat: *mut f32, energy: *mut f32) -> c_int;
+    fn ss_lmfe(cfg: *const SsConfig, x: *const f32, n: usize, feat: *mut f32) -> c_int;
     fn ss_mel_spectrogram(cfg: *const SsConfig, x: *const f32, channels: usize, n: usize, out: *mut f32) -> c_int;
     fn ss_mfcc_batch(cfg: *const SsConfig, x: *const f32, batch: usize, n: usize, ld: usize, out: *mut f32) -> c_int;
     fn ss_mfcc_batch_device(cfg: *const SsConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
@@ -196,6 +197,17 @@ pub fn try_mfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<(Array2<f3
     Ok((feat, en))
 }
 pub fn mfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> (Array2<f32>, Array1<f32>) { try_mfe(signal, cfg).expect("mfe") }
+
+/// feature.rs:242-245 (private there; README.md:14 lists log mel-filterbank energies as a supported feature)
+pub fn try_lmfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+    let x = contiguous(signal);
+    let mut t = 0usize;
+    check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
+    let mut feat = Array2::<f32>::zeros((t, cfg.num_filters));
+    check(unsafe { ss_lmfe(cfg.handle, x.as_ptr(), x.len(), feat.as_mut_ptr()) })?;
+    Ok(feat)
+}
+pub fn lmfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_lmfe(signal, cfg).expect("lmfe") }
 
 /// feature.rs:163-174: [channels, samples] -> [channels, n_mels, rows]; rows need contiguous storage like
 /// the reference's `as_slice().expect(..)` (functions.rs:104)

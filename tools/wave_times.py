@@ -11,7 +11,10 @@ print(f"waves {len(d)}  span {en.max():.1f} us")
 cols = [("start", st), ("prologue_end", pro), ("end", en), ("lifetime", en - st), ("main_loop", en - pro)]
 if d.shape[1] >= 8:
     first, last = us(6), us(7)  # column 7: table words arrived (prologue)
-    cols += [("first_samples", first), ("table_arrived", last)]
+    cols += [("first_samples", first)]
+    tab = last[d[:, 7] != 0]  # only the workgroup's table waves stamp this
+    if len(tab):
+        cols += [("table_in_lds", np.pad(tab, (0, len(first) - len(tab)), mode="edge"))]
 for name, v in cols:
     print(f"{name:15s} min {v.min():7.2f}  p10 {np.percentile(v,10):7.2f}  p50 {np.median(v):7.2f}  p90 {np.percentile(v,90):7.2f}  max {v.max():7.2f} us")
 for q in np.unique(nq):
