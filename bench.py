@@ -150,7 +150,7 @@ def load_profile(kernel_name, workload, headline):
     out = {"traffic": e.get("hbm_bytes_per_launch"),
            "traffic_source": "profiles/pmc_traffic.json (stored: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                              f"{e.get('profiled', 'round 1')}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"}
-    for k in ("valu_busy_frac", "valu_insts_per_launch", "lds_bank_conflict_frac", "lds_busy_frac"):
+    for k in ("valu_insts_per_launch", "valu_floor_frac", "lds_busy_frac", "lds_bank_conflict_frac", "clock_ghz_assumed", "wave_time_shares"):
         if k in e:
             out[k] = e[k]
     return out

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const int wave = tid >> 6;
     const int lane = tid & 63;
     const unsigned long long t_start = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long c_start = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;  // shader-clock ticks: the launch's average clock
     const int f = lane >> 4;  // frame within the quad
     // column of the frame's 16 x 16 point matrix owned by this lane of the DPP row.  The untangle pairs column j with
     // column 16 - j: lanes l and 15 - l hold such a pair (1..7 <-> 15..9), lanes 0 and 15 the self-paired columns 0 and 8,
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         d[1] = t_pro;
         d[2] = __builtin_amdgcn_s_memrealtime();
         d[4] = t_first;
-        d[5] = t_tab;
+        d[5] = wave < 2 ? t_tab : (__builtin_amdgcn_s_memtime() - c_start) | (1ull << 40);  // table waves: tables in LDS; others: cycles lived
         d[3] = (static_cast<unsigned long long>(n_done) << 32) | __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // XCC_ID
     }
 }

@@ -12,6 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLOCK_GHZ = 1.974  # measured during a cfg2 launch (profiles/r02/wave_timeline_cfg2.txt)
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for arg in sys.argv[1:]:
@@ -34,12 +35,15 @@ for arg in sys.argv[1:]:
         out[wl]["valu_insts_per_launch"] = d.get("SQ_INSTS_VALU")
         out[wl]["lds_insts_per_launch"] = d.get("SQ_INSTS_LDS")
         out[wl]["wave_time_shares"] = {k: d.get(k, 0.0) / d["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS")}
-        # VALU issue floor measured in tools/ubench/valu_issue.hip: 2.14 cycles per instruction per SIMD with >= 2 waves
+        # VALU issue floor measured in tools/ubench/valu_issue.hip: 2.14 cycles per instruction per SIMD with >= 2 waves.
+        # Clock: the shader clock during a cfg2 launch, measured with s_memtime against s_memrealtime (tools/dbg_times.py):
+        # 1.97 GHz (1.90-2.07) -- the part does not hold 2.4 GHz under this load.
         if d.get("avg_ns"):
-            out[wl]["valu_floor_frac_at_2p4ghz"] = d.get("SQ_INSTS_VALU", 0.0) / 1024.0 * 2.14 / (d["avg_ns"] * 2.4)
+            out[wl]["clock_ghz_assumed"] = CLOCK_GHZ
+            out[wl]["valu_floor_frac"] = d.get("SQ_INSTS_VALU", 0.0) / 1024.0 * 2.14 / (d["avg_ns"] * CLOCK_GHZ)
     if d.get("SQ_LDS_IDX_ACTIVE"):
         out[wl]["lds_bank_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
         if d.get("avg_ns"):
-            out[wl]["lds_busy_frac_at_2p4ghz"] = d["SQ_LDS_IDX_ACTIVE"] / 256.0 / (d["avg_ns"] * 2.4)
+            out[wl]["lds_busy_frac"] = d["SQ_LDS_IDX_ACTIVE"] / 256.0 / (d["avg_ns"] * CLOCK_GHZ)
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -12,7 +12,13 @@ cols = [("start", st), ("prologue_end", pro), ("end", en), ("lifetime", en - st)
 if d.shape[1] >= 8:
     first, last = us(6), us(7)  # column 7: table words arrived (prologue)
     cols += [("first_samples", first)]
-    tab = last[d[:, 7] != 0]  # only the workgroup's table waves stamp this
+    raw = d[:, 7]
+    cyc = (raw >= (1 << 40)) & (raw < (1 << 41))  # waves other than the table waves report the shader cycles they lived (flag bit 40)
+    if cyc.any():
+        cycles = (raw[cyc] - (1 << 40)).astype(np.float64)
+        life_us = (d[cyc, 3] - d[cyc, 1]) / 100.0
+        print(f"shader clock over the waves' lifetime: mean {np.mean(cycles / life_us):.0f} MHz  (min {np.min(cycles / life_us):.0f}, max {np.max(cycles / life_us):.0f})")
+    tab = last[~cyc & (d[:, 7] != 0)]  # only the workgroup's table waves stamp this
     if len(tab):
         cols += [("table_in_lds", np.pad(tab, (0, len(first) - len(tab)), mode="edge"))]
 for name, v in cols:
