@@ -69,6 +69,75 @@ __host__ __device__ __forceinline__ void fft_reg<8>(float2 *v)
 // W16^6 = h(-1 - i) leave their factor h to the FMAs of the next butterfly, and the general ones are applied as
 // c (1 - i t) with the factor c folded the same way (148 instructions instead of 160; VALU issue is what bounds the
 // kernels built on this).
+// The same 16-point DFT, handing each output to `emit(k, X[k])` as soon as its group of four is final (k = k2, k2 + 4, k2 + 8,
+// k2 + 12 after group k2) and calling `fence()` after every group: a kernel that stores the outputs to LDS can spread the
+// stores over the butterfly instead of issuing all of them behind it (the LDS queue then never sees a 16-store burst).
+template <class Emit, class Fence>
+__device__ __forceinline__ void fft16_emit(float2 *v, Emit &&emit, Fence &&fence)
+{
+    // step A: for each n1, 4-point DFT over n2 (elements n1, n1+4, n1+8, n1+12) -> Y[n1][k2] kept in v[n1 + 4 k2]
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) fft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    constexpr float t1 = 0.41421356237309504880f, t3 = 2.41421356237309504880f;  // tan(pi/8), cot(pi/8)
+    constexpr float h = 0.70710678118654752440f;
+    // k2 = 0: no twiddles
+    {
+        float2 a = v[0], b = v[1], c = v[2], d = v[3];
+        fft4(a, b, c, d);
+        emit(0, a); emit(4, b); emit(8, c); emit(12, d);
+    }
+    fence();
+    // k2 = 1: b = Y1 W16^1 = c1 b'', c = Y2 W16^2 = h c', d = Y3 W16^3 = s1 d''
+    {
+        const float2 a = v[4];
+        const float2 bb = make_float2(fmaf(t1, v[5].y, v[5].x), fmaf(-t1, v[5].x, v[5].y));
+        const float2 cc = make_float2(v[6].x + v[6].y, v[6].y - v[6].x);
+        const float2 dd = make_float2(fmaf(t3, v[7].y, v[7].x), fmaf(-t3, v[7].x, v[7].y));
+        const float2 a0 = make_float2(fmaf(h, cc.x, a.x), fmaf(h, cc.y, a.y));
+        const float2 a1 = make_float2(fmaf(-h, cc.x, a.x), fmaf(-h, cc.y, a.y));
+        const float2 p = make_float2(s1 * dd.x, s1 * dd.y);
+        const float2 a2 = make_float2(fmaf(c1, bb.x, p.x), fmaf(c1, bb.y, p.y));    // b + d
+        const float2 bd = make_float2(fmaf(c1, bb.x, -p.x), fmaf(c1, bb.y, -p.y));  // b - d
+        emit(1, cadd(a0, a2));
+        emit(5, make_float2(a1.x + bd.y, a1.y - bd.x));  // a1 - i (b - d)
+        emit(9, csub(a0, a2));
+        emit(13, make_float2(a1.x - bd.y, a1.y + bd.x));
+    }
+    fence();
+    // k2 = 2: b = Y1 W16^2 = h b', c = Y2 W16^4 = -i Y2, d = Y3 W16^6 = h d'
+    {
+        const float2 a = v[8];
+        const float2 bb = make_float2(v[9].x + v[9].y, v[9].y - v[9].x);
+        const float2 c = make_float2(v[10].y, -v[10].x);
+        const float2 dd = make_float2(v[11].y - v[11].x, -(v[11].x + v[11].y));
+        const float2 a0 = cadd(a, c), a1 = csub(a, c);
+        const float2 u1 = cadd(bb, dd), u2 = csub(bb, dd);  // (b + d) / h, (b - d) / h
+        emit(2, make_float2(fmaf(h, u1.x, a0.x), fmaf(h, u1.y, a0.y)));
+        emit(6, make_float2(fmaf(h, u2.y, a1.x), fmaf(-h, u2.x, a1.y)));  // a1 - i (b - d)
+        emit(10, make_float2(fmaf(-h, u1.x, a0.x), fmaf(-h, u1.y, a0.y)));
+        emit(14, make_float2(fmaf(-h, u2.y, a1.x), fmaf(h, u2.x, a1.y)));
+    }
+    fence();
+    // k2 = 3: b = Y1 W16^3 = s1 b'', c = Y2 W16^6 = h c', d = Y3 W16^9 = -c1 d''
+    {
+        const float2 a = v[12];
+        const float2 bb = make_float2(fmaf(t3, v[13].y, v[13].x), fmaf(-t3, v[13].x, v[13].y));
+        const float2 cc = make_float2(v[14].y - v[14].x, -(v[14].x + v[14].y));
+        const float2 dd = make_float2(fmaf(t1, v[15].y, v[15].x), fmaf(-t1, v[15].x, v[15].y));
+        const float2 a0 = make_float2(fmaf(h, cc.x, a.x), fmaf(h, cc.y, a.y));
+        const float2 a1 = make_float2(fmaf(-h, cc.x, a.x), fmaf(-h, cc.y, a.y));
+        const float2 p = make_float2(c1 * dd.x, c1 * dd.y);
+        const float2 a2 = make_float2(fmaf(s1, bb.x, -p.x), fmaf(s1, bb.y, -p.y));  // b + d
+        const float2 bd = make_float2(fmaf(s1, bb.x, p.x), fmaf(s1, bb.y, p.y));    // b - d
+        emit(3, cadd(a0, a2));
+        emit(7, make_float2(a1.x + bd.y, a1.y - bd.x));
+        emit(11, csub(a0, a2));
+        emit(15, make_float2(a1.x - bd.y, a1.y + bd.x));
+    }
+    fence();
+}
+
 template <>
 __host__ __device__ __forceinline__ void fft_reg<16>(float2 *v)
 {

@@ -60,6 +60,12 @@
 #ifndef SS_OPT
 #define SS_OPT 0
 #endif
+// SS_SPREAD (default on): LDS stores, partner fetches and sample loads leave in small groups from inside the butterflies and
+// the twiddle loop instead of as bursts behind them -- a wave issues in order, so a burst of 8..16 memory instructions holds
+// back its own VALU work while the LDS / vector-memory queue drains.  -1.0 us of 30.8 on one box (0: the round-1 bursts).
+#ifndef SS_SPREAD
+#define SS_SPREAD 1
+#endif
 
 namespace ss {
 
@@ -155,6 +161,27 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
         }
     }
     return t;
+}
+
+// Contract framing only: where this lane's frame of `quad` starts (frame t of its clip begins at sample t * step), and t.
+__device__ __forceinline__ const float2 *quad_src(const Fast512Args &a, unsigned quad, unsigned total, int f, unsigned &t_out)
+{
+    const unsigned q4 = quad * 4;
+    const unsigned fl = min(static_cast<unsigned>(f), total - 1 - q4);
+    unsigned clip, t;
+    if (a.nf_magic) {
+        clip = __umulhi(q4, a.nf_magic) >> a.nf_shift;
+        t = q4 - clip * a.n_frames + fl;
+        const bool wrap = t >= a.n_frames;
+        t -= wrap ? a.n_frames : 0u;
+        clip += wrap ? 1u : 0u;
+    } else {
+        const unsigned gf = q4 + fl;
+        clip = gf / a.n_frames;
+        t = gf - clip * a.n_frames;
+    }
+    t_out = t;
+    return reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
 }
 
 // One mel slot with a compile-time tap count (multiple of 4): weights and P taps are all requested before
@@ -351,15 +378,27 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         }
 
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
+        if (SS_SPREAD && !(SS_ABLATE & 4)) {
+            // the exchange stores leave group by group while the butterfly is still computing (no 16-store burst into the LDS queue)
+            fft16_emit(
+                v, [&](int r, float2 val) { zh[wbase1 + 2 * r] = val; }, [] { __builtin_amdgcn_sched_barrier(0); });
+        } else {
         fft16_reg(v);
         if (!(SS_ABLATE & 4)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
         }
+        }
         wave_order();
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
-        if (PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
+        // SPREAD: the ten sample loads of the next quad go out one per twiddle step instead of as a burst (a wave issues in
+        // order: behind a burst of vector-memory instructions its own VALU work waits); no branch surrounds them -- the last
+        // iteration of a wave fetches the block's last quad again and drops it
+        constexpr bool SPREAD = SS_SPREAD && PREFETCH && EXACT && !PRE && !CENTER && !(SS_ABLATE & 16);
+        const float2 *nsrc = nullptr;
+        if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, t_next) + j;
+        if (!SPREAD && PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
         float2 u[16];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -378,16 +417,38 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
             const float4 w2 = (RES & 2) ? tw2r[p] : s_tw2[p * 16 + j];
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+            if (SPREAD) {
+                if (p < NE) vin[p] = nsrc[16 * p];
+                if (p == 7) {
+#pragma unroll
+                    for (int e = 8; e < NE; ++e) vin[e] = nsrc[16 * e];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (!(SS_ABLATE & 64)) fft16_reg(u);  // u[r] = Z[j + 16 r]
-
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
-        // all 16 partner fetches (register 15 - r of lane 16 - j) go out back to back: one LDS wait
+        // the partner of bin j + 16 r is register 15 - r of lane 16 - j: fetched with ds_bpermute
         float2 zcs[8];
+        if (SS_SPREAD && !(SS_ABLATE & 65) && !(SS_OPT & 1)) {
+            // the fetches of the upper registers go out as soon as the butterfly has produced them, group by group
+            float2 uo[16];  // (the butterfly still reads its input registers while the first groups' outputs appear)
+            fft16_emit(
+                u,
+                [&](int k, float2 val) {
+                    uo[k] = val;
+                    if (k >= 8) zcs[15 - k] = make_float2(bperm(paddr, val.x), bperm(paddr, val.y));
+                },
+                [] { __builtin_amdgcn_sched_barrier(0); });
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u[k] = uo[k];
+        } else {
+        if (!(SS_ABLATE & 64)) fft16_reg(u);  // u[r] = Z[j + 16 r]
+        // all 16 partner fetches go out back to back: one LDS wait
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (SS_OPT & 1) continue;  // fetched by DPP where it is used
             zcs[r] = (SS_ABLATE & 1) ? u[15 - r] : make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
+        }
         }
         float esum = 0.f;
         // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
