@@ -299,11 +299,12 @@ def main():
         if buckets is None or not ((i + 1) % G == 0 or last):
             return
         b = (i // G) % 2
+        n = i % G + 1  # filled slots (a run's last bucket may be partial: only what was computed is gathered)
         ev = torch.cuda.Event()
         ev.record(stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev)
-            all_gather_into(gathered[b], buckets[b])
+            all_gather_into(gathered[b][: world * n], buckets[b][:n])
             done = torch.cuda.Event()
             done.record(comm_stream)
         bucket_done[b] = done
