@@ -203,6 +203,15 @@ int ss_ln_device(float *d_x, size_t n, void *stream);
 int ss_power_to_db(const float *s, size_t n, float ref, float amin, float top_db, float *out);
 int ss_power_to_db_device(const float *d_s, size_t n, float ref, float amin, float top_db, float *d_out, void *stream);
 
+/* ---- multi-GPU callers below Python (one process or thread per GPU) -------------------------------------
+ * Clips are independent, so a batch shards by contiguous blocks with no exchange inside the path: rank r of `world`
+ * computes clips [lo, hi) of ss_shard_bounds on its own device with the *_device entry points.  The north-star's "RCCL
+ * gather over xGMI of the final [n_frames x n_mfcc] blocks" is ss_all_gather_features: every rank passes its block of
+ * elems_per_rank floats (pad uneven shards to the largest) and receives [world x elems_per_rank] on `stream`.  `nccl_comm` is
+ * the caller's ncclComm_t; the library resolves RCCL (librccl.so.1) at the first call and links nothing at build time. */
+int ss_shard_bounds(size_t n_items, int world, int rank, size_t *lo, size_t *hi);
+int ss_all_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, void *stream);
+
 int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,
                                    size_t ld, float *d_P, void *stream);
 /* stft2 (functions.rs:86-123): interleaved re,im  [channels x rows x (fft_points/2+1) x 2] */

@@ -3,6 +3,8 @@
 // stream.  There is no CPU compute path here: without a HIP device these return SS_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -810,6 +812,33 @@ int ss_lmfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_s
 int ss_lmfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat)
 {
     return ss_lmfe_batch(cfg, x, 1, n_samples, n_samples, feat);
+}
+
+int ss_shard_bounds(size_t n_items, int world, int rank, size_t *lo, size_t *hi)
+{
+    if (!lo || !hi || world <= 0 || rank < 0 || rank >= world) return ss::fail(SS_ERR_ARG, "bad world / rank");
+    // contiguous block partition: ranks [0, n % world) get one extra item (speechsauce_amd.distributed.shard_bounds)
+    const size_t w = static_cast<size_t>(world), r = static_cast<size_t>(rank), base = n_items / w, extra = n_items % w;
+    *lo = r * base + std::min(r, extra);
+    *hi = *lo + base + (r < extra ? 1 : 0);
+    return SS_OK;
+}
+
+int ss_all_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, void *stream)
+{
+    if (!nccl_comm || !d_block || !d_out) return ss::fail(SS_ERR_ARG, "null argument");
+    if (elems_per_rank == 0) return SS_OK;
+    // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); ncclFloat32 = 7 (rccl.h)
+    using all_gather_fn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
+    static all_gather_fn fn = [] {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        return h ? reinterpret_cast<all_gather_fn>(dlsym(h, "ncclAllGather")) : nullptr;
+    }();
+    if (!fn) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded");
+    const int rc = fn(d_block, d_out, elems_per_rank, 7, nccl_comm, static_cast<hipStream_t>(stream));
+    if (rc != 0) return ss::fail(SS_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+    return SS_OK;
 }
 
 int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,

@@ -67,7 +67,27 @@ extern "C" {
     fn ss_cmvnw(vec: *const f32, rows: usize, cols: usize, win_size: usize, variance_normalization: c_int, out: *mut f32) -> c_int;
     fn ss_derivative_extraction(feat: *const f32, rows: usize, cols: usize, delta_windows: usize, out: *mut f32) -> c_int;
     fn ss_extract_derivative_feature(feat: *const f32, rows: usize, cols: usize, cube: *mut f32) -> c_int;
+    fn ss_shard_bounds(n_items: usize, world: c_int, rank: c_int, lo: *mut usize, hi: *mut usize) -> c_int;
+    fn ss_all_gather_features(nccl_comm: *mut c_void, d_block: *const f32, elems_per_rank: usize, d_out: *mut f32,
+                              stream: *mut c_void) -> c_int;
     fn ss_last_error_string() -> *const c_char;
+}
+
+/// Contiguous clip shard of rank `rank` of `world` (one process or thread per GPU; clips are independent units).
+pub fn shard_bounds(n_items: usize, world: usize, rank: usize) -> (usize, usize) {
+    let (mut lo, mut hi) = (0usize, 0usize);
+    check(unsafe { ss_shard_bounds(n_items, world as c_int, rank as c_int, &mut lo, &mut hi) }).expect("shard_bounds");
+    (lo, hi)
+}
+
+/// RCCL all-gather of the ranks' feature blocks (device pointers, `comm` = the caller's ncclComm_t): the north-star's
+/// "gather over xGMI of the final [n_frames x n_mfcc] blocks".
+///
+/// # Safety
+/// `d_block` / `d_out` must be device buffers of `elems_per_rank` / `world * elems_per_rank` floats on the current device.
+pub unsafe fn all_gather_features(comm: *mut c_void, d_block: *const f32, elems_per_rank: usize, d_out: *mut f32,
+                                  stream: *mut c_void) -> Result<(), Error> {
+    check(ss_all_gather_features(comm, d_block, elems_per_rank, d_out, stream))
 }
 
 #[derive(Debug)]

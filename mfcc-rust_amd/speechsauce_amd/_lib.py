@@ -94,6 +94,8 @@ PROTOTYPES = {
     "ss_ln_device": (C.c_int, [_fp, C.c_size_t, C.c_void_p]),
     "ss_power_to_db": (C.c_int, [_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp]),
     "ss_power_to_db_device": (C.c_int, [_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp, C.c_void_p]),
+    "ss_shard_bounds": (C.c_int, [C.c_size_t, C.c_int, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
+    "ss_all_gather_features": (C.c_int, [C.c_void_p, _fp, C.c_size_t, _fp, C.c_void_p]),
     "ss_power_spectrum_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_stft_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_cmvn": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_int, _fp]),

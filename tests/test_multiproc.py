@@ -144,3 +144,49 @@ def test_bench_launches_its_own_ranks():
     assert d["gather"] and d["gather"]["bucket_steps"] >= 1
     assert d["backend"] in ("nccl", "gloo")
     assert d["rccl_ranks"] == (2 if d["backend"] == "nccl" else 0)
+
+
+def test_abi_shard_bounds_matches_the_python_partition(sslib):
+    import ctypes as C
+
+    from speechsauce_amd.distributed import shard_bounds
+
+    lo, hi = C.c_size_t(), C.c_size_t()
+    for n in (0, 1, 7, 1024, 360000):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                assert sslib.ss_shard_bounds(n, w, r, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_bounds(n, w, r)
+    assert sslib.ss_shard_bounds(4, 2, 2, C.byref(lo), C.byref(hi)) != 0
+
+
+@pytest.mark.gpu
+def test_abi_rccl_all_gather_single_rank(ss, sslib):
+    """ss_all_gather_features is the C ABI's RCCL gather for callers below Python.  A one-GPU box can only form a one-rank
+    communicator: the call goes through ncclAllGather and must return the block unchanged."""
+    import ctypes as C
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl.so.1 not loadable")
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    torch.cuda.set_device(0)
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        x = torch.from_numpy((np.random.default_rng(3).standard_normal((5, 16000)) * 0.1).astype(np.float32)).cuda()
+        block = ss.mfcc_batch(x, 16000)
+        out = torch.zeros_like(block)
+        stream = torch.cuda.current_stream().cuda_stream
+        assert sslib.ss_all_gather_features(comm, block.data_ptr(), block.numel(), out.data_ptr(), C.c_void_p(stream)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, block)
+    finally:
+        rccl.ncclCommDestroy(comm)
