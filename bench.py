@@ -347,7 +347,7 @@ def main():
     for i in range(args.steps):
         step(i)
         after_step(i, i + 1 == args.steps)
-        if args.streams == 1 and (i + 1) % seg_every == 0 and i + 1 < args.steps:
+        if args.streams == 1 and args.steps >= 200 and (i + 1) % seg_every == 0 and i + 1 < args.steps:  # (an event between launches costs ~1 us)
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(stream)
             seg_events.append((i + 1, ev))

@@ -10,4 +10,4 @@ rm -rf /tmp/old/repo && mkdir -p /tmp/old/repo && git archive HEAD | tar -x -C /
 sed -i "s#ROOT    := .*#ROOT    := /tmp/old/repo#" /tmp/old/repo/mfcc-rust_amd/csrc/Makefile
 make -C /tmp/old/repo/mfcc-rust_amd/csrc 2>&1 | grep -E "error" || true
 cp /tmp/old/repo/mfcc-rust_amd/lib/libspeechsauce_amd.so ab/lib_prev.so
-/usr/local/graft/bin/gpurun --timeout 900 -- "timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -1; for w in ${WL:-cfg2}; do tools/ab_bench.sh \$PWD/ab/lib_prev.so \$PWD/ab/lib_new.so $R --workload \$w $*; done" 2>&1 | grep -E "passed|failed|lib_|error"
+gpurun --timeout 900 -- "timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -1; for w in ${WL:-cfg2}; do tools/ab_bench.sh \$PWD/ab/lib_prev.so \$PWD/ab/lib_new.so $R --workload \$w $*; done" 2>&1 | grep -E "passed|failed|lib_|error"
