@@ -342,8 +342,8 @@ def main():
     # ten intermediate events on the launch stream: median / spread of the per-launch time over tenths of the timed region
     seg_every = max(1, args.steps // 10)
     seg_events = []
-    t0 = time.perf_counter()
     e0.record(stream)
+    t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
         after_step(i, i + 1 == args.steps)
