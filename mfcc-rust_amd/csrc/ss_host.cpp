@@ -880,21 +880,28 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
     int32_t off = 0;
     for (int s = 0; s < 4; ++s) {
         const int32_t span = 4 * f.q4[s];
+        // the slot's filters go to lanes and first float4 slots that keep the lock-step ds_read_b128 tap reads conflict-free
+        // (32 lanes share a P row: two read groups of 16 lanes; see place_taps_b128)
+        std::vector<int32_t> lo4, hi4, lane_of, start4_of, idle;
         for (int j = 0; j < 32; ++j) {
             const size_t q = static_cast<size_t>(s) * 32 + j;
-            start[q] = 0;
-            filt[q] = -1;
-            if (q >= M) continue;
-            const int32_t m = order[q];
-            filt[q] = m;
-            const int32_t len = t.bank.len[m];
-            int32_t shift = len ? (t.bank.start[m] & 3) : 0;
-            int32_t st = len ? t.bank.start[m] - shift : 0;
-            if (st + span > kRow) {
-                shift += st + span - kRow;
-                st = kRow - span;
-            }
-            start[q] = st;
+            if (q >= M) break;
+            const int32_t m = order[q], len = t.bank.len[m], st = len ? t.bank.start[m] : 0;
+            hi4.push_back(len ? std::min(st, kRow - span) / 4 : (kRow - span) / 4);  // an empty filter may read anywhere
+            lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
+            if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
+        }
+        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle);
+        for (int j = 0; j < 32; ++j) {
+            start[s * 32 + j] = 4 * idle[j];
+            filt[s * 32 + j] = -1;
+        }
+        for (size_t k = 0; k < lo4.size(); ++k) {
+            const size_t q = static_cast<size_t>(s) * 32 + k;
+            const int32_t m = order[q], len = t.bank.len[m], j = lane_of[k], st = 4 * start4_of[k];
+            const int32_t shift = len ? t.bank.start[m] - st : 0;  // zero weights in front of the filter's first tap
+            start[s * 32 + j] = st;
+            filt[s * 32 + j] = m;
             for (int32_t i = 0; i < len; ++i)
                 f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
         }
@@ -959,21 +966,28 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
     int32_t off = 0;
     for (int s = 0; s < 4; ++s) {
         const int32_t span = 4 * f.q4[s];
+        // the slot's filters go to lanes and first float4 slots that keep the lock-step ds_read_b128 tap reads conflict-free
+        // (32 lanes share a P row: two read groups of 16 lanes; see place_taps_b128)
+        std::vector<int32_t> lo4, hi4, lane_of, start4_of, idle;
         for (int j = 0; j < 32; ++j) {
             const size_t q = static_cast<size_t>(s) * 32 + j;
-            start[q] = 0;
-            filt[q] = -1;
-            if (q >= M) continue;
-            const int32_t m = order[q];
-            filt[q] = m;
-            const int32_t len = t.bank.len[m];
-            int32_t shift = len ? (t.bank.start[m] & 3) : 0;
-            int32_t st = len ? t.bank.start[m] - shift : 0;
-            if (st + span > kRow) {
-                shift += st + span - kRow;
-                st = kRow - span;
-            }
-            start[q] = st;
+            if (q >= M) break;
+            const int32_t m = order[q], len = t.bank.len[m], st = len ? t.bank.start[m] : 0;
+            hi4.push_back(len ? std::min(st, kRow - span) / 4 : (kRow - span) / 4);  // an empty filter may read anywhere
+            lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
+            if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
+        }
+        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle);
+        for (int j = 0; j < 32; ++j) {
+            start[s * 32 + j] = 4 * idle[j];
+            filt[s * 32 + j] = -1;
+        }
+        for (size_t k = 0; k < lo4.size(); ++k) {
+            const size_t q = static_cast<size_t>(s) * 32 + k;
+            const int32_t m = order[q], len = t.bank.len[m], j = lane_of[k], st = 4 * start4_of[k];
+            const int32_t shift = len ? t.bank.start[m] - st : 0;  // zero weights in front of the filter's first tap
+            start[s * 32 + j] = st;
+            filt[s * 32 + j] = m;
             for (int32_t i = 0; i < len; ++i)
                 f.tab[L::kMelW + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
         }
