@@ -13,10 +13,11 @@
 //   * untangle with ds_bpermute_b32 (partner = lane 32-j, register 31-r); only bins 0..512 are produced: the mel
 //     bank ends at bin (F+1)/2 (feature.rs:69-70) and this path has no frame energy.
 //   * (|X| wnorm)^2 (functions.rs:166-169, feature.rs:164) -> P row in LDS -> banded mel reduction, 4 filters per lane.
-//   * each lane stores its four mel values straight to out[clip][m][r]: the wave's two rows are adjacent words, so
-//     the stores are 8-byte pairs; the other rows of a line come from other waves and merge in L2.  (A workgroup-wide
-//     transposing tile with coalesced row stores measured 20 % slower: its two barriers per clip cost more than the
-//     partial-line stores.)  No barrier anywhere in the main loop.
+//   * output [clip][m][r]: with at least one clip per CU the clip's block is collected in a CU-wide LDS tile and leaves as
+//     whole 128-byte lines (TILE below; HBM writes = the output, 1.00x).  Otherwise each lane stores its four mel values
+//     straight to out[clip][m][r]: the wave's two rows are adjacent words, so the stores are 8-byte pieces of lines
+//     whose other rows come from other waves and merge in L2 only partly (writes 1.39x the output).  No workgroup barrier
+//     anywhere in the main loop in either build (a barrier-synchronised transposing tile measured 20 % slower in round 1).
 // Rows >= real_rows (the trailing n_pad rows the reference never writes, functions.rs:121) come out as exact zeros.
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -36,7 +37,21 @@ constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange re
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
 
-template <int kWavesM, bool STFT, bool FULLP = false>
+// TILE (mel output; rows <= 32 and a multiple of 4, filters <= 128 and a multiple of 8; batch >= CUs): a clip's [mel][row]
+// block is collected in a CU-wide LDS tile and leaves as whole 128-byte lines.  No workgroup barrier: two LDS counters per
+// tile buffer that only grow -- row pairs written into it, wave shares written out of it -- tell a wave when a clip is
+// complete and when its buffer may be reused; each wave writes a fixed share (filters 8w .. 8w + 7 and 8(w + 8) ..) of every
+// clip at its next unit after the clip completed, and the rest when it runs out of units.  kTileBufs buffers: the CU's waves
+// run ahead of its slowest wave by at most kTileBufs - 1 clips before they wait.  Measured on cfg3 (profiles/r02): same
+// duration as the direct stores (52.9 vs 52.8 us), HBM traffic 1.007x instead of 1.09x the algorithmic bytes.  What it took
+// to get there: polls as relaxed atomics (a volatile LDS poll is a flat_load whose vmcnt(0) drains the prefetch), counter
+// reads issued at the top of the unit, no returning atomics, 16-byte stores only (one wave flushing a whole tile: +5 us;
+// slices handed out through a CAS counter: +9 us).
+constexpr int kTileRows = 32, kTileMels = 128, kTilePitch = 36;  // [mel][row], rows of 144 bytes: 16-byte aligned for the flush
+constexpr int kTileBufs = 3;  // clips a CU may have open at once (its waves run ahead of the slowest by up to kTileBufs - 1 clips)
+constexpr int kTileFloats = kTileBufs * kTileMels * kTilePitch;
+
+template <int kWavesM, bool STFT, bool FULLP = false, bool TILE = false>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
     constexpr bool PREFETCH_M = kWavesM <= 8;  // the next unit's samples are requested while the current one is in its second pass
@@ -61,13 +76,31 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_melw = s_tab + L::kMelW;
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+    float *s_tile = reinterpret_cast<float *>(s_next + 4);                        // TILE: [kTileBufs][32][129]
+    // both counters only ever grow, so nobody needs the value its own increment returned: clip c (the g-th user of its
+    // buffer, g = (c - c_lo) / kTileBufs) may write the tile once s_fd == kWavesM g, and is complete at s_cnt == pairs (g + 1)
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tile + kTileFloats);           // row pairs written into buffer b so far
+    // polling reads of those words: relaxed atomics, not volatile -- a volatile access keeps the generic address space and
+    // becomes a flat_load, whose s_waitcnt vmcnt(0) drains the wave's outstanding global loads and stores on every poll
+    auto peek = [](const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    unsigned *s_fd = s_cnt + kTileBufs;  // shares of buffer b written out so far (kWavesM per clip)
+    const unsigned pairs0 = (a.rows + 1) / 2;
+    // TILE: the workgroup's range is made of whole clips
+    const unsigned c_lo = static_cast<unsigned>(static_cast<unsigned long long>(a.batch) * blockIdx.x / gridDim.x);
+    const unsigned c_hi = static_cast<unsigned>(static_cast<unsigned long long>(a.batch) * (blockIdx.x + 1) / gridDim.x);
 
     {
         const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) {
             const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
-            *s_next = static_cast<unsigned>(units0 * blockIdx.x / gridDim.x) + kWavesM;
+            *s_next = (TILE ? c_lo * pairs0 : static_cast<unsigned>(units0 * blockIdx.x / gridDim.x)) + kWavesM;
+            if (TILE) {
+                for (int b = 0; b < kTileBufs; ++b) {
+                    s_cnt[b] = 0u;
+                    s_fd[b] = 0u;
+                }
+            }
         }
     }
     __syncthreads();
@@ -87,8 +120,42 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     // pull them from an LDS counter
     const unsigned pairs = (a.rows + 1) / 2;
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
-    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
-    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    const unsigned u_lo = TILE ? c_lo * pairs : static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+    const unsigned u_hi = TILE ? c_hi * pairs : static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    // TILE: a finished clip's tile leaves in slices of eight filters (eight whole lines, one 16-byte store per lane); wave w
+    // writes slices w, w + kWavesM, ... of every clip, at its next stop after the clip's last row pair has arrived; once
+    // all kWavesM shares are out the buffer is clip + kTileBufs's.  (One wave writing all 128 lines held that wave up for
+    // microseconds; handing slices out through an LDS counter cost four LDS round trips per slice.)
+    const int nsl = (M + 7) >> 3;
+    unsigned fl_next = c_lo;  // the oldest clip whose share this wave has not written yet
+    auto tile_full = [&](unsigned c) { return pairs * ((c - c_lo) / kTileBufs + 1u); };  // s_cnt of c's buffer once c is complete
+    auto flush_one = [&]() {  // this wave's share of clip fl_next, which is complete
+        const unsigned fb = (fl_next - c_lo) % kTileBufs;
+        // rows % 4 == 0 and filters % 8 == 0 here (launcher): lane l holds rows 4 (l & 7) .. + 3 of filter 8 sl + (l >> 3)
+        const float *tb = s_tile + fb * (kTileMels * kTilePitch) + (lane >> 3) * kTilePitch + (lane & 7) * 4;
+        float *dstc = a.out + static_cast<unsigned long long>(fl_next) * M * R + (lane >> 3) * R + (lane & 7) * 4;
+        if ((lane & 7) * 4 < R) {
+            for (int sl = wave; sl < nsl; sl += kWavesM) *reinterpret_cast<float4 *>(dstc + sl * 8 * R) = *reinterpret_cast<const float4 *>(tb + sl * 8 * kTilePitch);
+        }
+        wave_order();
+        if (lane == 0) atomicAdd(s_fd + fb, 1u);
+        ++fl_next;
+    };
+    auto flush_share = [&](unsigned upto, bool wait) {
+        while (fl_next < upto) {
+            const unsigned fb = (fl_next - c_lo) % kTileBufs;
+            const unsigned full = tile_full(fl_next);
+            if (peek(s_cnt + fb) != full) {
+                if (!wait) return;
+                unsigned tries = 0;  // bounded: a protocol error must not hang
+                while (peek(s_cnt + fb) != full && tries < (1u << 22)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++tries;
+                }
+            }
+            flush_one();
+        }
+    };
     // (clip, row) of this half-wave within a unit, and the loads of its window: functions.rs:137-151, the window covers the
     // last W samples ending at chunk r + n_pad
     auto load_unit = [&](unsigned un, float2 (&vv)[32]) {
@@ -147,6 +214,16 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     const float2 w = s_win[j + 32 * e];
                     v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
                 }
+                // TILE: this wave's share of the finished clips behind this one leaves here, right after the unit's samples
+                // have arrived: vmcnt retires in order and a write is acknowledged microseconds after it was issued, so
+                // stores issued later in the unit (ahead of or behind the next unit's loads) made that unit wait for them
+                // TILE: the two counters this unit will look at are read here, long before their values are needed, so that the
+                // round trips hide behind the transform (a stale value only postpones the flush to the wave's next unit)
+                unsigned seen_cnt = 0, seen_fd = 0;
+                if (TILE) {
+                    seen_cnt = peek(s_cnt + (fl_next - c_lo) % kTileBufs);
+                    seen_fd = peek(s_fd + (clip - c_lo) % kTileBufs);
+                }
                 // ---- 1024-point complex FFT: radix-32, transpose through LDS (one frame at a time), twiddle, radix-32 ----
                 fft_reg<32>(v);
                 // The transpose runs in two register halves (columns k1 < 16, then k1 >= 16) so that only 16 of v's 32
@@ -180,6 +257,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 }
                 wave_order();
                 // the window registers are dead now: the next unit's samples load into them while this one is finished
+                if (TILE && fl_next < clip && seen_cnt == tile_full(fl_next)) flush_one();
                 if (PREFETCH_M && next < u_hi) load_unit(next, v);
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {  // two twiddles per ds_read_b128: W^(j(2p+1)), W^(j(2p+2))
@@ -245,7 +323,32 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 wave_order();
                 // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are
                 //      adjacent words of out[clip][m][.] ----
-                if (in_rows) {
+                if (TILE) {
+                    const unsigned b = (clip - c_lo) % kTileBufs;
+                    float mv[4];
+                    {
+                        int off = 0;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            mv[s] = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                            off += a.mel_q4[s];
+                        }
+                    }
+                    // the buffer is ours once clip - kTileBufs has left it (bounded: a protocol error must not hang)
+                    const unsigned freed = kWavesM * ((clip - c_lo) / kTileBufs);
+                    for (unsigned tries = 0; seen_fd != freed && peek(s_fd + b) != freed && tries < (1u << 22); ++tries) {
+                        flush_share(clip, false);  // the buffer may be waiting for this very wave's share of an older clip
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    float *tcol = s_tile + b * (kTileMels * kTilePitch) + r;
+                    if (in_rows) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (fi[s] >= 0) tcol[fi[s] * kTilePitch] = mv[s];
+                    }
+                    wave_order();
+                    if (lane == 0) atomicAdd(s_cnt + b, 1u);
+                } else if (in_rows) {
                     float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
                     int off = 0;
 #pragma unroll
@@ -261,13 +364,23 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         if (!PREFETCH_M && next < u_hi) load_unit(next, v);
         unit = next;
     }
+    if (TILE) {
+        // out of units: what is left of the range's last clips (bounded wait for rows other waves are still computing)
+        flush_share(c_hi, true);
+    }
 }
 
 template <int kWavesM>
 hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // whole-line stores through the CU-wide tile: mel output, every CU at least one clip, the tile fits next to everything else
+    static const char *tile_env = std::getenv("SS_MEL_TILE");  // A/B knob
+    const size_t lds_tile = lds + (kTileFloats + 2 * kTileBufs + 2) * sizeof(float);
+    const bool tile = !(tile_env && std::atoi(tile_env) == 0) && !a.out_stft && !a.fullp && a.rows <= kTileRows && a.rows % 4 == 0 && a.n_filters <= 128 && a.n_filters % 8 == 0 &&
+                      lds_tile <= 160 * 1024 && a.batch >= static_cast<uint32_t>(num_cus > 0 ? num_cus : 256);
+    if (tile) lds = lds_tile;
     if (a.batch == 0) return hipSuccess;
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
@@ -281,6 +394,7 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
         return hipGetLastError();
     };
+    if (tile) return go(ss_mel_c1024<kWavesM, false, false, true>, "ss_mel_c1024<tile>");
     if (a.out_stft) return go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>");
     if (a.fullp) return go(ss_mel_c1024<kWavesM, false, true>, "ss_mel_c1024<fullp>");
     return go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");

@@ -199,6 +199,36 @@ def test_mel_spectrogram_2048_full_spectrum_bank(ss, oracle, sslib):
             assert _rel(got[b], want[b]) <= RTOL, (sw, b)
 
 
+def test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslib):
+    """fft_points = 2048 with at least one clip per CU: a clip's [mel][row] block is collected in LDS and leaves as whole
+    lines (ss_mel_c1024<tile>).  Shapes that give a CU one clip, an uneven number of clips, few row pairs per clip (most waves
+    never get a unit and only write their share), more clips than tile buffers; every clip must equal, bit for bit, the
+    direct-store build that small batches take, and a sample of clips is checked against the oracle."""
+    import torch
+
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for n, M, B in ((16000, 128, ncu), (16000, 128, 5 * ncu + 37), (16000, 64, ncu + 19), (3584, 128, 2 * ncu + 1), (7680, 40, ncu + 3),
+                    (16000, 100, ncu + 5), (13312, 128, ncu + 7)):
+        x = _signal(71, (B, n))
+        kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=M, fft_length=2048, high_frequency=8000.0)
+        xd = torch.from_numpy(x).cuda()
+        got = ss.mel_spectrogram(xd, 16000, **kw)
+        name = sslib.ss_last_kernel_name()
+        R = got.shape[2]
+        tiled = R % 4 == 0 and R <= 32 and M % 8 == 0 and M <= 128
+        assert name == (b"ss_mel_c1024<tile>" if tiled else b"ss_mel_c1024"), (name, n, M, B, R)
+        for lo in range(0, B, 100):  # fewer clips than CUs: direct stores
+            part = ss.mel_spectrogram(xd[lo:lo + 100].contiguous(), 16000, **kw)
+            assert sslib.ss_last_kernel_name() == b"ss_mel_c1024"
+            assert torch.equal(part, got[lo:lo + 100]), (n, M, B, lo)
+        pick = sorted({0, 1, B // 2, B - 2, B - 1})
+        p = oracle.make_params(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=M, high_frequency=8000.0)
+        want = oracle.mel_spectrogram(p, x[pick])
+        g = got[pick].cpu().numpy()
+        for i in range(len(pick)):
+            assert _rel(g[i], want[i]) <= RTOL, (n, M, B, pick[i])
+
+
 def test_mel_spectrogram_4096_kernel(ss, oracle, sslib):
     """mel_spectrogram at fft_points = 4096 (44.1 kHz, 1024- and 2048-sample chunks, 256 / 128 / 100 mels): one row per wave on
     the 4096-point FFT mapping; partial last chunks, clips shorter than a window."""
