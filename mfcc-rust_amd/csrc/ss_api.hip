@@ -408,6 +408,8 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.tab = cfg->d_mfcc4096_tab;
         f.mel_wpitch = cfg->mfcc4096.wpitch;
         for (int s = 0; s < 4; ++s) f.mel_q4[s] = cfg->mfcc4096.q4[s];
+        f.cos_floats = cfg->mfcc4096.cos_floats;
+        f.dct_fold2 = cfg->mfcc4096.dct_fold2 ? 1 : 0;
         f.n_filters = a.n_filters;
         f.n_ceps = a.n_ceps;
         f.dct_scale_k = a.dct_scale_k;

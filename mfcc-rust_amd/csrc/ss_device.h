@@ -223,6 +223,8 @@ struct Mfcc4096Args {
     const float *tab;    // table block (layout: ss::mfcc4096_layout in ss_internal.h), copied verbatim into LDS
     int32_t mel_wpitch;  // floats per lane weight row
     int32_t mel_q4[4];   // taps / 4 per slot
+    int32_t cos_floats;  // floats of the cosine block in front of the mel rows
+    int32_t dct_fold2;   // 1: per-lane cosine rows of the twice-folded DCT (n_filters % 4 == 0, n_ceps <= 43)
     uint32_t n_filters, n_ceps;
     float dct_scale_k, dct_scale_0, dct_scale_00;
     int32_t dc_elimination;

@@ -1021,7 +1021,11 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
     if (f.wpitch == 0) f.wpitch = 4;
     if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the lanes' ds_read_b128 of their rows spread over all banks
     if (f.wpitch > 128) return;
-    const size_t melw0 = static_cast<size_t>(L::kCos) + Cc * L::kCosPitch;
+    // DCT stage: with n_filters % 4 == 0 the 256-term product folds twice (an even coefficient is 64 terms, an odd one two
+    // halves of 64) and 64 lanes cover up to 43 coefficients in one pass; the cosine block is then one 64-term row per lane
+    f.dct_fold2 = !mel && M % 4 == 0 && Cc >= 1 && Cc <= 43;
+    f.cos_floats = static_cast<int32_t>(f.dct_fold2 ? 64 * L::kCosLanePitch : Cc * L::kCosPitch);
+    const size_t melw0 = static_cast<size_t>(L::kCos) + f.cos_floats;
     f.tab.assign(melw0 + 64 * static_cast<size_t>(f.wpitch), 0.0f);
     const double pi = 3.14159265358979323846;
     auto cis = [&](double num, double den, float *dst) {
@@ -1071,8 +1075,23 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
         }
         off += span;
     }
-    for (size_t cc = 0; cc < Cc; ++cc)
-        for (size_t m = 0; m < (M + 1) / 2; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
+    if (f.dct_fold2) {
+        // lane assignment of ss_mfcc_c2048's product stage: lanes 0 .. ne-1 the even coefficients 2 lane (filters 0 .. M/4-1),
+        // then from the next even lane on pairs of lanes per odd coefficient (filters 0..63 and 64..127 of its M/2)
+        const size_t ne = (Cc + 1) / 2, no = Cc / 2, nep = (ne + 1) & ~size_t(1);
+        for (size_t lane = 0; lane < 64; ++lane) {
+            float *row = &f.tab[L::kCos + lane * L::kCosLanePitch];
+            if (lane < ne) {
+                for (size_t m = 0; m < M / 4; ++m) row[m] = t.dct[2 * lane * M + m];
+            } else if (lane >= nep && (lane - nep) / 2 < no) {
+                const size_t cc = 2 * ((lane - nep) / 2) + 1, m0 = 64 * ((lane - nep) & 1);
+                for (size_t i = 0; i < 64 && m0 + i < M / 2; ++i) row[i] = t.dct[cc * M + m0 + i];
+            }
+        }
+    } else {
+        for (size_t cc = 0; cc < Cc; ++cc)
+            for (size_t m = 0; m < (M + 1) / 2; ++m) f.tab[L::kCos + cc * L::kCosPitch + m] = t.dct[cc * M + m];
+    }
     if (mel) {
         const size_t base = f.tab.size();
         f.tab.resize(base + 4096);

@@ -223,13 +223,16 @@ constexpr int kStart = kTwn + 16 * 128;   // [4][64] int32: first P bin of the f
 constexpr int kFilt = kStart + 256;       // [4][64] int32: filter index of (slot, lane), -1 if none
 constexpr int kCos = kFilt + 256;         // [n_ceps][132]: cos(pi c (2m+1) / 2M), m < 128 (the other half by symmetry)
 constexpr int kCosPitch = 132;
+constexpr int kCosLanePitch = 68;         // dct_fold2 layout: [64 lanes][68], the 64 cosines of the lane's share of its coefficient
 constexpr int kPRow = 1032;               // floats per P row: bins 0..1024 + zero pad bins
-// melw [64][pitch] follows the cosine block: offset kCos + n_ceps * kCosPitch
+// melw [64][pitch] follows the cosine block: offset kCos + cos_floats
 }  // namespace mfcc4096_layout
 
 struct Mfcc4096Tables {
     bool ok = false;
     bool stft_only = false;  // mel-spectrogram block whose bank does not fit the mel stage: stft build only
+    bool dct_fold2 = false;  // the cosine block holds one 64-term row per lane ([64][kCosLanePitch]) instead of [n_ceps][kCosPitch]
+    int32_t cos_floats = 0;  // floats of the cosine block (the mel rows follow it)
     std::vector<float> tab;
     int32_t q4[4] = {0, 0, 0, 0};
     int32_t wpitch = 0;

@@ -23,6 +23,7 @@
 #include "ss_wave.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // SS_TOUCH=1: one load per 128-byte line of the frame that is claimed about one iteration from now (pulls its new samples
 // into L2 ahead of the sample loads).  Measured: -0.9 % time, but +57 % HBM fetch traffic (lines evicted again before their
@@ -46,7 +47,8 @@ constexpr int kClsStride = 16 * 34 + 8;    // float2 per class slice: +8 keeps t
 constexpr int kExFloats = (kClsStride + 16 * 34) * 2;  // exchange region (two classes x half the columns, 8768 B); P row + ln(mel) row reuse it
 constexpr bool kDbgStages = false;        // true: SS_DEBUG_ROWS also dumps frame 0's registers after each FFT stage (tools/dbg4096.py)
 constexpr int kFRowOff = L::kPRow;        // ln(mel) row [256] behind the P row (both inside the exchange region)
-constexpr int kSRowOff = kFRowOff + 256;  // s[128] and d[128] rows of the symmetric DCT, behind the ln(mel) row
+constexpr int kSRowOff = kFRowOff + 256;  // s and d rows of the symmetric DCT (4 segments of 64 + 4 floats), behind the ln(mel) row
+constexpr int kSegPitch = 68;
 
 // v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.  Inline assembly: hipcc 7.2 drops the
 // second result of __builtin_amdgcn_permlane32_swap (both extracts read the first register).  The s_nop covers the
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_cos = s_tab + L::kCos;
     const int Cc = static_cast<int>(a.n_ceps);
-    const int melw0 = L::kCos + Cc * L::kCosPitch;
+    const int melw0 = L::kCos + a.cos_floats;
     const float *s_melw = s_tab + melw0;
     // WIN: the frame window (4096 floats, zero beyond flen) sits behind the table block
     const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + melw0 + 64 * a.mel_wpitch);
@@ -323,46 +325,126 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             frame = next;
             continue;
         }
+        // ---- DCT-II (feature.rs:120-123), folded twice.  cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M): with
+        // s[m] = L[m] + L[M-1-m] and d[m] = L[m] - L[M-1-m] an even coefficient is an M/2-term product with s, an odd one
+        // with d.  For c = 2c' the same identity holds once more inside s (cos(pi c (2(M/2-1-m)+1) / 2M) =
+        // (-1)^c' cos(pi c (2m+1) / 2M)): M/4 terms with s[m] + s[M/2-1-m] or s[m] - s[M/2-1-m].  Lane roles (host table,
+        // ss_host.cpp build_4096): lanes 0 .. ne-1 the even coefficients, then two lanes per odd coefficient (d[0..63] and
+        // d[64..127]); every lane has 64 terms -- 16 + 16 ds_read_b128 and 64 FMAs, against 64 and 128 with one lane per
+        // coefficient.  Rows as four 64-value segments (s+, s-, d low, d high) one float4 apart: the four addresses a read
+        // touches lie in different banks; the cosine rows are per lane at an odd float4 pitch. ----
+        if (a.dct_fold2) {
+            float *seg = wbase + kSRowOff;
+            {
+                const int m2 = lane + 64;
+                const float l0 = lane < Mh ? frow[lane] : 0.f, l1 = lane < Mh ? frow[M - 1 - lane] : 0.f;
+                const float l2 = m2 < Mh ? frow[m2] : 0.f, l3 = m2 < Mh ? frow[M - 1 - m2] : 0.f;
+                const bool q = lane < (M >> 2);
+                const float sa = q ? l0 + l1 : 0.f, sb = q ? frow[Mh - 1 - lane] + frow[Mh + lane] : 0.f;
+                seg[lane] = sa + sb;
+                seg[kSegPitch + lane] = sa - sb;
+                seg[2 * kSegPitch + lane] = l0 - l1;
+                seg[3 * kSegPitch + lane] = l2 - l3;
+            }
+            wave_order();
+            const int ne = (Cc + 1) >> 1, no = Cc >> 1, nep = (ne + 1) & ~1;
+            const int lp = lane - nep;
+            const bool even = lane < nep;
+            const int c = even ? 2 * min(lane, ne - 1) : 2 * min(lp >> 1, no - 1) + 1;
+            const int sk = even ? (min(lane, ne - 1) & 1) : 2 + (lp & 1);
+            const float4 *r4 = reinterpret_cast<const float4 *>(seg + sk * kSegPitch);
+            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosLanePitch);
+            float4 rq[16], cq[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                rq[i] = r4[i];
+                cq[i] = c4[i];
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc = fmaf(rq[i].x, cq[i].x, acc);
+                acc = fmaf(rq[i].y, cq[i].y, acc);
+                acc = fmaf(rq[i].z, cq[i].z, acc);
+                acc = fmaf(rq[i].w, cq[i].w, acc);
+            }
+            if (!even) acc += dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the coefficient's other half (nep is even)
+            if (lane < ne || (!even && !(lp & 1) && (lp >> 1) < no)) {
+                // scaling + column-0 replacement (feature.rs:126-146)
+                float o = acc * a.dct_scale_k;
+                if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                a.out[static_cast<unsigned long long>(frame) * Cc + c] = o;
+            }
+            wave_order();
+            frame = next;
+            continue;
+        }
+        // Other shapes (n_filters not a multiple of 4, more than 43 coefficients): one fold, cosine rows [c][kCosPitch].
         // ---- DCT-II (feature.rs:120-123) with cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M = 256:
         // the wave first forms s[m] = L[m] + L[255-m] and d[m] = L[m] - L[255-m] once (2 + 2 values per lane); an even
-        // coefficient is then a 128-term product with s, an odd one with d -- half the FMAs and half the LDS reads ----
+        // coefficient is then a 128-term product with s, an odd one with d -- half the FMAs and half the LDS reads.
+        // The rows are kept as four 64-value segments (s low, s high, d low, d high) one float4 apart, so that the four
+        // addresses one read of the product stage touches lie in different banks. ----
         {
-            float *srow = wbase + kSRowOff, *drow = wbase + kSRowOff + 128;
+            float *seg = wbase + kSRowOff;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int m = lane + 64 * h2;
                 const bool in = m < Mh;  // M < 256: the rows are zero beyond M/2 (as are the cosine rows)
                 const bool mid = (M & 1) && m == Mh;  // odd filter count: the middle filter pairs with itself
                 const float lo = in || mid ? frow[m] : 0.f, hi = in ? frow[M - 1 - m] : 0.f;
-                srow[m] = lo + hi;
-                drow[m] = mid ? 0.f : lo - hi;
+                seg[h2 * kSegPitch + lane] = lo + hi;
+                seg[(2 + h2) * kSegPitch + lane] = mid ? 0.f : lo - hi;
             }
         }
         wave_order();
-        if (lane < Cc) {
-            const float4 *r4 = reinterpret_cast<const float4 *>(wbase + kSRowOff + ((lane & 1) ? 128 : 0));
-            const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosPitch);
-            float acc = 0.f;
-#pragma unroll 1
-            for (int g = 0; g < 2; ++g) {  // 16 float4s per batch of fetches
-                float4 rq[16], cq[16];
+        {
+            // terms [first, first + 4 NQ) of coefficient c's 128-term product (first a multiple of 4 NQ <= 64)
+            auto dct_part = [&](int c, int first, auto nq) {
+                constexpr int NQ = decltype(nq)::value;
+                const float4 *r4 = reinterpret_cast<const float4 *>(wbase + kSRowOff + ((c & 1) * 2 + (first >> 6)) * kSegPitch + (first & 63));
+                const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + c * L::kCosPitch + first);
+                float4 rq[NQ], cq[NQ];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    rq[i] = r4[16 * g + i];
-                    cq[i] = c4[16 * g + i];
+                for (int i = 0; i < NQ; ++i) {
+                    rq[i] = r4[i];
+                    cq[i] = c4[i];
                 }
+                float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < NQ; ++i) {
                     acc = fmaf(rq[i].x, cq[i].x, acc);
                     acc = fmaf(rq[i].y, cq[i].y, acc);
                     acc = fmaf(rq[i].z, cq[i].z, acc);
                     acc = fmaf(rq[i].w, cq[i].w, acc);
                 }
+                return acc;
+            };
+            // All 64 lanes work: coefficient c < 32 is split over lanes c (terms 0..63) and c + 32 (terms 64..127); the
+            // coefficients from 32 on take a second, shorter pass -- up to 8 of them in eighths over lanes (c & 7) + 8 part,
+            // more in halves like the first pass.  (One lane per coefficient left 24 lanes idle and cost 128 FMAs and 64
+            // ds_read_b128 per lane; this is 80 + 40 for 40 coefficients.)
+            float acc = dct_part(min(lane & 31, Cc - 1), 64 * (lane >> 5), std::integral_constant<int, 16>{});
+            acc += __shfl_xor(acc, 32, 64);
+            if (Cc > 32) {
+                float acc2;
+                if (Cc <= 40) {
+                    acc2 = dct_part(min(32 + (lane & 7), Cc - 1), 16 * (lane >> 3), std::integral_constant<int, 4>{});
+                    acc2 += dpp<0x128>(acc2);  // row_ror:8: lane ^ 8
+                    acc2 += __shfl_xor(acc2, 16, 64);
+                    acc2 += __shfl_xor(acc2, 32, 64);
+                } else {
+                    acc2 = dct_part(min(32 + (lane & 31), Cc - 1), 64 * (lane >> 5), std::integral_constant<int, 16>{});
+                    acc2 += __shfl_xor(acc2, 32, 64);
+                }
+                if (lane >= 32) acc = acc2;
             }
-            // scaling + column-0 replacement (feature.rs:126-146)
-            float o = acc * a.dct_scale_k;
-            if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-            a.out[static_cast<unsigned long long>(frame) * Cc + lane] = o;
+            if (lane < Cc) {
+                // scaling + column-0 replacement (feature.rs:126-146)
+                float o = acc * a.dct_scale_k;
+                if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                a.out[static_cast<unsigned long long>(frame) * Cc + lane] = o;
+            }
         }
         wave_order();
         frame = next;
@@ -574,7 +656,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
 template <int WAVES>
 hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.n_ceps) * L::kCosPitch +
+    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.cos_floats) +
                         64 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;

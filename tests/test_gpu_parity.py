@@ -842,7 +842,11 @@ def test_mfcc_4096_other_filter_counts(ss, oracle, sslib):
     x = _signal(26, (4, sr))
     xd = torch.from_numpy(x).cuda()
     for flen, M, C, sw in ((4096, 128, 20, {}), (3000, 100, 13, dict(mfcc_window="hann")), (4096, 64, 40, dict(dc_elimination=False)),
-                           (4096, 128, 20, dict(mfcc_window="hann", spectrum_exponent=2, dct_norm="ortho")), (3001, 256, 13, dict(mfcc_window="vorbis", spectrum_exponent=2))):
+                           (4096, 128, 20, dict(mfcc_window="hann", spectrum_exponent=2, dct_norm="ortho")), (3001, 256, 13, dict(mfcc_window="vorbis", spectrum_exponent=2)),
+                           # the DCT stage's lane layouts: twice folded up to 43 coefficients when the filter count is a multiple
+                           # of 4 (41..43: the odd coefficients start on the next even lane), once folded in two passes otherwise
+                           (4096, 256, 41, {}), (4096, 256, 42, {}), (4096, 256, 43, dict(dc_elimination=False)), (4096, 256, 44, {}), (4096, 256, 64, {}),
+                           (4096, 254, 36, {}), (4096, 130, 33, dict(dc_elimination=False)), (4096, 255, 40, {}), (4096, 60, 5, {}), (4096, 252, 1, {})):
         kw = dict(frame_length=flen / sr, frame_stride=1024 / sr, num_cepstral=C, num_filters=M, fft_length=4096)
         p = oracle.make_params(sample_rate=sr, fft_points=4096, frame_length=flen / sr, frame_stride=1024 / sr, num_cepstral=C,
                                num_filters=M, **sw)
