@@ -384,7 +384,7 @@ static HostTables without_bank(const HostTables &t)
 // start4_idle[lane] a harmless first slot for lanes without a filter.  Filters that cannot be matched take a free cell at
 // their latest start (a conflict costs time, never correctness).
 static void place_taps_b128(int lanes, const std::vector<int32_t> &lo4, const std::vector<int32_t> &hi4, std::vector<int32_t> &lane_of,
-                            std::vector<int32_t> &start4_of, std::vector<int32_t> &start4_idle)
+                            std::vector<int32_t> &start4_of, std::vector<int32_t> &start4_idle, int32_t max4)
 {
     static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                       {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
@@ -427,7 +427,7 @@ static void place_taps_b128(int lanes, const std::vector<int32_t> &lo4, const st
     start4_idle.assign(lanes, 0);
     for (int c = 0; c < cells; ++c) {
         if (owner[c] >= 0) lane_of[owner[c]] = lane_of_cell(c);
-        else start4_idle[lane_of_cell(c)] = c & 15;  // its own residue: no conflict with the group's other lanes
+        else start4_idle[lane_of_cell(c)] = std::min<int32_t>(c & 15, max4);  // its own residue (no conflict with the group's other lanes), inside the row
     }
 }
 
@@ -787,7 +787,7 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
             lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
             if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
         }
-        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle);
+        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle, (kRow - span) / 4);
         for (int j = 0; j < 32; ++j) {
             start[s * 32 + j] = 4 * idle[j];
             filt[s * 32 + j] = -1;
@@ -891,7 +891,7 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
             lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
             if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
         }
-        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle);
+        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle, (kRow - span) / 4);
         for (int j = 0; j < 32; ++j) {
             start[s * 32 + j] = 4 * idle[j];
             filt[s * 32 + j] = -1;
@@ -977,7 +977,7 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
             lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
             if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
         }
-        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle);
+        place_taps_b128(32, lo4, hi4, lane_of, start4_of, idle, (kRow - span) / 4);
         for (int j = 0; j < 32; ++j) {
             start[s * 32 + j] = 4 * idle[j];
             filt[s * 32 + j] = -1;
@@ -1059,7 +1059,7 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
             lo4.push_back(std::max<int32_t>(0, st + len - span + 3) / 4);
             if (lo4.back() > hi4.back()) lo4.back() = hi4.back();
         }
-        place_taps_b128(64, lo4, hi4, lane_of, start4_of, idle);
+        place_taps_b128(64, lo4, hi4, lane_of, start4_of, idle, (kRow - span) / 4);
         for (int j = 0; j < 64; ++j) {
             start[s * 64 + j] = 4 * idle[j];
             filt[s * 64 + j] = -1;
