@@ -1061,18 +1061,18 @@ def test_fused_preemphasis_on_the_dedicated_kernels(ss, oracle, sslib, sr, nfft,
 
 
 def test_configuration_that_outgrows_a_dedicated_kernel_falls_back(ss, oracle, sslib):
-    """A windowed 4096-point configuration whose table block (48 long filters, 37 cosine rows, the window) does not fit the
+    """A windowed 4096-point configuration whose table block (47 long filters, 37 cosine rows, the window: 164 436 bytes) does not fit the
     dedicated kernel's LDS budget: its launcher declines before launching and the dispatcher moves on to the generic kernel."""
     import torch
 
     sr = 22050
-    kw = dict(frame_length=0.13506802721088434, frame_stride=0.029489795918367347, num_cepstral=37, num_filters=48, fft_length=4096)
+    kw = dict(frame_length=0.13506802721088434, frame_stride=0.029489795918367347, num_cepstral=37, num_filters=47, fft_length=4096)
     sw = dict(mfcc_window="hann", spectrum_exponent=2)
     x = _signal(75, (3, 21076))
     got = ss.mfcc_batch(torch.from_numpy(x).cuda(), sr, **kw, **sw).cpu().numpy()
     assert sslib.ss_last_kernel_name().startswith(b"ss_front_generic<11>")
     p = oracle.make_params(sample_rate=sr, fft_points=4096, frame_length=kw["frame_length"], frame_stride=kw["frame_stride"], num_cepstral=37,
-                           num_filters=48, **sw)
+                           num_filters=47, **sw)
     for b in range(3):
         assert _rel(got[b], oracle.mfcc(p, x[b])) <= RTOL
 
