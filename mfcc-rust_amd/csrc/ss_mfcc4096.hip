@@ -333,6 +333,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         // d[64..127]); every lane has 64 terms -- 16 + 16 ds_read_b128 and 64 FMAs, against 64 and 128 with one lane per
         // coefficient.  Rows as four 64-value segments (s+, s-, d low, d high) one float4 apart: the four addresses a read
         // touches lie in different banks; the cosine rows are per lane at an odd float4 pitch. ----
+        // (The stage's lane-dependent addresses are loop invariants: the compiler keeps them across the transform and spills
+        // three of them to scratch -- 1.5 MB of extra writes per cfg5 launch.  Re-deriving them per frame from an opaque copy
+        // of the lane number removes the spills and measured 1.1 us slower, so they stay.)
         if (a.dct_fold2) {
             float *seg = wbase + kSRowOff;
             {
@@ -347,10 +350,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 seg[3 * kSegPitch + lane] = l2 - l3;
             }
             wave_order();
-            const int ne = (Cc + 1) >> 1, no = Cc >> 1, nep = (ne + 1) & ~1;
+            const int ne = (Cc + 1) >> 1, nep = (ne + 1) & ~1;
             const int lp = lane - nep;
             const bool even = lane < nep;
-            const int c = even ? 2 * min(lane, ne - 1) : 2 * min(lp >> 1, no - 1) + 1;
             const int sk = even ? (min(lane, ne - 1) & 1) : 2 + (lp & 1);
             const float4 *r4 = reinterpret_cast<const float4 *>(seg + sk * kSegPitch);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosLanePitch);
@@ -369,11 +371,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 acc = fmaf(rq[i].w, cq[i].w, acc);
             }
             if (!even) acc += dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the coefficient's other half (nep is even)
-            if (lane < ne || (!even && !(lp & 1) && (lp >> 1) < no)) {
+            if (lane < ne || (!even && !(lp & 1) && lp < Cc - 1)) {  // the lanes that hold a whole coefficient
                 // scaling + column-0 replacement (feature.rs:126-146)
                 float o = acc * a.dct_scale_k;
                 if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-                a.out[static_cast<unsigned long long>(frame) * Cc + c] = o;
+                a.out[static_cast<unsigned long long>(frame) * Cc + (even ? 2 * lane : lp + 1)] = o;
             }
             wave_order();
             frame = next;
