@@ -237,8 +237,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
-    const unsigned long long t_start = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const unsigned long long c_start = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;  // shader-clock ticks: the launch's average clock
+    // diagnostic stamps (tools/dbg_times.py) go to memory where they are taken: kept in registers until the end they cost the
+    // production path two spilled VGPRs (1.5 MB of scratch writes per cfg2 launch)
+    auto stamp = [&](int k, unsigned long long v) {
+        if (a.dbg && lane == 0) a.dbg[6ull * (blockIdx.x * WAVES + wave) + k] = v;
+    };
+    if (a.dbg) {
+        stamp(0, __builtin_amdgcn_s_memrealtime());
+        stamp(5, __builtin_amdgcn_s_memtime());  // shader-clock ticks: replaced by the cycles lived at the end
+        stamp(4, 0ull);
+    }
     const int f = lane >> 4;  // frame within the quad
     // column of the frame's 16 x 16 point matrix owned by this lane of the DPP row.  The untangle pairs column j with
     // column 16 - j: lanes l and 15 - l hold such a pair (1..7 <-> 15..9), lanes 0 and 15 the self-paired columns 0 and 8,
@@ -273,7 +281,6 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     // takes 3-4 us instead of 1, and the barrier below waits for the slowest one.
     constexpr int kTabWaves = 2;
     const int n4 = (L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0)) / 4;
-    unsigned long long t_tab = 0ull;
     if (wave < kTabWaves) {
         constexpr int kBatch = 6;  // loads in flight per lane (768 float4s cover every 512-point table block with <= 80 floats per mel row)
         for (int base = 0; base < n4; base += kBatch * kTabWaves * 64) {
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 if (idx < n4) reinterpret_cast<float4 *>(s_tab)[idx] = tv[k];
             }
         }
-        if (a.dbg) t_tab = __builtin_amdgcn_s_memrealtime();
+        if (a.dbg) stamp(5, __builtin_amdgcn_s_memrealtime());  // table waves: when the tables were in LDS
     }
     // first quad of this wave; its loads are in flight across the barrier (a wave without a quad loads the block's last
     // one: no branch around the loads)
@@ -347,9 +354,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 #pragma unroll
         for (int p = 0; p < 8; ++p) tw2r[p] = s_tw2[p * 16 + j];
     }
-    const unsigned long long t_pro = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (a.dbg) stamp(1, __builtin_amdgcn_s_memrealtime());
     unsigned n_done = 0;
-    unsigned long long t_first = 0ull;
 
     while (quad < q_hi) {
         // claim the next quad now so that its samples can be prefetched during this one
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         if (a.dbg && n_done == 1) {
             // diagnostic runs: when this wave's first samples have arrived
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            t_first = __builtin_amdgcn_s_memrealtime();
+            stamp(4, __builtin_amdgcn_s_memrealtime());
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -634,11 +640,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
     }
     if (a.dbg && lane == 0) {
         unsigned long long *d = a.dbg + 6ull * (blockIdx.x * WAVES + wave);
-        d[0] = t_start;
-        d[1] = t_pro;
         d[2] = __builtin_amdgcn_s_memrealtime();
-        d[4] = t_first;
-        d[5] = wave < 2 ? t_tab : (__builtin_amdgcn_s_memtime() - c_start) | (1ull << 40);  // table waves: tables in LDS; others: cycles lived
+        if (wave >= kTabWaves) d[5] = (__builtin_amdgcn_s_memtime() - d[5]) | (1ull << 40);  // the other waves: cycles lived
         d[3] = (static_cast<unsigned long long>(n_done) << 32) | __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // XCC_ID
     }
 }
