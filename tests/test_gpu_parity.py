@@ -199,6 +199,31 @@ def test_mel_spectrogram_2048_full_spectrum_bank(ss, oracle, sslib):
             assert _rel(got[b], want[b]) <= RTOL, (sw, b)
 
 
+def test_host_calls_small_and_chunked_give_the_device_bits(ss):
+    """Host-pointer calls take pinned device-mapped staging up to 1 MB of samples (one launch, no copy commands) and the chunked
+    two-stream pipeline beyond; both must return exactly what the device-pointer path computes, for every output kind, for
+    batch sizes on either side of the limit and when small and large calls alternate on one config (the staging is reused)."""
+    import torch
+
+    x = _signal(91, (40, 16000))
+    xd = torch.from_numpy(x).cuda()
+    want = ss.mfcc_batch(xd, 16000).cpu().numpy()
+    wf, we = [t.cpu().numpy() for t in ss.mfe_batch(xd, 16000)]
+    kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+    wm = ss.mel_spectrogram(xd, 16000, **kw).cpu().numpy()
+    for nb in (1, 40, 2, 16, 17, 15, 40, 3):   # 16 clips = 1 024 000 bytes: the last mapped size; 17 is chunked
+        np.testing.assert_array_equal(ss.mfcc_batch(x[:nb], 16000), want[:nb])
+        f, e = ss.mfe_batch(x[:nb], 16000)
+        np.testing.assert_array_equal(f, wf[:nb])
+        np.testing.assert_array_equal(e, we[:nb])
+        np.testing.assert_array_equal(ss.mel_spectrogram(x[:nb], 16000, **kw), wm[:nb])
+    np.testing.assert_array_equal(ss.mfcc(x[7], 16000), want[7])
+    # a strided view (every second clip) is made contiguous by the front; a clip shorter than the others on the same config
+    np.testing.assert_array_equal(ss.mfcc_batch(x[::2][:5], 16000), want[::2][:5])
+    short = ss.mfcc(x[3, :8000], 16000)
+    np.testing.assert_array_equal(short, ss.mfcc_batch(xd[3:4, :8000].contiguous(), 16000).cpu().numpy()[0])
+
+
 def test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslib):
     """fft_points = 2048 with at least one clip per CU: a clip's [mel][row] block is collected in LDS and leaves as whole
     lines (ss_mel_c1024<tile>).  Shapes that give a CU one clip, an uneven number of clips, few row pairs per clip (most waves
