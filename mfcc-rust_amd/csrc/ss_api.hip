@@ -252,22 +252,28 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             DeviceBuf flush;  // larger than the Infinity Cache: the stamped launch reads its samples from HBM like a bench step
             rc2 = flush.alloc(512ull << 20);
             if (rc2) return rc2;
-            for (int rep = 0; rep < 3; ++rep) {  // the last repetition has warm code / tables and cold samples
+            // the last repetition has warm code / tables and cold samples; SS_DEBUG_TIMES_REPS=<n> stamps n launches and
+            // writes <file>.<k> for each from the third on (are the same workgroups late every time?)
+            const char *reps_env = std::getenv("SS_DEBUG_TIMES_REPS");
+            const int reps = reps_env && std::atoi(reps_env) > 3 ? std::atoi(reps_env) : 3;
+            std::vector<unsigned long long> hb(nwaves * 6);
+            for (int rep = 0; rep < reps; ++rep) {
                 SS_HIP(hipMemsetAsync(flush.p, rep, 512ull << 20, stream));
                 SS_HIP(hipMemsetAsync(db.p, 0, nwaves * 6 * sizeof(unsigned long long), stream));
                 f.dbg = db.as<unsigned long long>();
                 hipError_t e2 = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
                 if (e2 != hipSuccess) return hip_fail(e2, "launch_mfcc_c256");
                 SS_HIP(hipStreamSynchronize(stream));
-            }
-            std::vector<unsigned long long> hb(nwaves * 6);
-            SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE *fp = std::fopen(dbg_path, "w")) {
-                for (size_t w = 0; w < nwaves; ++w)
-                    if (hb[6 * w + 2])
-                        std::fprintf(fp, "%zu %llu %llu %llu %llu %llu %llu %llu\n", w, hb[6 * w], hb[6 * w + 1], hb[6 * w + 2],
-                                     hb[6 * w + 3] >> 32, hb[6 * w + 3] & 0xffffffffull, hb[6 * w + 4], hb[6 * w + 5]);
-                std::fclose(fp);
+                if (rep < 2) continue;
+                SS_HIP(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                const std::string path = rep == reps - 1 ? std::string(dbg_path) : std::string(dbg_path) + "." + std::to_string(rep);
+                if (FILE *fp = std::fopen(path.c_str(), "w")) {
+                    for (size_t w = 0; w < nwaves; ++w)
+                        if (hb[6 * w + 2])
+                            std::fprintf(fp, "%zu %llu %llu %llu %llu %llu %llu %llu\n", w, hb[6 * w], hb[6 * w + 1], hb[6 * w + 2],
+                                         hb[6 * w + 3] >> 32, hb[6 * w + 3] & 0xffffffffull, hb[6 * w + 4], hb[6 * w + 5]);
+                    std::fclose(fp);
+                }
             }
             f.dbg = nullptr;
         }
