@@ -147,11 +147,14 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
             const unsigned full = tile_full(fl_next);
             if (peek(s_cnt + fb) != full) {
                 if (!wait) return;
-                unsigned tries = 0;  // bounded: a protocol error must not hang
-                while (peek(s_cnt + fb) != full && tries < (1u << 22)) {
+                // bounded: a protocol error must neither hang nor pass for a result -- the clip's block gets NaNs (a trap here
+                // measured 2 us on the whole launch)
+                unsigned tries = 0;
+                while (peek(s_cnt + fb) != full && tries < (1u << 24)) {
                     __builtin_amdgcn_s_sleep(1);
                     ++tries;
                 }
+                if (tries >= (1u << 24)) a.out[static_cast<unsigned long long>(fl_next) * M * R + lane] = __builtin_nanf("");
             }
             flush_one();
         }
@@ -334,11 +337,15 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                             off += a.mel_q4[s];
                         }
                     }
-                    // the buffer is ours once clip - kTileBufs has left it (bounded: a protocol error must not hang)
+                    // the buffer is ours once clip - kTileBufs has left it
                     const unsigned freed = kWavesM * ((clip - c_lo) / kTileBufs);
-                    for (unsigned tries = 0; seen_fd != freed && peek(s_fd + b) != freed && tries < (1u << 22); ++tries) {
+                    for (unsigned tries = 0; seen_fd != freed && peek(s_fd + b) != freed; ++tries) {
                         flush_share(clip, false);  // the buffer may be waiting for this very wave's share of an older clip
                         __builtin_amdgcn_s_sleep(1);
+                        if (tries > (1u << 24)) {  // as above: visible, not silent
+                            a.out[static_cast<unsigned long long>(clip) * M * R + lane] = __builtin_nanf("");
+                            break;
+                        }
                     }
                     float *tcol = s_tile + b * (kTileMels * kTilePitch) + r;
                     if (in_rows) {
