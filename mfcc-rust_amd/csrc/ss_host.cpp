@@ -766,11 +766,15 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
         }
     for (int r = 0; r < 16; ++r)
         for (int j = 0; j < 32; ++j) {  // exp(-2 pi i (j + 32 r) / 2048) = tw_n[j + 32 r]
-            f.tab[L::kTwn + (r * 32 + j) * 2] = t.tw_n[2 * (j + 32 * r)];
-            f.tab[L::kTwn + (r * 32 + j) * 2 + 1] = t.tw_n[2 * (j + 32 * r) + 1];
+            f.tab[L::kTwn + j * L::kTwnPitch + 2 * r] = t.tw_n[2 * (j + 32 * r)];
+            f.tab[L::kTwn + j * L::kTwnPitch + 2 * r + 1] = t.tw_n[2 * (j + 32 * r) + 1];
         }
     (void)pi;
-    for (int i = 0; i < 2048; ++i) f.tab[L::kWin + i] = t.window_stft[i];
+    for (int e = 0; e < 32; ++e)
+        for (int j = 0; j < 32; ++j) {  // the sample pair of lane j, register e
+            f.tab[L::kWin + j * L::kWinPitch + 2 * e] = t.window_stft[2 * (j + 32 * e)];
+            f.tab[L::kWin + j * L::kWinPitch + 2 * e + 1] = t.window_stft[2 * (j + 32 * e) + 1];
+        }
     int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
     int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
     int32_t off = 0;

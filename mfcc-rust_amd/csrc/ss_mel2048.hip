@@ -70,8 +70,8 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     float *prow = wbase + half * (FULLP ? 1088 : L::kPRow);
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
-    const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
-    const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kWin);
+    const float4 *s_twn4 = reinterpret_cast<const float4 *>(s_tab + L::kTwn + j * L::kTwnPitch);  // this lane's 16 untangle twiddles, two per read
+    const float4 *s_win4 = reinterpret_cast<const float4 *>(s_tab + L::kWin + j * L::kWinPitch);  // this lane's 32 window pairs, two per read
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_melw = s_tab + L::kMelW;
@@ -213,9 +213,10 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 const int r = static_cast<int>(unit - clip * pairs) * 2 + half;
                 const bool in_rows = r < R;
 #pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    const float2 w = s_win[j + 32 * e];
+                for (int e = 0; e < 32; e += 2) {
+                    const float4 w = s_win4[e >> 1];
                     v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
+                    v[e + 1] = make_float2(v[e + 1].x * w.z, v[e + 1].y * w.w);
                 }
                 // TILE: this wave's share of the finished clips behind this one leaves here, right after the unit's samples
                 // have arrived: vmcnt retires in order and a write is acknowledged microseconds after it was issued, so
@@ -281,13 +282,16 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     float2 zcs[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm(paddr, u[31 - (8 * hb + q)].x), bperm(paddr, u[31 - (8 * hb + q)].y));
+                    float4 tw4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tw4[i] = s_twn4[4 * hb + i];
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         const int q = 8 * hb + qq;
                         const float2 zk = u[q];
                         // lane 0 pairs with itself: Z[1024 - 32 q] = own register (32 - q) & 31
                         const float2 zc = j == 0 ? u[(32 - q) & 31] : zcs[qq];
-                        const float2 w = s_twn[q * 32 + j];
+                        const float2 w = (qq & 1) ? make_float2(tw4[qq >> 1].z, tw4[qq >> 1].w) : make_float2(tw4[qq >> 1].x, tw4[qq >> 1].y);
                         const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
                         const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
                         // 2 X[k] = s - i w d: two chained FMAs per component
