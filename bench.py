@@ -372,6 +372,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Shader clock during the launches (512-point MFCC kernel only): thirty more steps right behind the timed ones, with the
+    # kernel's per-wave stamps switched on (ss_debug_stamp_buffer): cycles a wave lived / its lifetime on the 100 MHz clock.
+    clock_ghz = None
+    if rank == 0 and lib.ss_last_kernel_name().decode().startswith("ss_mfcc_c256<") and args.streams == 1:
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        stamps = torch.zeros((ncu * 16, 6), dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+        lib.ss_debug_stamp_buffer(stamps.data_ptr())
+        try:
+            for i in range(30):
+                step(i)
+            torch.cuda.synchronize()
+        finally:
+            lib.ss_debug_stamp_buffer(None)
+        w = stamps.cpu().numpy()
+        live = (w[:, 2] != 0) & ((w[:, 5] >> 40) == 1)  # the waves that report cycles (the two table waves per workgroup do not)
+        if live.any():
+            cycles = (w[live, 5] - (1 << 40)).astype("float64")
+            life_us = (w[live, 2] - w[live, 0]).astype("float64") / 100.0
+            clock_ghz = float((cycles / life_us).mean() / 1000.0)
+
     if rank == 0:
         kernel = lib.ss_last_kernel_name().decode()
         total_frames = frames_per_launch * args.steps * world  # equal shards (360 000 divides by 1, 2, 4, 8)
@@ -433,6 +454,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kind, pkw, n_samples, args.cpu_seconds)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(kind, pkw, n_samples, args.cpu_seconds / 2)
+        if clock_ghz is not None:
+            rf = res["roofline"]
+            rf["clock_ghz_measured"] = clock_ghz
+            if rf.get("valu_insts_per_launch"):
+                # VALU issue floor (2.14 cycles per instruction per SIMD, 1024 SIMDs) at the clock this device held in this run
+                rf["valu_floor_frac_at_measured_clock"] = rf["valu_insts_per_launch"] / 1024.0 * 2.14 / (avg_launch_s * 1e9 * clock_ghz)
         print(json.dumps(res), flush=True)
 
     if world > 1:

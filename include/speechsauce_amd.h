@@ -235,6 +235,13 @@ int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_
  * between kernels, so a kernel that lets a word it never wrote reach its results fails loudly after this. */
 int ss_debug_poison_lds(void *stream);
 
+/* Diagnostic: while `d_stamps` is non-null, every launch of the 512-point MFCC kernel writes six 64-bit words per wave into
+ * it (16 waves x CUs x 6 words, overwritten by each launch): [0] s_memrealtime (100 MHz) at wave start, [2] at wave end,
+ * [5] shader-clock cycles the wave lived | 1 << 40 (table waves: a realtime stamp instead), [1] / [3] / [4] prologue end,
+ * quads done << 32 | XCC id, first samples arrived.  bench.py uses it to report the shader clock the part held during the
+ * timed launches (`roofline.clock_ghz_measured`).  Process-wide; pass NULL to switch it off. */
+int ss_debug_stamp_buffer(unsigned long long *d_stamps);
+
 const char *ss_status_string(int status);
 const char *ss_last_error_string(void); /* thread-local detail of the last failure */
 int ss_abi_version(void);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -81,6 +82,7 @@ struct ss_config {
 namespace {
 
 thread_local const char *g_last_kernel = "";
+std::atomic<unsigned long long *> g_stamp_buffer{nullptr};  // ss_debug_stamp_buffer
 
 int hip_fail(hipError_t e, const char *what)
 {
@@ -277,6 +279,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             }
             f.dbg = nullptr;
         }
+        f.dbg = g_stamp_buffer.load(std::memory_order_relaxed);
         const hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
             g_last_kernel = info.kernel_name;
@@ -1000,6 +1003,12 @@ int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, floa
 // ---- diagnostics ---------------------------------------------------------------------------
 
 const char *ss_last_kernel_name(void) { return g_last_kernel; }
+
+int ss_debug_stamp_buffer(unsigned long long *d_stamps)
+{
+    g_stamp_buffer.store(d_stamps, std::memory_order_relaxed);
+    return SS_OK;
+}
 
 int ss_debug_poison_lds(void *stream)
 {

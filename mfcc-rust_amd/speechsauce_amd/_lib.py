@@ -112,6 +112,7 @@ PROTOTYPES = {
     "ss_time_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_time_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_debug_poison_lds": (C.c_int, [C.c_void_p]),
+    "ss_debug_stamp_buffer": (C.c_int, [C.c_void_p]),
     "ss_status_string": (C.c_char_p, [C.c_int]),
     "ss_last_error_string": (C.c_char_p, []),
     "ss_abi_version": (C.c_int, []),
