@@ -121,3 +121,33 @@ def test_mel_spectrogram_in_db(ss, oracle):
     p = oracle.make_params(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=128, high_frequency=8000.0)
     want = _power_to_db_ref(oracle.mel_spectrogram(p, x), top_db=80.0)
     np.testing.assert_allclose(db, want, rtol=0, atol=5e-4)
+
+
+@pytest.mark.gpu
+def test_stamp_buffer_reports_a_plausible_clock_and_leaves_results_alone(ss, sslib):
+    """ss_debug_stamp_buffer: while set, launches of the 512-point MFCC kernel write per-wave stamps (what bench.py turns into
+    roofline.clock_ghz_measured); the features must not change, and the stamps must describe a sane launch."""
+    import torch
+
+    x = torch.randn((1024, 16000), device="cuda") * 0.1
+    want = ss.mfcc_batch(x, 16000)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    stamps = torch.zeros((ncu * 16, 6), dtype=torch.int64, device="cuda")
+    assert sslib.ss_debug_stamp_buffer(stamps.data_ptr()) == 0
+    try:
+        got = ss.mfcc_batch(x, 16000)
+        torch.cuda.synchronize()
+    finally:
+        assert sslib.ss_debug_stamp_buffer(None) == 0
+    assert torch.equal(got, want)
+    w = stamps.cpu().numpy()
+    ran = w[:, 2] != 0
+    assert ran.sum() == ncu * 12                                  # twelve waves per workgroup, one workgroup per CU
+    assert int((w[ran, 3] >> 32).sum()) == 1024 * 98 // 4          # every quad was claimed exactly once
+    cyc = ran & ((w[:, 5] >> 40) == 1)
+    ghz = ((w[cyc, 5] - (1 << 40)) / ((w[cyc, 2] - w[cyc, 0]) / 100.0)).mean() / 1000.0
+    assert 1.0 < ghz < 3.0, ghz
+    stamps.zero_()
+    ss.mfcc_batch(x, 16000)                                         # switched off again: nothing is written
+    torch.cuda.synchronize()
+    assert int(stamps.abs().sum().item()) == 0
