@@ -375,7 +375,7 @@ def main():
     # Shader clock during the launches (512-point MFCC kernel only): thirty more steps right behind the timed ones, with the
     # kernel's per-wave stamps switched on (ss_debug_stamp_buffer): cycles a wave lived / its lifetime on the 100 MHz clock.
     clock_ghz = None
-    if rank == 0 and lib.ss_last_kernel_name().decode().startswith("ss_mfcc_c256<") and args.streams == 1:
+    if world == 1 and lib.ss_last_kernel_name().decode().startswith("ss_mfcc_c256<") and args.streams == 1:
         ncu = torch.cuda.get_device_properties(device).multi_processor_count
         stamps = torch.zeros((ncu * 16, 6), dtype=torch.int64, device=device)
         torch.cuda.synchronize()
