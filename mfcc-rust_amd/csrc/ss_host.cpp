@@ -761,8 +761,8 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
     for (int r = 1; r < 32; ++r)
         for (int j = 0; j < 32; ++j) {  // exp(-2 pi i j r / 1024) = tw_c[j r]
             const int p = (r - 1) / 2, half = (r - 1) % 2;
-            f.tab[L::kTw2 + (p * 32 + j) * 4 + 2 * half] = t.tw_c[2 * (j * r)];
-            f.tab[L::kTw2 + (p * 32 + j) * 4 + 2 * half + 1] = t.tw_c[2 * (j * r) + 1];
+            f.tab[L::kTw2 + j * L::kTw2Pitch + p * 4 + 2 * half] = t.tw_c[2 * (j * r)];
+            f.tab[L::kTw2 + j * L::kTw2Pitch + p * 4 + 2 * half + 1] = t.tw_c[2 * (j * r) + 1];
         }
     for (int r = 0; r < 16; ++r)
         for (int j = 0; j < 32; ++j) {  // exp(-2 pi i (j + 32 r) / 2048) = tw_n[j + 32 r]

@@ -90,12 +90,13 @@ void build_fast512(const HostTables &t, Fast512Tables &f);
 
 // Table block of the fft_points = 2048 mel-spectrogram kernel (ss_mel2048.hip), float offsets.
 namespace mel2048_layout {
-constexpr int kTw2 = 0;                  // [16][32] float4: (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 1024)
+constexpr int kTw2Pitch = 68;            // 16 float4 + 1 float4 pad
+constexpr int kTw2 = 0;                  // [32 lanes][kTw2Pitch]: lane j, entry p: float4 (W^(j(2p+1)), W^(j(2p+2))), W = exp(-2 pi i / 1024)
 // The untangle twiddles and the window are stored per lane, so that a lane fetches two of its values per ds_read_b128 (half
 // the LDS instructions of the [r][lane] layout); row pitches are odd in 16-byte units: the lanes of a read spread over all banks
 constexpr int kTwnPitch = 36;            // 16 float2 + 1 float4 pad
 constexpr int kWinPitch = 68;            // 32 float2 + 1 float4 pad
-constexpr int kTwn = kTw2 + 16 * 128;    // [32 lanes][kTwnPitch]: lane j, entry r: exp(-2 pi i (j + 32 r) / 2048)
+constexpr int kTwn = kTw2 + 32 * kTw2Pitch + 4;  // [32 lanes][kTwnPitch]: lane j, entry r: exp(-2 pi i (j + 32 r) / 2048)
 constexpr int kWin = kTwn + 32 * kTwnPitch;  // [32 lanes][kWinPitch]: lane j, entry e: Vorbis window pair (w[2n], w[2n+1]), n = j + 32 e
 constexpr int kStart = kWin + 32 * kWinPitch;  // [4][32] int32: first P bin of the filter owned by (slot, lane)
 constexpr int kFilt = kStart + 128;      // [4][32] int32: filter index of (slot, lane), -1 if none

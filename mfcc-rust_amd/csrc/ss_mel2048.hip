@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     // fit the region)
     float *prow = wbase + half * (FULLP ? 1088 : L::kPRow);
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
-    const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2);
+    const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2 + j * L::kTw2Pitch);  // this lane's 16 twiddle pairs
     const float4 *s_twn4 = reinterpret_cast<const float4 *>(s_tab + L::kTwn + j * L::kTwnPitch);  // this lane's 16 untangle twiddles, two per read
     const float4 *s_win4 = reinterpret_cast<const float4 *>(s_tab + L::kWin + j * L::kWinPitch);  // this lane's 32 window pairs, two per read
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 if (PREFETCH_M && next < u_hi) load_unit(next, v);
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {  // two twiddles per ds_read_b128: W^(j(2p+1)), W^(j(2p+2))
-                    const float4 w2 = s_tw2[p * 32 + j];
+                    const float4 w2 = s_tw2[p];
                     u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
                     if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
                 }
