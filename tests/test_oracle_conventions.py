@@ -52,3 +52,22 @@ def test_mfcc_columns_are_scipy_dct2_of_the_log_mel_rows(oracle, M, C):
     yo = scipy_fft.dct(np.log(feat), type=2, norm="ortho", axis=1)[:, :C]
     go = np.asarray(oracle.mfcc(po, x), dtype=np.float64)
     assert np.abs(go - yo).max() <= 1e-9 * np.abs(yo).max()
+
+
+@pytest.mark.parametrize("sr,nfft,flen,hop", [(22050, 2048, 2048, 512), (16000, 512, 400, 160), (44100, 1024, 1024, 256)])
+def test_centred_reflect_padded_hann_frames_are_what_numpy_and_scipy_make(oracle, sr, nfft, flen, hop):
+    """The librosa-style switches (framing="center", pad_mode="reflect", mfcc_window="hann", spectrum_exponent=2): frame t covers
+    flen samples centred on t * hop of the reflect-padded clip (numpy.pad mode="reflect"), times the periodic Hann window
+    (scipy.signal.get_window("hann", flen, fftbins=True)), zero-padded to n_fft: |rfft|^2 / N."""
+    scipy_signal = pytest.importorskip("scipy.signal")
+    x = _signal(7, sr // 4)
+    p = oracle.make_params(sample_rate=sr, fft_points=nfft, frame_length=flen / sr, frame_stride=hop / sr, framing="center", pad_mode="reflect",
+                           mfcc_window="hann", spectrum_exponent=2)
+    got = np.asarray(oracle.power_spectrum(p, x), dtype=np.float64)
+    T = got.shape[0]
+    assert T == 1 + x.size // hop
+    xp = np.pad(x.astype(np.float64), flen // 2, mode="reflect")
+    w = scipy_signal.get_window("hann", flen, fftbins=True)
+    frames = np.stack([xp[t * hop:t * hop + flen] * w.astype(np.float32).astype(np.float64) for t in range(T)])
+    want = np.abs(np.fft.rfft(frames, n=nfft, axis=1)) ** 2 / nfft
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()    # the window is an f32 table in the oracle as in the library
