@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 3
+#define SS_ABI_VERSION 4
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -40,7 +40,9 @@ typedef enum ss_status {
     SS_ERR_BAD_CONFIG = 2,   /* parameter combination the reference asserts on or underflows with */
     SS_ERR_ARG = 3,          /* null pointer, bad leading dimension, ... */
     SS_ERR_HIP = 4,          /* HIP runtime error or no device (see ss_last_error_string) */
-    SS_ERR_UNSUPPORTED = 5   /* valid in the reference but not built here (fft_points > 8192, or > 2730 and not a power of two) */
+    SS_ERR_UNSUPPORTED = 5,  /* valid in the reference but not built here (fft_points > 8192, or > 2730 and not a power of two) */
+    SS_ERR_DEVICE = 6        /* a kernel reported a device-side protocol error through the config's error word: the results of
+                                that launch are incomplete (ss_config_device_status) */
 } ss_status;
 
 enum { SS_FRAMING_CONTRACT = 0, SS_FRAMING_LITERAL = 1, SS_FRAMING_CENTER = 2, SS_FRAMING_PADDED = 3 };
@@ -110,6 +112,11 @@ int ss_params_default(ss_params *p, uint32_t sample_rate);
 int ss_config_create(const ss_params *p, ss_config **out);
 void ss_config_destroy(ss_config *cfg);
 int ss_config_params(const ss_config *cfg, ss_params *out);
+/* Device-side status of the asynchronous (*_device) launches made on this config: SS_OK, or SS_ERR_DEVICE if a kernel has
+ * reported a protocol error since the last call (the word is cleared).  Call it after synchronising the stream; the
+ * host-pointer entry points check it themselves before they return, and every launch on a config with a pending error
+ * fails with SS_ERR_DEVICE instead of queueing more work behind a broken one. */
+int ss_config_device_status(const ss_config *cfg);
 
 /* Validation and table construction only (no device): what ss_config_create checks. */
 int ss_params_validate(const ss_params *p);
@@ -146,12 +153,29 @@ int ss_mfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat, 
 int ss_mel_spectrogram(const ss_config *cfg, const float *x, size_t channels, size_t n_samples, float *out);
 /* speechsauce::processing::preemphasis (processing.rs:31-53) */
 int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, float *y);
+/* speechsauce::functions::stft1 (channels = 1, functions.rs:199-233) / stft2 (functions.rs:86-123) -> Array2 / Array3<Complex32>:
+ * x [channels x n_samples]; out: interleaved re, im  [channels x rows x (fft_points/2+1) x 2], rows = ss_stft_rows
+ * (the reference slices its n_pad leading rows off, functions.rs:121: the trailing n_pad rows are zero). */
+int ss_stft(const ss_config *cfg, const float *x, size_t channels, size_t n_samples, float *out);
+/* speechsauce::processing::stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding)
+ * (processing.rs:65-129) with the config's framing switch (contract / literal / padded = zero_padding) and frame window
+ * (the `filter` argument; mfcc_window switch): frames [n_frames x frame_len], sizes from ss_num_frames / ss_frame_sizes. */
+int ss_stack_frames(const ss_config *cfg, const float *x, size_t n_samples, float *frames);
+/* speechsauce::processing::power_spectrum(frames: Array2<f32>, fft_points) -> Array2<f32>  (processing.rs:179-181; fft_spectrum
+ * :143-171 zero-pads rows shorter than fft_points): frames [rows x cols], cols <= the config's fft_points;
+ * P [rows x (fft_points/2+1)] = |rfft(row)| / fft_points.  Only fft_points of the config is used. */
+int ss_power_spectrum_frames(const ss_config *cfg, const float *frames, size_t rows, size_t cols, float *P);
+/* the same stage on the frames mfe cuts from a signal (stack_frames + power_spectrum, feature.rs:203-214):
+ * P [n_frames x (fft_points/2+1)] */
+int ss_power_spectrum(const ss_config *cfg, const float *x, size_t n_samples, float *P);
 
 /* batch of equal-length clips: x [batch x n_samples] with row stride ld >= n_samples.
  * out: [batch x n_frames x num_cepstral] */
 int ss_mfcc_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *out);
 int ss_mfe_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld,
                  float *feat, float *energy);
+/* P [batch x n_frames x (fft_points/2+1)] */
+int ss_power_spectrum_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *P);
 
 /* ---- hot path, device pointers (asynchronous on `stream`) ----------------------------------- */
 
@@ -162,6 +186,18 @@ int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, si
 int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
                               size_t ld, float *d_out, void *stream);
 int ss_preemphasis_device(const float *d_x, size_t n_samples, long shift, float cof, float *d_y, void *stream);
+/* power_spectrum over the frames of each clip: [batch x n_frames x (fft_points/2+1)] (processing.rs:179-181) */
+int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,
+                                   size_t ld, float *d_P, void *stream);
+/* power_spectrum of a frames matrix [rows x cols] with row stride ld: [rows x (fft_points/2+1)] */
+int ss_power_spectrum_frames_device(const ss_config *cfg, const float *d_frames, size_t rows, size_t cols, size_t ld,
+                                    float *d_P, void *stream);
+/* stft2 (functions.rs:86-123): interleaved re,im  [channels x rows x (fft_points/2+1) x 2] */
+int ss_stft_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples, size_t ld,
+                   float *d_out, void *stream);
+/* stack_frames over a batch of clips: frames [batch x n_frames x frame_len] */
+int ss_stack_frames_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
+                           float *d_frames, void *stream);
 
 /* ---- post-processing on the feature matrix (row-major [rows x cols] f32) ---------- */
 
@@ -188,8 +224,6 @@ int ss_derivative_extraction_device(const float *d_feat, size_t rows, size_t col
 int ss_extract_derivative_feature(const float *feat, size_t rows, size_t cols, float *cube);
 int ss_extract_derivative_feature_device(const float *d_feat, size_t rows, size_t cols, float *d_cube, void *stream);
 
-/* stage outputs (parity triage; pub fns of the reference too):
- * power_spectrum (processing.rs:179-181) over the frames of each clip: [batch x n_frames x (fft_points/2+1)] */
 /* lmfe (feature.rs:242-245, README.md:14 "log mel filterbank energies"): ln of mfe's zero-handled energies, [frames x
  * num_filters].  d_energy may be NULL (the frame energies mfe also produces are then kept in a stream-ordered temporary). */
 int ss_lmfe(const ss_config *cfg, const float *x, size_t n_samples, float *feat);
@@ -206,17 +240,21 @@ int ss_power_to_db_device(const float *d_s, size_t n, float ref, float amin, flo
 /* ---- multi-GPU callers below Python (one process or thread per GPU) -------------------------------------
  * Clips are independent, so a batch shards by contiguous blocks with no exchange inside the path: rank r of `world`
  * computes clips [lo, hi) of ss_shard_bounds on its own device with the *_device entry points.  The north-star's "RCCL
- * gather over xGMI of the final [n_frames x n_mfcc] blocks" is ss_all_gather_features: every rank passes its block of
- * elems_per_rank floats (pad uneven shards to the largest) and receives [world x elems_per_rank] on `stream`.  `nccl_comm` is
- * the caller's ncclComm_t; the library resolves RCCL (librccl.so.1) at the first call and links nothing at build time. */
+ * gather over xGMI of the final [n_frames x n_mfcc] blocks" is ss_gather_features: every rank passes its block of
+ * elems_per_rank floats (pad uneven shards to the largest); rank `root` receives [world x elems_per_rank] in rank order
+ * (one ncclRecv per peer and one device copy of its own block inside an ncclGroup: every peer has a direct xGMI link to
+ * the root, so the blocks arrive concurrently), the other ranks only send (d_out may be NULL there).
+ * ss_all_gather_features is the all-to-all form for consumers that need the whole corpus on every GPU (one
+ * ncclAllGather; every rank then writes (world - 1) blocks into its HBM).
+ * `nccl_comm` is the caller's ncclComm_t and MUST come from the RCCL library this one resolves: the copy already mapped
+ * into the process (e.g. torch's bundled librccl.so) is preferred, then librccl.so.1 / librccl.so by name;
+ * ss_rccl_library(path) names the library explicitly (before the first collective) -- passing a communicator created by a
+ * different RCCL copy is undefined behaviour.  Nothing is linked at build time. */
 int ss_shard_bounds(size_t n_items, int world, int rank, size_t *lo, size_t *hi);
+int ss_rccl_library(const char *path);
+int ss_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, int root, int rank,
+                       int world, void *stream);
 int ss_all_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, void *stream);
-
-int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples,
-                                   size_t ld, float *d_P, void *stream);
-/* stft2 (functions.rs:86-123): interleaved re,im  [channels x rows x (fft_points/2+1) x 2] */
-int ss_stft_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples, size_t ld,
-                   float *d_out, void *stream);
 
 /* ---- device / diagnostics ------------------------------------------------------------------- */
 
@@ -231,16 +269,7 @@ int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t bat
 int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
                                    size_t ld, float *d_out, void *stream, int iters, float *avg_ms);
 
-/* Test aid: fills the LDS of every compute unit with 0xFFFFFFFF (a NaN pattern as f32, -1 as i32).  LDS is not cleared
- * between kernels, so a kernel that lets a word it never wrote reach its results fails loudly after this. */
-int ss_debug_poison_lds(void *stream);
-
-/* Diagnostic: while `d_stamps` is non-null, every launch of the 512-point MFCC kernel writes six 64-bit words per wave into
- * it (16 waves x CUs x 6 words, overwritten by each launch): [0] s_memrealtime (100 MHz) at wave start, [2] at wave end,
- * [5] shader-clock cycles the wave lived | 1 << 40 (table waves: a realtime stamp instead), [1] / [3] / [4] prologue end,
- * quads done << 32 | XCC id, first samples arrived.  bench.py uses it to report the shader clock the part held during the
- * timed launches (`roofline.clock_ghz_measured`).  Process-wide; pass NULL to switch it off. */
-int ss_debug_stamp_buffer(unsigned long long *d_stamps);
+/* Test aids and diagnostics (LDS poisoning, per-wave stamps, kernel-selection overrides): include/speechsauce_amd_debug.h */
 
 const char *ss_status_string(int status);
 const char *ss_last_error_string(void); /* thread-local detail of the last failure */

@@ -3,12 +3,15 @@
 //   speechsauce::config::{SpeechConfigBuilder, SpeechConfig}   (speechsauce/src/config.rs:10-190)
 //   speechsauce::feature::{mfcc, mfe, mel_spectrogram1, mel_spectrogram2}  (feature.rs:99-233)
 //   speechsauce::processing::preemphasis                        (processing.rs:31-53)
+//   speechsauce::processing::{stack_frames, power_spectrum}     (processing.rs:65-129, :179-181)
+//   speechsauce::functions::{stft1, stft2}                      (functions.rs:199-233, :86-123)
 //   speechsauce::processing::{cmvn, cmvnw, derivative_extraction}, feature::extract_derivative_feature
 //                                                               (processing.rs:222-371, feature.rs:253-269)
 // Where the reference panics, these throw speechsauce::Error carrying the ss_status.
 // Arrays are plain row-major std::vector<float> plus shapes (the reference returns ndarray::ArrayN<f32>).
 #pragma once
 
+#include <complex>
 #include <cstddef>
 #include <stdexcept>
 #include <string>
@@ -148,6 +151,43 @@ inline Array2 mel_spectrogram1(const float *signal, std::size_t n, const SpeechC
 {
     Array3 a = mel_spectrogram2(signal, 1, n, cfg);
     return Array2{a.d1, a.d2, std::move(a.data)};
+}
+
+// functions.rs:86-123: Array3<Complex32> [channels x rows x freq_size]
+struct ComplexArray3 {
+    std::size_t d0 = 0, d1 = 0, d2 = 0;
+    std::vector<std::complex<float>> data;
+};
+inline ComplexArray3 stft2(const float *signal, std::size_t channels, std::size_t n, const SpeechConfig &cfg)
+{
+    std::size_t rows = 0, real_rows = 0;
+    check(ss_stft_rows(&cfg.params(), n, &rows, &real_rows));
+    ComplexArray3 out{channels, rows, cfg.freq_size(), std::vector<std::complex<float>>(channels * rows * cfg.freq_size())};
+    // std::complex<float> is layout-compatible with float[2] (re, im): the interleaved block the ABI writes
+    check(ss_stft(cfg.handle(), signal, channels, n, reinterpret_cast<float *>(out.data.data())));
+    return out;
+}
+// functions.rs:199-233 (one channel): [rows x freq_size]
+inline ComplexArray3 stft1(const float *signal, std::size_t n, const SpeechConfig &cfg) { return stft2(signal, 1, n, cfg); }
+
+// processing.rs:65-129: frames [num_frames x frame_len].  sample_rate / frame_length / frame_stride, the `filter` argument
+// (mfcc_window switch) and zero_padding (framing = SS_FRAMING_PADDED) are the config's.
+inline Array2 stack_frames(const float *signal, std::size_t n, const SpeechConfig &cfg)
+{
+    std::size_t t = 0, flen = 0, step = 0;
+    check(ss_num_frames(&cfg.params(), n, &t));
+    check(ss_frame_sizes(&cfg.params(), &flen, &step));
+    Array2 out{t, flen, std::vector<float>(t * flen)};
+    check(ss_stack_frames(cfg.handle(), signal, n, out.data.data()));
+    return out;
+}
+
+// processing.rs:179-181: power_spectrum(frames, fft_points) with fft_points = the config's
+inline Array2 power_spectrum(const Array2 &frames, const SpeechConfig &cfg)
+{
+    Array2 out{frames.rows, cfg.freq_size(), std::vector<float>(frames.rows * cfg.freq_size())};
+    check(ss_power_spectrum_frames(cfg.handle(), frames.data.data(), frames.rows, frames.cols, out.data.data()));
+    return out;
 }
 
 // processing.rs:31-53

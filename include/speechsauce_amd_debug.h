@@ -1,0 +1,45 @@
+/*
+ * speechsauce_amd_debug.h -- test aids and diagnostics of libspeechsauce_amd.so.
+ *
+ * Not part of the drop-in boundary (include/speechsauce_amd.h): nothing here is needed to use the hot path, and nothing
+ * here changes a result.  tests/ and bench.py use these to prove properties of the product build (no uninitialised LDS
+ * word reaches a result; every kernel family agrees with the generic one; a lost tile hand-off becomes a status) and to
+ * measure the shader clock a launch held.  All settings are process-wide and meant for single-threaded test drivers.
+ */
+#ifndef SPEECHSAUCE_AMD_DEBUG_H
+#define SPEECHSAUCE_AMD_DEBUG_H
+
+#include "speechsauce_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Fills the LDS of every compute unit with 0xFFFFFFFF (a NaN pattern as f32, -1 as i32).  LDS is not cleared between
+ * kernels, so a kernel that lets a word it never wrote reach its results fails loudly after this. */
+int ss_debug_poison_lds(void *stream);
+
+/* While `d_stamps` is non-null, every launch of the 512-point MFCC kernel writes six 64-bit words per wave into it
+ * (16 waves x CUs x 6 words, overwritten by each launch): [0] s_memrealtime (100 MHz) at wave start, [2] at wave end,
+ * [5] shader-clock cycles the wave lived | 1 << 40 (table waves: a realtime stamp instead), [1] / [3] / [4] prologue end,
+ * quads done << 32 | XCC id, first samples arrived.  bench.py uses it to report the shader clock the part held during the
+ * timed launches (`roofline.clock_ghz_measured`).  Pass NULL to switch it off. */
+int ss_debug_stamp_buffer(unsigned long long *d_stamps);
+
+/* on != 0: every configuration runs on the generic kernel (ss_front_generic) instead of its dedicated one -- the
+ * cross-check of tests/test_gpu_parity.py::test_kernel_variants_agree and the "generic us" columns of DESIGN.md. */
+int ss_debug_force_generic(int on);
+
+/* on == 0: ss_mel_c1024 stores its rows directly instead of through the CU-wide whole-line tile (A/B and the bit-for-bit
+ * comparison of the two builds); on != 0: default selection. */
+int ss_debug_mel_tile(int on);
+
+/* on != 0: the next launches of ss_mel_c1024<tile> withhold wave 0's row pairs in every workgroup and poll only 4096
+ * times before giving up, so that the tile hand-off time-out path runs: the launch must end (no hang) and the config must
+ * report SS_ERR_DEVICE.  on == 0: normal operation. */
+int ss_debug_tile_fault(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECHSAUCE_AMD_DEBUG_H */

@@ -77,12 +77,31 @@ struct ss_config {
         size_t cap_small[3] = {0, 0, 0};
     };
     mutable HostPipe pipe;
+    // Device error word: one pinned, device-mapped word a kernel sets when it detects a condition that must not pass for a
+    // result (today: a tile hand-off of ss_mel_c1024<tile> that never came).  The host reads it without a copy; a non-zero
+    // word turns into SS_ERR_DEVICE at the next launch or synchronisation point on this config (pending_device_error).
+    unsigned *h_err = nullptr, *d_err = nullptr;
 };
+
+namespace {
+extern std::atomic<int> g_force_generic, g_mel_tile_off;
+extern std::atomic<unsigned> g_tile_fault;
+}  // namespace
+namespace ss {
+bool dbg_force_generic() { return g_force_generic.load(std::memory_order_relaxed) != 0; }
+bool dbg_mel_tile_off() { return g_mel_tile_off.load(std::memory_order_relaxed) != 0; }
+unsigned dbg_tile_fault() { return g_tile_fault.load(std::memory_order_relaxed); }
+// a forced fault polls 4096 times only (the test must not take seconds per wave)
+unsigned dbg_tile_spin_limit() { return g_tile_fault.load(std::memory_order_relaxed) ? 4096u : (1u << 24); }
+}  // namespace ss
 
 namespace {
 
 thread_local const char *g_last_kernel = "";
 std::atomic<unsigned long long *> g_stamp_buffer{nullptr};  // ss_debug_stamp_buffer
+// test aids of include/speechsauce_amd_debug.h (process-wide)
+std::atomic<int> g_force_generic{0}, g_mel_tile_off{0};
+std::atomic<unsigned> g_tile_fault{0};
 
 int hip_fail(hipError_t e, const char *what)
 {
@@ -122,6 +141,16 @@ struct DeviceBuf {
 
 int check_device(const ss_config *cfg);
 
+// SS_ERR_DEVICE if a kernel of an earlier launch on this config has set the device error word (and clears it).
+int pending_device_error(const ss_config *cfg)
+{
+    if (!cfg->h_err || __atomic_load_n(cfg->h_err, __ATOMIC_ACQUIRE) == 0) return SS_OK;
+    const unsigned w = __atomic_exchange_n(cfg->h_err, 0u, __ATOMIC_ACQ_REL);
+    if (w == 0) return SS_OK;
+    return ss::fail(SS_ERR_DEVICE, "a kernel launched on this config reported a device-side protocol error (error word " + std::to_string(w) +
+                                       "): the results of that launch are incomplete");
+}
+
 void fill_common(const ss_config *cfg, ss::FrontArgs &a)
 {
     const ss::HostTables &h = cfg->host;
@@ -142,8 +171,10 @@ void fill_common(const ss_config *cfg, ss::FrontArgs &a)
 }
 
 // MFCC-path launch (OUT_MFCC / OUT_MFE / OUT_POWER).
+// rows_are_frames: d_x is a frames matrix [batch x n] (row stride ld) -- every row is one frame of n <= fft_points samples,
+// no window, no pre-emphasis (processing::power_spectrum(frames, fft_points), processing.rs:179-181).
 int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t batch, size_t n, size_t ld,
-                  float *out0, float *out1, hipStream_t stream)
+                  float *out0, float *out1, hipStream_t stream, bool rows_are_frames = false)
 {
     if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
     if (batch == 0) return SS_OK;  // an empty batch has no buffers (a zero-row tensor's data pointer is null)
@@ -155,10 +186,18 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         // device pointers into that one's memory
         const int drc = check_device(cfg);
         if (drc) return drc;
+        const int erc = pending_device_error(cfg);  // no more work behind a launch that reported a device-side error
+        if (erc) return erc;
     }
     const ss::HostTables &h = cfg->host;
     size_t T = 0;
-    int rc = ss::num_frames(h.params, n, T);
+    int rc = SS_OK;
+    if (rows_are_frames) {
+        if (n == 0 || n > h.params.fft_points) return ss::fail(SS_ERR_ARG, "frame length must be in [1, fft_points]");
+        T = 1;
+    } else {
+        rc = ss::num_frames(h.params, n, T);
+    }
     if (rc) return rc;
     ss::FrontArgs a{};
     fill_common(cfg, a);
@@ -166,18 +205,19 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     a.ld = ld;
     a.n_samples = static_cast<uint32_t>(n);
     a.batch = static_cast<uint32_t>(batch);
-    a.flen = h.d.flen;
-    a.step = h.d.step;
+    a.flen = rows_are_frames ? static_cast<uint32_t>(n) : h.d.flen;
+    a.step = rows_are_frames ? static_cast<uint32_t>(n) : h.d.step;
     a.n_frames = static_cast<uint32_t>(T);
     // processing.rs:110-120 as written: nothing is copied for > 2 frames, x[0..flen] into every row otherwise
-    if (h.params.framing == SS_FRAMING_LITERAL) a.frame_mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
+    if (rows_are_frames) a.frame_mode = ss::FRAME_NORMAL;
+    else if (h.params.framing == SS_FRAMING_LITERAL) a.frame_mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
     else if (h.params.framing == SS_FRAMING_CENTER) a.frame_mode = ss::FRAME_CENTER;  // librosa center=True (generic kernel only)
     else if (h.params.framing == SS_FRAMING_PADDED) a.frame_mode = ss::FRAME_PADDED;  // zero_padding = true (generic kernel only)
     else a.frame_mode = ss::FRAME_NORMAL;
     a.pad_reflect = h.params.pad_mode == SS_PAD_REFLECT;
-    a.preemph = h.params.preemph_coef;
+    a.preemph = rows_are_frames ? 0.0f : h.params.preemph_coef;
     a.preemph_shift = static_cast<uint32_t>(h.params.preemph_shift > 0 ? h.params.preemph_shift : 1);
-    a.window = cfg->d_window_mfcc;
+    a.window = rows_are_frames ? nullptr : cfg->d_window_mfcc;
     a.scale = 1.0f / static_cast<float>(h.params.fft_points);  // processing.rs:180
     // feature.rs:126-131 (n = T * M as f32) or scipy ortho over the axis length
     const float g = h.params.dct2_gain;
@@ -197,7 +237,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     ss::LaunchInfo info{};
     // fft_points = 512 MFCC: the specialised wave-private kernel (its builds: default bank / run-time bank, window,
     // pre-emphasis, mfe and power outputs, librosa variants)
-    static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
+    const bool force_generic = ss::dbg_force_generic();
     // the mfe-output build of that kernel exists for the default bank shape only
     const bool mfe_shape = a.flen == 320 && a.spectrum_exponent != 2 && cfg->fast.q4[0] == 4 && cfg->fast.q4[1] == 2 &&
                            cfg->fast.q4[2] == 1 && a.n_filters <= 40;
@@ -214,8 +254,10 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
                          (out_kind == ss::OUT_MFCC || (out_kind == ss::OUT_MFE && mfe_shape) || (out_kind == ss::OUT_POWER && mfe_shape && !front)) &&
                          (lib_variant ? lib_ok : (!front || mfe_shape)) && (a.frame_mode == ss::FRAME_NORMAL || centre);
     const bool fits32 = static_cast<unsigned long long>(batch) * T < 0xffffffffull;
-    static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only: per-wave realtime stamps of ONE launch
+#if SS_LAB
+    static const char *dbg_path = std::getenv("SS_DEBUG_TIMES");  // diagnostic only (lab build): per-wave realtime stamps of ONE launch
     static bool dbg_done = false;
+#endif
     if (fast_ok && fits32) {
         ss::Fast512Args f{};
         f.x = d_x;
@@ -245,6 +287,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.center = centre;
         f.pad_reflect = a.pad_reflect;
         f.fullp = cfg->fast.fullp;
+#if SS_LAB
         if (dbg_path && !dbg_done && !f.out_mfe) {
             dbg_done = true;
             const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
@@ -279,6 +322,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             }
             f.dbg = nullptr;
         }
+#endif
         f.dbg = g_stamp_buffer.load(std::memory_order_relaxed);
         const hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
@@ -433,7 +477,11 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out_energy = out1;
         f.out_mfe = out_kind == ss::OUT_MFE;
         f.window = a.window;
-        static const char *rows_path = std::getenv("SS_DEBUG_ROWS");  // diagnostic only: frame 0's P row and ln(mel) row
+#if SS_LAB
+        static const char *rows_path = std::getenv("SS_DEBUG_ROWS");  // diagnostic only (lab build): frame 0's P row and ln(mel) row
+#else
+        constexpr const char *rows_path = nullptr;
+#endif
         if (rows_path) (void)hipMalloc(reinterpret_cast<void **>(&f.dbg), (1028 + 256 + 4 * 4096) * sizeof(float));
         const hipError_t e4 = ss::launch_mfcc_c2048(f, stream, cfg->num_cus, &info);
         if (e4 != hipSuccess && f.dbg) (void)hipFree(f.dbg);
@@ -472,6 +520,8 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     {
         const int drc = check_device(cfg);  // see launch_frames
         if (drc) return drc;
+        const int erc = pending_device_error(cfg);
+        if (erc) return erc;
     }
     const ss::HostTables &h = cfg->host;
     size_t R = 0, Rreal = 0;
@@ -493,7 +543,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     a.out0 = out0;
     ss::LaunchInfo info{};
     // fft_points = 2048 mel spectrogram: the wave-private kernel when its layout assumptions hold
-    static const bool force_generic = std::getenv("SS_FORCE_GENERIC") != nullptr;
+    const bool force_generic = ss::dbg_force_generic();
     const bool want_stft = out_kind == ss::OUT_STFT;  // the stft builds do not use the bank (stft_only table blocks)
     if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel2048.ok || (want_stft && cfg->mel2048.stft_only)) &&
         static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
@@ -514,6 +564,9 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.n_filters = a.n_filters;
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
+        m.err = cfg->d_err;
+        m.spin_limit = ss::dbg_tile_spin_limit();
+        m.fault = ss::dbg_tile_fault();
         const hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
             g_last_kernel = info.kernel_name;
@@ -587,6 +640,42 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
     return SS_OK;
 }
 
+// stack_frames (processing.rs:65-129): frames[clip][t][i] = x[clip][t * step + i] (* window[i]); one thread per element,
+// neighbouring threads on neighbouring samples of a frame.  frame_mode as in the fused kernels' loaders: contract framing,
+// zero_padding = true (zeros past the signal), the literal exact_chunks copy (all-zero rows for > 2 frames, x[0 .. flen & ~1]
+// in every row otherwise), librosa's centred frames.
+__global__ __launch_bounds__(256) void ss_stack_frames_kernel(const float *__restrict__ x, unsigned long long ld, unsigned n_samples, unsigned flen,
+                                                             unsigned step, unsigned n_frames, int frame_mode, int pad_reflect,
+                                                             const float *__restrict__ window, float *__restrict__ frames, unsigned long long total)
+{
+    const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const unsigned i = static_cast<unsigned>(g % flen);
+    const unsigned long long row = g / flen;
+    const unsigned t = static_cast<unsigned>(row % n_frames);
+    const float *xc = x + (row / n_frames) * ld;
+    float v = 0.0f;
+    if (frame_mode == ss::FRAME_NORMAL) {
+        v = xc[t * step + i];
+    } else if (frame_mode == ss::FRAME_PADDED) {
+        const unsigned idx = t * step + i;
+        v = idx < n_samples ? xc[idx] : 0.0f;
+    } else if (frame_mode == ss::FRAME_FIRST) {
+        v = i < (flen & ~1u) ? xc[i] : 0.0f;
+    } else if (frame_mode == ss::FRAME_CENTER) {
+        long long pos = static_cast<long long>(t) * step + i - flen / 2;
+        const long long ns = n_samples;
+        bool inside = true;
+        if (pos < 0 || pos >= ns) {
+            if (pad_reflect) pos = pos < 0 ? -pos : 2 * (ns - 1) - pos;
+            else inside = false;
+        }
+        v = inside ? xc[pos] : 0.0f;
+    }  // FRAME_ZERO: zeros
+    if (window) v *= window[i];
+    frames[g] = v;
+}
+
 int check_device(const ss_config *cfg)
 {
     int dev = -1;
@@ -608,11 +697,15 @@ int host_pipeline(const ss_config *cfg, const float *x, size_t units, size_t n, 
 {
     ss_config::HostPipe &hp = cfg->pipe;
     std::lock_guard<std::mutex> lock(hp.mu);
+#if SS_LAB
     static const size_t chunk_bytes = [] {
-        const char *e = std::getenv("SS_HOST_CHUNK_MB");
+        const char *e = std::getenv("SS_HOST_CHUNK_MB");  // A/B knob (lab build)
         const long mb = e ? std::atol(e) : 16;
         return static_cast<size_t>(mb > 0 ? mb : 16) << 20;
     }();
+#else
+    constexpr size_t chunk_bytes = size_t(16) << 20;
+#endif
     for (int b = 0; b < 2; ++b) {
         if (!hp.stream[b]) {
             SS_HIP(hipStreamCreateWithFlags(&hp.stream[b], hipStreamNonBlocking));
@@ -624,11 +717,15 @@ int host_pipeline(const ss_config *cfg, const float *x, size_t units, size_t n, 
     // 1 and 2 MB of samples, tools/latency.py) of input and of output
     // the samples are copied into pinned, device-mapped memory by the CPU, the kernel reads them and writes its results
     // through the mapping, and the only stream operations are the launch and one synchronise.
+#if SS_LAB
     static const size_t small_bytes = [] {
-        const char *e = std::getenv("SS_HOST_SMALL_KB");
+        const char *e = std::getenv("SS_HOST_SMALL_KB");  // A/B knob (lab build)
         const long kb = e ? std::atol(e) : 1024;
         return static_cast<size_t>(kb > 0 ? kb : 0) << 10;
     }();
+#else
+    constexpr size_t small_bytes = size_t(1024) << 10;
+#endif
     const size_t in_all = ((units - 1) * ld + n) * sizeof(float), o0_all = units * out0_per_unit * sizeof(float),
                  o1_all = out1 ? units * out1_per_unit * sizeof(float) : 0;
     if (units > 0 && in_all <= small_bytes && o0_all <= small_bytes && o1_all <= small_bytes) {
@@ -648,6 +745,7 @@ int host_pipeline(const ss_config *cfg, const float *x, size_t units, size_t n, 
         int rc = launch(static_cast<const float *>(hp.d_small[0]), units, static_cast<float *>(hp.d_small[1]), static_cast<float *>(hp.d_small[2]), hp.stream[0]);
         const hipError_t e = hipStreamSynchronize(hp.stream[0]);
         if (e != hipSuccess && rc == SS_OK) rc = hip_fail(e, "host call (mapped staging)");
+        if (rc == SS_OK) rc = pending_device_error(cfg);
         if (rc == SS_OK) {
             std::memcpy(out0, hp.h_small[1], o0_all);
             if (out1) std::memcpy(out1, hp.h_small[2], o1_all);
@@ -660,11 +758,22 @@ int host_pipeline(const ss_config *cfg, const float *x, size_t units, size_t n, 
     const size_t in_cap = ((cu - 1) * ld + n) * sizeof(float), o0_cap = cu * out0_per_unit * sizeof(float), o1_cap = cu * out1_per_unit * sizeof(float);
     auto grow = [&](void *(&buf)[2], size_t &cap, size_t need) -> int {
         if (need <= cap) return SS_OK;
+        // the capacity is void until BOTH new buffers exist: a failed hipMalloc must not leave a non-zero cap beside a
+        // freed pointer (every later call with need <= cap would launch on a null buffer)
+        cap = 0;
         for (int b = 0; b < 2; ++b) {
             SS_HIP(hipStreamSynchronize(hp.stream[b]));
             if (buf[b]) (void)hipFree(buf[b]);
             buf[b] = nullptr;
-            SS_HIP(hipMalloc(&buf[b], need));
+        }
+        for (int b = 0; b < 2; ++b) {
+            const hipError_t e = hipMalloc(&buf[b], need);
+            if (e != hipSuccess) {
+                buf[b] = nullptr;
+                if (buf[0]) (void)hipFree(buf[0]);
+                buf[0] = buf[1] = nullptr;
+                return hip_fail(e, "hipMalloc (host pipeline buffers)");
+            }
         }
         cap = need;
         return SS_OK;
@@ -677,17 +786,22 @@ int host_pipeline(const ss_config *cfg, const float *x, size_t units, size_t n, 
         const int b = static_cast<int>(k & 1);
         const size_t c = std::min(cu, units - u0);
         hipStream_t st = hp.stream[b];
-        // the stream orders this chunk behind the previous use of the same buffer set
-        SS_HIP(hipMemcpyAsync(hp.d_in[b], x + u0 * ld, ((c - 1) * ld + n) * sizeof(float), hipMemcpyHostToDevice, st));
+        // the stream orders this chunk behind the previous use of the same buffer set.  A failure only breaks out of the
+        // loop: earlier chunks may still have copies in flight that touch the caller's x / out buffers, so both streams are
+        // synchronised below before this function returns, whatever happened.
+        hipError_t e = hipMemcpyAsync(hp.d_in[b], x + u0 * ld, ((c - 1) * ld + n) * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync (H2D)"); break; }
         rc = launch(static_cast<const float *>(hp.d_in[b]), c, static_cast<float *>(hp.d_out0[b]), static_cast<float *>(hp.d_out1[b]), st);
         if (rc) break;
-        SS_HIP(hipMemcpyAsync(out0 + u0 * out0_per_unit, hp.d_out0[b], c * out0_per_unit * sizeof(float), hipMemcpyDeviceToHost, st));
-        if (out1) SS_HIP(hipMemcpyAsync(out1 + u0 * out1_per_unit, hp.d_out1[b], c * out1_per_unit * sizeof(float), hipMemcpyDeviceToHost, st));
+        e = hipMemcpyAsync(out0 + u0 * out0_per_unit, hp.d_out0[b], c * out0_per_unit * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && out1) e = hipMemcpyAsync(out1 + u0 * out1_per_unit, hp.d_out1[b], c * out1_per_unit * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync (D2H)"); break; }
     }
     for (int b = 0; b < 2; ++b) {
         const hipError_t e = hipStreamSynchronize(hp.stream[b]);
         if (e != hipSuccess && rc == SS_OK) rc = hip_fail(e, "host pipeline");
     }
+    if (rc == SS_OK) rc = pending_device_error(cfg);
     return rc;
 }
 
@@ -774,6 +888,21 @@ int ss_config_create(const ss_params *p, ss_config **out)
     ss::build_mel2048(h, c->mel2048);
     if (c->mel2048.ok || c->mel2048.stft_only) SS_UP(d_mel2048_tab, c->mel2048.tab);
 #undef SS_UP
+    {
+        // device error word (see ss_config): pinned and device-mapped, so that a kernel's store is visible to the host without
+        // a copy and costs nothing unless it happens
+        void *hp = nullptr, *dp = nullptr;
+        hipError_t e2 = hipHostMalloc(&hp, 64, hipHostMallocMapped);
+        if (e2 == hipSuccess) e2 = hipHostGetDevicePointer(&dp, hp, 0);
+        if (e2 != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            ss_config_destroy(cfg.release());
+            return hip_fail(e2, "hipHostMalloc (device error word)");
+        }
+        std::memset(hp, 0, 64);
+        c->h_err = static_cast<unsigned *>(hp);
+        c->d_err = static_cast<unsigned *>(dp);
+    }
     *out = cfg.release();
     return SS_OK;
 }
@@ -795,6 +924,7 @@ void ss_config_destroy(ss_config *cfg)
     }
     for (void *p : cfg->pipe.h_small)
         if (p) (void)hipHostFree(p);
+    if (cfg->h_err) (void)hipHostFree(cfg->h_err);
     delete cfg;
 }
 
@@ -803,6 +933,12 @@ int ss_config_params(const ss_config *cfg, ss_params *out)
     if (!cfg || !out) return ss::fail(SS_ERR_ARG, "null argument");
     *out = cfg->host.params;
     return SS_OK;
+}
+
+int ss_config_device_status(const ss_config *cfg)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    return pending_device_error(cfg);
 }
 
 // ---- device-pointer variants ---------------------------------------------------------------
@@ -876,20 +1012,143 @@ int ss_shard_bounds(size_t n_items, int world, int rank, size_t *lo, size_t *hi)
     return SS_OK;
 }
 
+}  // extern "C" (reopened below, after the RCCL resolver)
+
+// ---- RCCL, resolved at run time (nothing is linked at build time) ---------------------------------------------------------
+// The communicator is the caller's, so the functions must come from the RCCL copy that created it.  Order: a library named
+// with ss_rccl_library; a copy that is ALREADY mapped into the process (dlsym(RTLD_DEFAULT), then RTLD_NOLOAD on the usual
+// sonames -- a Python process that imported torch has torch/lib/librccl.so mapped, and torch.distributed's communicators
+// come from it); only then a fresh dlopen of librccl.so.1 / librccl.so.
+namespace {
+
+struct Rccl {
+    using all_gather_fn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
+    using send_fn = int (*)(const void *, size_t, int, int, void *, hipStream_t);
+    using recv_fn = int (*)(void *, size_t, int, int, void *, hipStream_t);
+    using group_fn = int (*)();
+    all_gather_fn all_gather = nullptr;
+    send_fn send = nullptr;
+    recv_fn recv = nullptr;
+    group_fn group_start = nullptr, group_end = nullptr;
+    std::string origin;
+    bool ok() const { return all_gather && send && recv && group_start && group_end; }
+};
+
+std::mutex g_rccl_mu;
+std::string g_rccl_path;       // ss_rccl_library
+std::unique_ptr<Rccl> g_rccl;  // resolved once
+
+bool rccl_from(void *handle, const char *origin, Rccl &r)
+{
+    r.all_gather = reinterpret_cast<Rccl::all_gather_fn>(dlsym(handle, "ncclAllGather"));
+    r.send = reinterpret_cast<Rccl::send_fn>(dlsym(handle, "ncclSend"));
+    r.recv = reinterpret_cast<Rccl::recv_fn>(dlsym(handle, "ncclRecv"));
+    r.group_start = reinterpret_cast<Rccl::group_fn>(dlsym(handle, "ncclGroupStart"));
+    r.group_end = reinterpret_cast<Rccl::group_fn>(dlsym(handle, "ncclGroupEnd"));
+    r.origin = origin;
+    return r.ok();
+}
+
+const Rccl *rccl()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl) return g_rccl->ok() ? g_rccl.get() : nullptr;
+    g_rccl.reset(new Rccl());
+    if (!g_rccl_path.empty()) {
+        void *h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (h && rccl_from(h, g_rccl_path.c_str(), *g_rccl)) return g_rccl.get();
+        return nullptr;  // an explicit path that does not load is an error, not a reason to guess
+    }
+    if (rccl_from(RTLD_DEFAULT, "already in the global symbol scope", *g_rccl)) return g_rccl.get();
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        void *h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (h && rccl_from(h, "already mapped (RTLD_NOLOAD)", *g_rccl)) return g_rccl.get();
+    }
+    {
+        // a copy mapped under another name (torch/lib/librccl.so is loaded by path): look through the process's objects
+        struct Ctx { std::string path; } ctx;
+        if (FILE *fp = std::fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (std::fgets(line, sizeof line, fp)) {
+                const char *sl = std::strchr(line, '/');
+                if (sl && std::strstr(sl, "librccl.so")) {
+                    ctx.path.assign(sl, std::strcspn(sl, "\n"));
+                    break;
+                }
+            }
+            std::fclose(fp);
+        }
+        if (!ctx.path.empty()) {
+            void *h = dlopen(ctx.path.c_str(), RTLD_NOW | RTLD_NOLOAD);
+            if (h && rccl_from(h, ctx.path.c_str(), *g_rccl)) return g_rccl.get();
+        }
+    }
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h && rccl_from(h, name, *g_rccl)) return g_rccl.get();
+    }
+    return nullptr;
+}
+
+int rccl_fail(const char *what, int rc)
+{
+    return ss::fail(SS_ERR_HIP, std::string(what) + " failed with ncclResult_t " + std::to_string(rc));
+}
+
+constexpr int kNcclFloat32 = 7;  // rccl.h: ncclFloat32
+
+}  // namespace
+
+extern "C" {
+
+int ss_rccl_library(const char *path)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl) return ss::fail(SS_ERR_ARG, "RCCL was already resolved (" + g_rccl->origin + "): ss_rccl_library must precede the first collective");
+    g_rccl_path = path ? path : "";
+    return SS_OK;
+}
+
 int ss_all_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, void *stream)
 {
     if (!nccl_comm || !d_block || !d_out) return ss::fail(SS_ERR_ARG, "null argument");
     if (elems_per_rank == 0) return SS_OK;
-    // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); ncclFloat32 = 7 (rccl.h)
-    using all_gather_fn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
-    static all_gather_fn fn = [] {
-        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        return h ? reinterpret_cast<all_gather_fn>(dlsym(h, "ncclAllGather")) : nullptr;
-    }();
-    if (!fn) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded");
-    const int rc = fn(d_block, d_out, elems_per_rank, 7, nccl_comm, static_cast<hipStream_t>(stream));
-    if (rc != 0) return ss::fail(SS_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+    const Rccl *r = rccl();
+    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (no mapped copy, librccl.so.1 / librccl.so not loadable)");
+    // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream)
+    const int rc = r->all_gather(d_block, d_out, elems_per_rank, kNcclFloat32, nccl_comm, static_cast<hipStream_t>(stream));
+    if (rc != 0) return rccl_fail("ncclAllGather", rc);
+    return SS_OK;
+}
+
+int ss_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, int root, int rank, int world,
+                       void *stream)
+{
+    if (!nccl_comm || !d_block) return ss::fail(SS_ERR_ARG, "null argument");
+    if (world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world) return ss::fail(SS_ERR_ARG, "bad world / rank / root");
+    if (rank == root && !d_out) return ss::fail(SS_ERR_ARG, "the root needs an output buffer");
+    if (elems_per_rank == 0) return SS_OK;
+    const Rccl *r = rccl();
+    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (no mapped copy, librccl.so.1 / librccl.so not loadable)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (rank != root) {
+        const int rc = r->send(d_block, elems_per_rank, kNcclFloat32, root, nccl_comm, st);
+        return rc ? rccl_fail("ncclSend", rc) : SS_OK;
+    }
+    // root: its own block is a device copy; one receive per peer inside a group, so that all of them progress together
+    // (every peer has a direct xGMI link to the root)
+    SS_HIP(hipMemcpyAsync(d_out + static_cast<size_t>(root) * elems_per_rank, d_block, elems_per_rank * sizeof(float), hipMemcpyDeviceToDevice, st));
+    int rc = r->group_start();
+    if (rc) return rccl_fail("ncclGroupStart", rc);
+    int first_err = 0;
+    for (int p = 0; p < world; ++p) {
+        if (p == root) continue;
+        const int e = r->recv(d_out + static_cast<size_t>(p) * elems_per_rank, elems_per_rank, kNcclFloat32, p, nccl_comm, st);
+        if (e && !first_err) first_err = e;
+    }
+    rc = r->group_end();  // always closed, also after a failed ncclRecv
+    if (first_err) return rccl_fail("ncclRecv", first_err);
+    if (rc) return rccl_fail("ncclGroupEnd", rc);
     return SS_OK;
 }
 
@@ -897,6 +1156,109 @@ int ss_power_spectrum_batch_device(const ss_config *cfg, const float *d_x, size_
                                    size_t ld, float *d_P, void *stream)
 {
     return launch_frames(cfg, ss::OUT_POWER, d_x, batch, n_samples, ld, d_P, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ss_power_spectrum_frames_device(const ss_config *cfg, const float *d_frames, size_t rows, size_t cols, size_t ld, float *d_P,
+                                    void *stream)
+{
+    return launch_frames(cfg, ss::OUT_POWER, d_frames, rows, cols, ld, d_P, nullptr, static_cast<hipStream_t>(stream), true);
+}
+
+// Host-pointer forms of the stage outputs the reference exposes as pub fns (processing.rs:179-181, functions.rs:86-123,
+// :199-233, processing.rs:65-129): same chunked two-stream pipeline / mapped small-call staging as ss_mfcc_batch.
+int ss_power_spectrum_batch(const ss_config *cfg, const float *x, size_t batch, size_t n_samples, size_t ld, float *P)
+{
+    if (!cfg || !x || !P) return ss::fail(SS_ERR_ARG, "null argument");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    size_t T = 0;
+    int rc = ss::num_frames(cfg->host.params, n_samples, T);
+    if (rc) return rc;
+    if (batch == 0) return SS_OK;
+    rc = check_device(cfg);
+    if (rc) return rc;
+    return host_pipeline(cfg, x, batch, n_samples, ld, P, T * (cfg->host.params.fft_points / 2 + 1), nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_power_spectrum_batch_device(cfg, d_x, c, n_samples, ld, d_o0, st);
+                         });
+}
+
+int ss_power_spectrum(const ss_config *cfg, const float *x, size_t n_samples, float *P)
+{
+    return ss_power_spectrum_batch(cfg, x, 1, n_samples, n_samples, P);
+}
+
+int ss_power_spectrum_frames(const ss_config *cfg, const float *frames, size_t rows, size_t cols, float *P)
+{
+    if (!cfg || !frames || !P) return ss::fail(SS_ERR_ARG, "null argument");
+    if (cols == 0 || cols > cfg->host.params.fft_points) return ss::fail(SS_ERR_ARG, "frame length must be in [1, fft_points]");
+    if (rows == 0) return SS_OK;
+    const int rc = check_device(cfg);
+    if (rc) return rc;
+    return host_pipeline(cfg, frames, rows, cols, cols, P, cfg->host.params.fft_points / 2 + 1, nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_power_spectrum_frames_device(cfg, d_x, c, cols, cols, d_o0, st);
+                         });
+}
+
+int ss_stack_frames_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_frames,
+                           void *stream)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    const ss::HostTables &h = cfg->host;
+    size_t T = 0;
+    int rc = ss::num_frames(h.params, n_samples, T);
+    if (rc) return rc;
+    if (batch == 0) return SS_OK;
+    if (!d_x || !d_frames) return ss::fail(SS_ERR_ARG, "null buffer");
+    if (n_samples > 0x7fffffffull || static_cast<unsigned long long>(T) * h.d.step + h.d.flen > 0xffffffffull)
+        return ss::fail(SS_ERR_ARG, "clip too long");
+    rc = check_device(cfg);
+    if (rc) return rc;
+    int mode = ss::FRAME_NORMAL;
+    if (h.params.framing == SS_FRAMING_LITERAL) mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
+    else if (h.params.framing == SS_FRAMING_CENTER) mode = ss::FRAME_CENTER;
+    else if (h.params.framing == SS_FRAMING_PADDED) mode = ss::FRAME_PADDED;
+    const unsigned long long total = static_cast<unsigned long long>(batch) * T * h.d.flen;
+    const unsigned long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "batch too large");
+    hipLaunchKernelGGL(ss_stack_frames_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), d_x,
+                       static_cast<unsigned long long>(ld), static_cast<unsigned>(n_samples), h.d.flen, h.d.step, static_cast<unsigned>(T), mode,
+                       h.params.pad_mode == SS_PAD_REFLECT ? 1 : 0, cfg->d_window_mfcc, d_frames, total);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "ss_stack_frames_kernel");
+    g_last_kernel = "ss_stack_frames_kernel";
+    return SS_OK;
+}
+
+int ss_stack_frames(const ss_config *cfg, const float *x, size_t n_samples, float *frames)
+{
+    if (!cfg || !x || !frames) return ss::fail(SS_ERR_ARG, "null argument");
+    size_t T = 0;
+    int rc = ss::num_frames(cfg->host.params, n_samples, T);
+    if (rc) return rc;
+    rc = check_device(cfg);
+    if (rc) return rc;
+    return host_pipeline(cfg, x, 1, n_samples, n_samples, frames, T * cfg->host.d.flen, nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_stack_frames_device(cfg, d_x, c, n_samples, n_samples, d_o0, st);
+                         });
+}
+
+int ss_stft(const ss_config *cfg, const float *x, size_t channels, size_t n_samples, float *out)
+{
+    if (!cfg || !x || !out) return ss::fail(SS_ERR_ARG, "null argument");
+    size_t R = 0, Rreal = 0;
+    int rc = ss::stft_rows(cfg->host.params, n_samples, R, Rreal);
+    if (rc) return rc;
+    if (channels == 0) return SS_OK;
+    if (n_samples == 0) return ss::fail(SS_ERR_ARG, "empty signal");
+    rc = check_device(cfg);
+    if (rc) return rc;
+    return host_pipeline(cfg, x, channels, n_samples, n_samples, out, R * (cfg->host.params.fft_points / 2 + 1) * 2, nullptr, 0,
+                         [&](const float *d_x, size_t c, float *d_o0, float *, hipStream_t st) {
+                             return ss_stft_device(cfg, d_x, c, n_samples, n_samples, d_o0, st);
+                         });
 }
 
 int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
@@ -1003,6 +1365,25 @@ int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, floa
 // ---- diagnostics ---------------------------------------------------------------------------
 
 const char *ss_last_kernel_name(void) { return g_last_kernel; }
+
+// ---- test aids (include/speechsauce_amd_debug.h) ----
+int ss_debug_force_generic(int on)
+{
+    g_force_generic.store(on ? 1 : 0, std::memory_order_relaxed);
+    return SS_OK;
+}
+
+int ss_debug_mel_tile(int on)
+{
+    g_mel_tile_off.store(on ? 0 : 1, std::memory_order_relaxed);
+    return SS_OK;
+}
+
+int ss_debug_tile_fault(int on)
+{
+    g_tile_fault.store(on ? 1u : 0u, std::memory_order_relaxed);
+    return SS_OK;
+}
 
 int ss_debug_stamp_buffer(unsigned long long *d_stamps)
 {

@@ -1226,6 +1226,7 @@ const char *ss_status_string(int status)
         case SS_ERR_ARG: return "invalid argument";
         case SS_ERR_HIP: return "HIP runtime error / no device";
         case SS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SS_ERR_DEVICE: return "device-side protocol error reported by a kernel";
         default: return "unknown status";
     }
 }

@@ -141,20 +141,32 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         if (lane == 0) atomicAdd(s_fd + fb, 1u);
         ++fl_next;
     };
+    // A hand-off that never comes (a protocol error: it cannot happen unless a wave of this workgroup died or the counters
+    // were corrupted) must neither hang nor pass for a result.  The waits are bounded; a wave that runs into the bound sets
+    // the config's device error word (pinned host memory, so the host sees it without a copy: ss_api.hip turns it into
+    // SS_ERR_DEVICE at the next launch / synchronisation point on the config) and stops producing: it writes nothing more
+    // into the tile, flushes nothing, takes no further unit.  Its peers then run into their own bounds and stop as well.
+    // (A trap measured 2 us on the whole launch; NaNs in the output could be overwritten by a later flush.)
+    bool dead = false;  // wave-uniform
+    auto protocol_error = [&]() {
+        if (lane == 0 && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dead = true;
+    };
     auto flush_share = [&](unsigned upto, bool wait) {
         while (fl_next < upto) {
             const unsigned fb = (fl_next - c_lo) % kTileBufs;
             const unsigned full = tile_full(fl_next);
             if (peek(s_cnt + fb) != full) {
                 if (!wait) return;
-                // bounded: a protocol error must neither hang nor pass for a result -- the clip's block gets NaNs (a trap here
-                // measured 2 us on the whole launch)
                 unsigned tries = 0;
-                while (peek(s_cnt + fb) != full && tries < (1u << 24)) {
+                while (peek(s_cnt + fb) != full && tries < a.spin_limit) {
                     __builtin_amdgcn_s_sleep(1);
                     ++tries;
                 }
-                if (tries >= (1u << 24)) a.out[static_cast<unsigned long long>(fl_next) * M * R + lane] = __builtin_nanf("");
+                if (tries >= a.spin_limit) {
+                    protocol_error();
+                    return;
+                }
             }
             flush_one();
         }
@@ -346,10 +358,16 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     for (unsigned tries = 0; seen_fd != freed && peek(s_fd + b) != freed; ++tries) {
                         flush_share(clip, false);  // the buffer may be waiting for this very wave's share of an older clip
                         __builtin_amdgcn_s_sleep(1);
-                        if (tries > (1u << 24)) {  // as above: visible, not silent
-                            a.out[static_cast<unsigned long long>(clip) * M * R + lane] = __builtin_nanf("");
+                        if (tries > a.spin_limit) {  // the buffer still belongs to an older clip: do not touch it
+                            protocol_error();
                             break;
                         }
+                    }
+                    if (dead) break;
+                    if (a.fault && wave == 0) {  // test aid: this wave's row pairs never arrive
+                        if (!PREFETCH_M && next < u_hi) load_unit(next, v);
+                        unit = next;
+                        continue;
                     }
                     float *tcol = s_tile + b * (kTileMels * kTilePitch) + r;
                     if (in_rows) {
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         if (!PREFETCH_M && next < u_hi) load_unit(next, v);
         unit = next;
     }
-    if (TILE) {
+    if (TILE && !dead) {
         // out of units: what is left of the range's last clips (bounded wait for rows other waves are still computing)
         flush_share(c_hi, true);
     }
@@ -387,9 +405,8 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
     size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // whole-line stores through the CU-wide tile: mel output, every CU at least one clip, the tile fits next to everything else
-    static const char *tile_env = std::getenv("SS_MEL_TILE");  // A/B knob
     const size_t lds_tile = lds + (kTileFloats + 2 * kTileBufs + 2) * sizeof(float);
-    const bool tile = !(tile_env && std::atoi(tile_env) == 0) && !a.out_stft && !a.fullp && a.rows <= kTileRows && a.rows % 4 == 0 && a.n_filters <= 128 && a.n_filters % 8 == 0 &&
+    const bool tile = !dbg_mel_tile_off() && !a.out_stft && !a.fullp && a.rows <= kTileRows && a.rows % 4 == 0 && a.n_filters <= 128 && a.n_filters % 8 == 0 &&
                       lds_tile <= 160 * 1024 && a.batch >= static_cast<uint32_t>(num_cus > 0 ? num_cus : 256);
     if (tile) lds = lds_tile;
     if (a.batch == 0) return hipSuccess;
@@ -415,8 +432,10 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    static const char *w = std::getenv("SS_MEL_WAVES");  // A/B knob
+#if SS_LAB
+    static const char *w = std::getenv("SS_MEL_WAVES");  // A/B knob (lab build)
     if (w && std::atoi(w) == 12) return launch_mel_w<12>(a, stream, num_cus, info);
+#endif
     return launch_mel_w<8>(a, stream, num_cus, info);
 }
 

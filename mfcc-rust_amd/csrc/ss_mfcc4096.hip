@@ -28,10 +28,15 @@
 // SS_TOUCH=1: one load per 128-byte line of the frame that is claimed about one iteration from now (pulls its new samples
 // into L2 ahead of the sample loads).  Measured: -0.9 % time, but +57 % HBM fetch traffic (lines evicted again before their
 // use: 8 waves x 16 KB per CU against a 4 MB L2 shared by 32 CUs) -- off.
+// timing-attribution builds (lab build only, tools/ablate.sh; results wrong by design): 1 no DCT, 2 no mel + DCT, 4 no partner
+// fetch, 8 no exchange.  The product build compiles both switches out.
+#if !SS_LAB
+#undef SS_TOUCH
+#undef SS_ABL5
+#endif
 #ifndef SS_TOUCH
 #define SS_TOUCH 0
 #endif
-// timing-attribution builds (tools/ablate.sh, results wrong by design): 1 no DCT, 2 no mel + DCT, 4 no partner fetch, 8 no exchange
 #ifndef SS_ABL5
 #define SS_ABL5 0
 #endif

@@ -47,25 +47,21 @@
 
 #include <cstdlib>
 
-// Timing-attribution builds (tools/ablate.sh): each bit removes one stage; results are then wrong by design.
+// Timing-attribution builds (lab build only: tools/ablate.sh passes -DSS_LAB=1 -DSS_ABLATE=<bits>): each bit removes one
+// stage; results are then wrong by design.  The product build compiles the switch out (SS_ABLATE is the constant 0 there,
+// whatever the command line says).
 //   1 partner fetch (ds_bpermute)   2 mel + ln + DCT   4 LDS exchange   8 square roots   16 sample loads in the loop
 //   32 DCT only   64 second radix-16 pass
 //   128 all sample loads from clip 0 (L2-resident: removes the HBM misses)
+#if !SS_LAB
+#undef SS_ABLATE
+#endif
 #ifndef SS_ABLATE
 #define SS_ABLATE 0
 #endif
-// Experiment switch (tools/ablate.sh "-DSS_OPT=1"), results stay correct: the untangle partner by DPP row_mirror instead of
-// ds_bpermute (lanes relabelled so that lane l and 15 - l hold columns j and 16 - j).  Measured equal within noise once the mel
-// tap reads were made conflict-free (16 LDS instructions traded for 32 VALU ones): off.
-#ifndef SS_OPT
-#define SS_OPT 0
-#endif
-// SS_SPREAD (default on): LDS stores, partner fetches and sample loads leave in small groups from inside the butterflies and
-// the twiddle loop instead of as bursts behind them -- a wave issues in order, so a burst of 8..16 memory instructions holds
-// back its own VALU work while the LDS / vector-memory queue drains.  -1.0 us of 30.8 on one box (0: the round-1 bursts).
-#ifndef SS_SPREAD
-#define SS_SPREAD 1
-#endif
+// LDS stores, partner fetches and sample loads leave in small groups from inside the butterflies and the twiddle loop instead
+// of as bursts behind them -- a wave issues in order, so a burst of 8..16 memory instructions holds back its own VALU work
+// while the LDS / vector-memory queue drains (-1.0 us of 30.8 on one box against the round-1 bursts).
 
 namespace ss {
 
@@ -248,11 +244,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         stamp(4, 0ull);
     }
     const int f = lane >> 4;  // frame within the quad
-    // column of the frame's 16 x 16 point matrix owned by this lane of the DPP row.  The untangle pairs column j with
-    // column 16 - j: lanes l and 15 - l hold such a pair (1..7 <-> 15..9), lanes 0 and 15 the self-paired columns 0 and 8,
-    // so the partner arrives by DPP row_mirror instead of an LDS round trip.
-    const int l16 = lane & 15;
-    const int j = (SS_OPT & 1) ? (l16 < 8 ? l16 : (l16 == 15 ? 8 : l16 + 1)) : l16;
+    const int j = lane & 15;  // column of the frame's 16 x 16 point matrix owned by this lane of the DPP row
 
     // ---- LDS carve: per-wave regions, then the shared read-only table block, then the quad counter ----
     float *wbase = reinterpret_cast<float *>(smem) + wave * WF;
@@ -384,16 +376,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         }
 
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
-        if (SS_SPREAD && !(SS_ABLATE & 4)) {
+        if (!(SS_ABLATE & 4)) {
             // the exchange stores leave group by group while the butterfly is still computing (no 16-store burst into the LDS queue)
             fft16_emit(
                 v, [&](int r, float2 val) { zh[wbase1 + 2 * r] = val; }, [] { __builtin_amdgcn_sched_barrier(0); });
         } else {
-        fft16_reg(v);
-        if (!(SS_ABLATE & 4)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zh[wbase1 + 2 * r] = v[r];
-        }
+            fft16_reg(v);
         }
         wave_order();
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
@@ -401,7 +389,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         // SPREAD: the ten sample loads of the next quad go out one per twiddle step instead of as a burst (a wave issues in
         // order: behind a burst of vector-memory instructions its own VALU work waits); no branch surrounds them -- the last
         // iteration of a wave fetches the block's last quad again and drops it
-        constexpr bool SPREAD = SS_SPREAD && PREFETCH && EXACT && !PRE && !CENTER && !(SS_ABLATE & 16);
+        constexpr bool SPREAD = PREFETCH && EXACT && !PRE && !CENTER && !(SS_ABLATE & 16);
         const float2 *nsrc = nullptr;
         if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, t_next) + j;
         if (!SPREAD && PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
@@ -435,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // the partner of bin j + 16 r is register 15 - r of lane 16 - j: fetched with ds_bpermute
         float2 zcs[8];
-        if (SS_SPREAD && !(SS_ABLATE & 65) && !(SS_OPT & 1)) {
+        if (!(SS_ABLATE & 65)) {
             // the fetches of the upper registers go out as soon as the butterfly has produced them, group by group
             float2 uo[16];  // (the butterfly still reads its input registers while the first groups' outputs appear)
             fft16_emit(
@@ -447,14 +435,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
                 [] { __builtin_amdgcn_sched_barrier(0); });
 #pragma unroll
             for (int k = 0; k < 16; ++k) u[k] = uo[k];
-        } else {
-        if (!(SS_ABLATE & 64)) fft16_reg(u);  // u[r] = Z[j + 16 r]
-        // all 16 partner fetches go out back to back: one LDS wait
+        } else {  // stage-removal builds only
+            if (!(SS_ABLATE & 64)) fft16_reg(u);  // u[r] = Z[j + 16 r]
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (SS_OPT & 1) continue;  // fetched by DPP where it is used
-            zcs[r] = (SS_ABLATE & 1) ? u[15 - r] : make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
-        }
+            for (int r = 0; r < 8; ++r) zcs[r] = (SS_ABLATE & 1) ? u[15 - r] : make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         }
         float esum = 0.f;
         // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
@@ -469,15 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         for (int r = 0; r < 8; ++r) {
             const float2 zk = u[r];
             // lane 0 pairs with itself: Z[256 - 16 r] = own register (16 - r) & 15
-            float2 zc;
-            if (SS_OPT & 1) {
-                // columns 0 and 8 pair with themselves: Z[256 - 16 r] = register (16 - r) & 15, Z[248 - 16 r] = register 15 - r
-                const float2 own = j == 0 ? u[(16 - r) & 15] : u[15 - r];
-                const float2 mir = make_float2(dpp<0x140>(u[15 - r].x), dpp<0x140>(u[15 - r].y));  // row_mirror
-                zc = (j == 0 || j == 8) ? own : mir;
-            } else {
-                zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
-            }
+            const float2 zc = j == 0 ? u[(16 - r) & 15] : zcs[r];
             const float2 w = TABREG ? twn[r] : s_twn[r * 16 + j];
             const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
             const float2 d = make_float2(zk.x - zc.x, zk.y + zc.y);
@@ -713,8 +689,13 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
 #undef SS_LV
         }
     }
-    static const char *res_env = std::getenv("SS_RES");  // A/B knob: register-resident tables (bit 0 cosines, bit 1 twiddles)
-    int res = res_env ? std::atoi(res_env) : 6;  // 2: twiddles resident (140 VGPRs, 0.7 us faster than 0; 3 spills); 6: + symmetric DCT (165 VGPRs, another 1.2 %)
+    // register-resident tables (bit 0 cosines, bit 1 twiddles, bit 2 symmetric DCT).  2: twiddles resident (140 VGPRs, 0.7 us
+    // faster than 0; 3 spills); 6: + symmetric DCT (165 VGPRs, another 1.2 %)
+    int res = 6;
+#if SS_LAB
+    static const char *res_env = std::getenv("SS_RES");  // A/B knob (lab build)
+    if (res_env) res = std::atoi(res_env);
+#endif
     if (a.flen == 320 && !pow2 && b421 && a.n_filters <= 40) {
         const int front = (a.win_floats > 0 ? 1 : 0) | (a.preemph != 0.0f ? 2 : 0);
         if (a.out_mfe == 2) {
@@ -772,9 +753,11 @@ hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cu
     // mfe output, frame window and pre-emphasis exist for the default-bank build only (the librosa-style builds take a window)
     if (!(a.fullp || a.center) && (a.out_mfe || a.win_floats > 0 || a.preemph != 0.0f) && !mfcc_c256_has_mfe(a)) return hipErrorInvalidValue;
     // 12 waves per CU (3 per SIMD, <= 168 VGPRs, 138 KB of LDS): measured equal to 14 and 16 and 8 % faster than 8
-    static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments
+#if SS_LAB
+    static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments (lab build)
     if (w && std::atoi(w) == 8 && !a.fullp && !a.center) return launch_w<8>(a, stream, num_cus, info);
     if (w && std::atoi(w) == 16 && !a.fullp && !a.center) return launch_w<16>(a, stream, num_cus, info);
+#endif
     return launch_w<12>(a, stream, num_cus, info);
 }
 

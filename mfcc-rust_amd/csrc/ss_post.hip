@@ -423,7 +423,7 @@ int ss_power_to_db_device(const float *d_s, size_t n, float ref, float amin, flo
     if (n == 0) return SS_OK;
     if (!d_s || !d_out) return ss::fail(SS_ERR_ARG, "null buffer");
     if (!(amin > 0.0f)) return ss::fail(SS_ERR_ARG, "amin must be strictly positive");  // librosa.power_to_db raises the same
-    if (!(ref > 0.0f) && ref != 0.0f) return ss::fail(SS_ERR_ARG, "ref must be non-negative");
+    if (ref != ref) return ss::fail(SS_ERR_ARG, "ref must not be NaN");  // |ref| is used, as in librosa (np.abs(ref))
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float ref_db = 10.0f * std::log10(std::max(amin, std::fabs(ref)));
     int *d_max = nullptr;

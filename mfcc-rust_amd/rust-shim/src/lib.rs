@@ -5,6 +5,8 @@
 //!   speechsauce::feature::mfe(ArrayView1<f32>, &SpeechConfig) -> (Array2, Array1)       (feature.rs:200)
 //!   speechsauce::feature::mel_spectrogram1 / mel_spectrogram2                           (feature.rs:151,163)
 //!   speechsauce::processing::preemphasis(Array1<f32>, isize, f32) -> Array1<f32>        (processing.rs:31)
+//!   speechsauce::processing::stack_frames / power_spectrum(frames, fft_points)          (processing.rs:65,179)
+//!   speechsauce::functions::stft1 / stft2 -> Array2 / Array3<Complex32>                 (functions.rs:199,86)
 //!   speechsauce::config::{SpeechConfig, SpeechConfigBuilder}                            (config.rs:10-190)
 //! The host side here owns what the north-star assigns to Rust: ndarray I/O (contiguity, shapes,
 //! allocation of the outputs) and the framing parameters; every numeric step runs in the HIP kernels
@@ -15,6 +17,7 @@
 //! This file is shipped uncompiled (the build image has no Rust toolchain).
 
 use ndarray::{Array1, Array2, Array3, ArrayView1, ArrayView2};
+use num_complex::Complex32;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_long, c_void};
 
@@ -63,6 +66,12 @@ extern "C" {
     fn ss_mfcc_batch_device(cfg: *const SsConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
                             stream: *mut c_void) -> c_int;
     fn ss_preemphasis(x: *const f32, n: usize, shift: c_long, cof: f32, y: *mut f32) -> c_int;
+    fn ss_frame_sizes(p: *const SsParams, frame_len: *mut usize, frame_step: *mut usize) -> c_int;
+    fn ss_stft(cfg: *const SsConfig, x: *const f32, channels: usize, n: usize, out: *mut f32) -> c_int;
+    fn ss_stack_frames(cfg: *const SsConfig, x: *const f32, n: usize, frames: *mut f32) -> c_int;
+    fn ss_power_spectrum_frames(cfg: *const SsConfig, frames: *const f32, rows: usize, cols: usize, p_out: *mut f32) -> c_int;
+    fn ss_power_spectrum(cfg: *const SsConfig, x: *const f32, n: usize, p_out: *mut f32) -> c_int;
+    fn ss_config_device_status(cfg: *const SsConfig) -> c_int;
     fn ss_cmvn(vec: *const f32, rows: usize, cols: usize, variance_normalization: c_int, out: *mut f32) -> c_int;
     fn ss_cmvnw(vec: *const f32, rows: usize, cols: usize, win_size: usize, variance_normalization: c_int, out: *mut f32) -> c_int;
     fn ss_derivative_extraction(feat: *const f32, rows: usize, cols: usize, delta_windows: usize, out: *mut f32) -> c_int;
@@ -70,6 +79,8 @@ extern "C" {
     fn ss_shard_bounds(n_items: usize, world: c_int, rank: c_int, lo: *mut usize, hi: *mut usize) -> c_int;
     fn ss_all_gather_features(nccl_comm: *mut c_void, d_block: *const f32, elems_per_rank: usize, d_out: *mut f32,
                               stream: *mut c_void) -> c_int;
+    fn ss_gather_features(nccl_comm: *mut c_void, d_block: *const f32, elems_per_rank: usize, d_out: *mut f32, root: c_int,
+                          rank: c_int, world: c_int, stream: *mut c_void) -> c_int;
     fn ss_last_error_string() -> *const c_char;
 }
 
@@ -88,6 +99,17 @@ pub fn shard_bounds(n_items: usize, world: usize, rank: usize) -> (usize, usize)
 pub unsafe fn all_gather_features(comm: *mut c_void, d_block: *const f32, elems_per_rank: usize, d_out: *mut f32,
                                   stream: *mut c_void) -> Result<(), Error> {
     check(ss_all_gather_features(comm, d_block, elems_per_rank, d_out, stream))
+}
+
+/// RCCL gather to `root` (the north-star's collective): the root receives `[world x elems_per_rank]` in rank order, one
+/// direct xGMI transfer per peer; the other ranks only send and may pass a null `d_out`.
+///
+/// # Safety
+/// As `all_gather_features`; `comm` must come from the RCCL library this crate's C side resolves (see speechsauce_amd.h).
+#[allow(clippy::too_many_arguments)]
+pub unsafe fn gather_features(comm: *mut c_void, d_block: *const f32, elems_per_rank: usize, d_out: *mut f32, root: usize,
+                              rank: usize, world: usize, stream: *mut c_void) -> Result<(), Error> {
+    check(ss_gather_features(comm, d_block, elems_per_rank, d_out, root as c_int, rank as c_int, world as c_int, stream))
 }
 
 #[derive(Debug)]
@@ -270,6 +292,66 @@ pub unsafe fn mfcc_batch_device(cfg: &SpeechConfig, d_x: *const f32, batch: usiz
                                 stream: *mut c_void) -> Result<(), Error> {
     check(ss_mfcc_batch_device(cfg.handle, d_x, batch, n, ld, d_out, stream))
 }
+
+/// functions.rs:86-123: `[channels, samples]` -> `Array3<Complex32>` `[channels, rows, freq_size]`
+pub fn try_stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<Complex32>, Error> {
+    let owned = input.as_standard_layout();
+    let (ch, n) = owned.dim();
+    let (mut rows, mut real) = (0usize, 0usize);
+    check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut real) })?;
+    let mut out = Array3::<Complex32>::zeros((ch, rows, cfg.freq_size));
+    // Complex32 is #[repr(C)] { re: f32, im: f32 }: the interleaved block the ABI writes
+    check(unsafe { ss_stft(cfg.handle, owned.as_ptr(), ch, n, out.as_mut_ptr() as *mut f32) })?;
+    Ok(out)
+}
+pub fn stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Array3<Complex32> { try_stft2(input, cfg).expect("stft2") }
+
+/// functions.rs:199-233 (one channel): `Array2<Complex32>` `[rows, freq_size]`
+pub fn stft1(input: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<Complex32> {
+    let x = contiguous(input);
+    let v = ArrayView2::from_shape((1, x.len()), &x).expect("shape");
+    let out = stft2(v, cfg);
+    let (_, r, f) = out.dim();
+    out.into_shape((r, f)).expect("shape")
+}
+
+/// processing.rs:65-129.  `sample_rate`, `frame_length`, `frame_stride`, the `filter` argument (the `mfcc_window` switch) and
+/// `zero_padding` (`framing = 3`) are the config's: `stack_frames(signal, &cfg)` replaces
+/// `stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding)`.
+pub fn try_stack_frames(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+    let x = contiguous(signal);
+    let (mut t, mut flen, mut step) = (0usize, 0usize, 0usize);
+    check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
+    check(unsafe { ss_frame_sizes(&cfg.params, &mut flen, &mut step) })?;
+    let mut out = Array2::<f32>::zeros((t, flen));
+    check(unsafe { ss_stack_frames(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
+    Ok(out)
+}
+pub fn stack_frames(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_stack_frames(signal, cfg).expect("stack_frames") }
+
+/// processing.rs:179-181: `power_spectrum(frames, fft_points)`; `fft_points` must be the config's (the reference takes it
+/// as a loose argument, its callers pass `speech_config.fft_points`, feature.rs:211)
+pub fn try_power_spectrum(frames: Array2<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+    let x = frames.as_standard_layout();
+    let (rows, cols) = x.dim();
+    let mut out = Array2::<f32>::zeros((rows, cfg.freq_size));
+    check(unsafe { ss_power_spectrum_frames(cfg.handle, x.as_ptr(), rows, cols, out.as_mut_ptr()) })?;
+    Ok(out)
+}
+pub fn power_spectrum(frames: Array2<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_power_spectrum(frames, cfg).expect("power_spectrum") }
+
+/// stack_frames + power_spectrum fused, as mfe uses them (feature.rs:203-214): `[frames, freq_size]`
+pub fn try_power_spectrum_of_signal(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+    let x = contiguous(signal);
+    let mut t = 0usize;
+    check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
+    let mut out = Array2::<f32>::zeros((t, cfg.freq_size));
+    check(unsafe { ss_power_spectrum(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
+    Ok(out)
+}
+
+/// Status of the asynchronous launches made on `cfg` (`Err` with status 6 after a device-side protocol error; cleared by the call).
+pub fn device_status(cfg: &SpeechConfig) -> Result<(), Error> { check(unsafe { ss_config_device_status(cfg.handle) }) }
 
 /// processing.rs:31-53
 pub fn preemphasis(signal: Array1<f32>, shift: isize, cof: f32) -> Array1<f32> {

@@ -21,8 +21,8 @@ from . import _lib
 from ._lib import SpeechSauceError, SsParams, make_params  # noqa: F401
 
 __all__ = ["mfcc", "mel_spectrogram", "preemphasis", "cmvn", "cmvnw", "derivative_extraction", "extract_derivative_feature",
-           "mfe", "mfcc_batch", "mfe_batch", "lmfe", "lmfe_batch", "power_to_db", "SpeechConfig",
-           "SpeechSauceError"]
+           "mfe", "mfcc_batch", "mfe_batch", "lmfe", "lmfe_batch", "power_to_db", "stft", "stack_frames", "power_spectrum",
+           "power_spectrum_of_signal", "SpeechConfig", "SpeechSauceError"]
 
 
 def _is_torch(x) -> bool:
@@ -60,6 +60,12 @@ class SpeechConfig:
     @property
     def handle(self) -> C.c_void_p:
         return self._h
+
+    def device_status(self) -> None:
+        """Raises SpeechSauceError (SS_ERR_DEVICE) if a kernel of an asynchronous launch on this config has reported a
+        device-side protocol error since the last call.  Meaningful after the stream has been synchronised; the numpy
+        (host-pointer) calls check it themselves."""
+        _lib.check(_lib.lib().ss_config_device_status(self._h))
 
 
 def _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
@@ -325,6 +331,127 @@ def mel_spectrogram(signal, sampling_frequency, frame_length=0.020, frame_stride
     config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
                   low_frequency, high_frequency, dc_elimination, switches, sig)
     return _internal_mel_spectrogram(sig, config)
+
+
+# ---- stage outputs the reference exposes as pub fns: processing::{stack_frames, power_spectrum}, functions::{stft1, stft2} ----
+
+def stft(signal, sampling_frequency, frame_length=0.020, fft_length=512, **switches):
+    """``speechsauce::functions::stft1`` (1-D signal, functions.rs:199-233) / ``stft2`` (2-D [C, L], functions.rs:86-123):
+    complex64 spectrum rows ``(..., rows, fft_length // 2 + 1)`` of the Vorbis-windowed chunks, scaled by wnorm, from zero
+    state per clip.  The hop is ``frame_length * sampling_frequency`` samples, the window ``fft_length`` samples
+    (config.rs:154); ``fft_length >= 2 * hop`` as in ``mel_spectrogram``.  numpy in -> numpy out; a ROCm tensor stays on
+    the device (torch.complex64 view of the interleaved block)."""
+    sig = _require_f32(signal, (1, 2), "stft")
+    config = _cfg(sampling_frequency, frame_length, 0.01, 13, 40, fft_length, 0, None, True, switches, sig)
+    lib = _lib.lib()
+    one_d = sig.ndim == 1
+    sig2 = sig[None, :] if one_d else sig
+    ch, L = sig2.shape
+    R, _ = config.stft_rows(L)
+    F = config.params.fft_points // 2 + 1
+    if _is_torch(sig2):
+        import torch
+
+        x = sig2 if sig2.stride(1) == 1 else sig2.contiguous()
+        out = torch.empty((ch, R, F, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_stft_device(config.handle, x.data_ptr(), ch, L, x.stride(0) if ch > 1 else L, out.data_ptr(), _stream_ptr()))
+        z = torch.view_as_complex(out)
+    else:
+        x = np.ascontiguousarray(sig2)
+        out = np.empty((ch, R, F, 2), dtype=np.float32)
+        _lib.check(lib.ss_stft(config.handle, x.ctypes.data, ch, L, out.ctypes.data))
+        z = out.view(np.complex64)[..., 0]
+    return z[0] if one_d else z
+
+
+def stack_frames(signal, sampling_frequency, frame_length=0.020, frame_stride=0.020, zero_padding=False, **switches):
+    """``speechsauce::processing::stack_frames`` (processing.rs:65-129): (num_frames, frame_len) frames of a 1-D signal.
+    ``zero_padding=True`` is the reference's flag (ceil instead of floor frames, the tail reading appended zeros);
+    ``mfcc_window=`` plays the role of its ``filter`` argument; ``framing="literal"`` gives the copy exactly as written."""
+    sig = _require_f32(signal, (1,), "stack_frames")
+    if zero_padding:
+        switches = dict(switches, framing="padded")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, 13, 40, 512, 0, None, True, switches, sig)
+    lib = _lib.lib()
+    L = sig.shape[0]
+    T = config.num_frames(L)
+    fl, st = C.c_size_t(), C.c_size_t()
+    _lib.check(lib.ss_frame_sizes(C.byref(config.params), C.byref(fl), C.byref(st)))
+    if _is_torch(sig):
+        import torch
+
+        x = sig.contiguous()
+        out = torch.empty((T, fl.value), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_stack_frames_device(config.handle, x.data_ptr(), 1, L, L, out.data_ptr(), _stream_ptr()))
+        return out
+    x = np.ascontiguousarray(sig)
+    out = np.empty((T, fl.value), dtype=np.float32)
+    _lib.check(lib.ss_stack_frames(config.handle, x.ctypes.data, L, out.ctypes.data))
+    return out
+
+
+def power_spectrum(frames, fft_points=512):
+    """``speechsauce::processing::power_spectrum(frames, fft_points)`` (processing.rs:179-181): |rfft(row)| / fft_points of
+    every row of a 2-D float32 frames matrix (rows shorter than fft_points are zero-padded, processing.rs:147-156) ->
+    (num_frames, fft_points // 2 + 1).  The name is the reference's; the values are magnitudes, as written there."""
+    if _is_torch(frames):
+        import torch
+
+        if frames.dtype != torch.float32:
+            raise TypeError("power_spectrum: frames must be float32")
+        if frames.dim() != 2:
+            raise ValueError("power_spectrum: frames must be 2d")
+        fr = frames if frames.is_cuda else frames.detach().numpy()
+    else:
+        fr = np.asarray(frames)
+        if fr.dtype != np.float32:
+            raise TypeError(f"power_spectrum: frames must be float32, got {fr.dtype}")
+        if fr.ndim != 2:
+            raise ValueError("power_spectrum: frames must be 2d")
+    # only fft_points of the config matters here; the other fields are the defaults at a rate that validates with it
+    config = _cfg(16000, 0.020, 0.01, 13, 40, int(fft_points), 0, None, True, {}, fr)
+    lib = _lib.lib()
+    rows, cols = fr.shape
+    F = int(fft_points) // 2 + 1
+    if _is_torch(fr):
+        import torch
+
+        x = fr if fr.stride(1) == 1 else fr.contiguous()
+        out = torch.empty((rows, F), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_power_spectrum_frames_device(config.handle, x.data_ptr(), rows, cols, x.stride(0) if rows > 1 else cols,
+                                                           out.data_ptr(), _stream_ptr()))
+        return out
+    x = np.ascontiguousarray(fr)
+    out = np.empty((rows, F), dtype=np.float32)
+    _lib.check(lib.ss_power_spectrum_frames(config.handle, x.ctypes.data, rows, cols, out.ctypes.data))
+    return out
+
+
+def power_spectrum_of_signal(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, fft_length=512, **switches):
+    """stack_frames + power_spectrum fused, as mfe uses them (feature.rs:203-214): 1-D -> (T, F), 2-D [B, L] -> (B, T, F)."""
+    sig = _require_f32(signal, (1, 2), "power_spectrum_of_signal")
+    config = _cfg(sampling_frequency, frame_length, frame_stride, 13, 40, fft_length, 0, None, True, switches, sig)
+    lib = _lib.lib()
+    one_d = sig.ndim == 1
+    sig2 = sig[None, :] if one_d else sig
+    B, L = sig2.shape
+    T = config.num_frames(L)
+    F = config.params.fft_points // 2 + 1
+    if _is_torch(sig2):
+        import torch
+
+        x = sig2 if sig2.stride(1) == 1 else sig2.contiguous()
+        out = torch.empty((B, T, F), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ss_power_spectrum_batch_device(config.handle, x.data_ptr(), B, L, x.stride(0) if B > 1 else L, out.data_ptr(), _stream_ptr()))
+    else:
+        x = np.ascontiguousarray(sig2)
+        out = np.empty((B, T, F), dtype=np.float32)
+        _lib.check(lib.ss_power_spectrum_batch(config.handle, x.ctypes.data, B, L, L, out.ctypes.data))
+    return out[0] if one_d else out
 
 
 def preemphasis(signal, shift=1, cof=0.98):

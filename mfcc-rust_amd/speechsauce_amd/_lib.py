@@ -14,7 +14,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 # SS_LIB_PATH overrides the in-tree build (A/B runs of two builds in one process tree)
 LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
 
-SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED = range(6)
+SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED, SS_ERR_DEVICE = range(7)
 FRAMING = {"contract": 0, "literal": 1, "center": 2, "padded": 3}
 MEL_SCALE = {"reference": 0, "slaney": 1, "htk": 2}
 MEL_NORM = {"none": 0, "slaney": 1}
@@ -62,7 +62,7 @@ class SpeechSauceError(RuntimeError):
 
 _lib = None
 
-# name -> (restype, argtypes); every symbol include/speechsauce_amd.h declares
+# name -> (restype, argtypes); every symbol include/speechsauce_amd.h and include/speechsauce_amd_debug.h declare
 _P = C.POINTER
 _cfg = C.c_void_p
 _fp = C.c_void_p  # float* passed as an address (numpy .ctypes.data or a device pointer)
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ss_config_create": (C.c_int, [_P(SsParams), _P(_cfg)]),
     "ss_config_destroy": (None, [_cfg]),
     "ss_config_params": (C.c_int, [_cfg, _P(SsParams)]),
+    "ss_config_device_status": (C.c_int, [_cfg]),
     "ss_params_validate": (C.c_int, [_P(SsParams)]),
     "ss_frame_sizes": (C.c_int, [_P(SsParams), _P(C.c_size_t), _P(C.c_size_t)]),
     "ss_num_frames": (C.c_int, [_P(SsParams), C.c_size_t, _P(C.c_size_t)]),
@@ -82,6 +83,11 @@ PROTOTYPES = {
     "ss_mfe": (C.c_int, [_cfg, _fp, C.c_size_t, _fp, _fp]),
     "ss_mel_spectrogram": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, _fp]),
     "ss_preemphasis": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp]),
+    "ss_stft": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, _fp]),
+    "ss_stack_frames": (C.c_int, [_cfg, _fp, C.c_size_t, _fp]),
+    "ss_power_spectrum_frames": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, _fp]),
+    "ss_power_spectrum": (C.c_int, [_cfg, _fp, C.c_size_t, _fp]),
+    "ss_power_spectrum_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp]),
     "ss_mfcc_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp]),
     "ss_mfe_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
     "ss_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
@@ -96,7 +102,11 @@ PROTOTYPES = {
     "ss_power_to_db_device": (C.c_int, [_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp, C.c_void_p]),
     "ss_shard_bounds": (C.c_int, [C.c_size_t, C.c_int, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
     "ss_all_gather_features": (C.c_int, [C.c_void_p, _fp, C.c_size_t, _fp, C.c_void_p]),
+    "ss_gather_features": (C.c_int, [C.c_void_p, _fp, C.c_size_t, _fp, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ss_rccl_library": (C.c_int, [C.c_char_p]),
     "ss_power_spectrum_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_power_spectrum_frames_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
+    "ss_stack_frames_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_stft_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_cmvn": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_int, _fp]),
     "ss_cmvn_batch_device": (C.c_int, [_fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _fp, C.c_void_p]),
@@ -113,6 +123,9 @@ PROTOTYPES = {
     "ss_time_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_debug_poison_lds": (C.c_int, [C.c_void_p]),
     "ss_debug_stamp_buffer": (C.c_int, [C.c_void_p]),
+    "ss_debug_force_generic": (C.c_int, [C.c_int]),
+    "ss_debug_mel_tile": (C.c_int, [C.c_int]),
+    "ss_debug_tile_fault": (C.c_int, [C.c_int]),
     "ss_status_string": (C.c_char_p, [C.c_int]),
     "ss_last_error_string": (C.c_char_p, []),
     "ss_abi_version": (C.c_int, []),
@@ -139,7 +152,7 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
-    if handle.ss_abi_version() != 3:
+    if handle.ss_abi_version() != 4:
         raise ImportError("libspeechsauce_amd.so ABI version mismatch")
     _lib = handle
     return _lib

@@ -169,6 +169,23 @@ def power_spectrum(p, x):
     return out
 
 
+def stack_frames(p, x):
+    x = _f32(x)
+    T = num_frames(p, x.size)
+    flen, _ = frame_sizes(p)
+    out = np.empty((T, flen), dtype=np.float64)
+    _chk(lib().orc_stack_frames(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(out, C.c_double)))
+    return out
+
+
+def power_spectrum_frames(frames, fft_points):
+    f = np.ascontiguousarray(frames, dtype=np.float32)
+    out = np.empty((f.shape[0], fft_points // 2 + 1), dtype=np.float64)
+    _chk(lib().orc_power_spectrum_frames(_ptr(f, C.c_float), C.c_size_t(f.shape[0]), C.c_size_t(f.shape[1]), C.c_size_t(fft_points),
+                                         _ptr(out, C.c_double)))
+    return out
+
+
 def mfe(p, x):
     x = _f32(x)
     T = num_frames(p, x.size)

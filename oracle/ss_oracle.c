@@ -498,6 +498,69 @@ int orc_power_spectrum(const orc_params *p, const float *x, size_t n, double *P)
     return ORC_OK;
 }
 
+/* stack_frames (processing.rs:65-129) on its own: frames [T x flen], same framing switch as orc_power_spectrum.  The
+ * `filter` argument of the reference is the mfcc_window switch (frames * window, processing.rs:122-126).  Pre-emphasis is
+ * not part of stack_frames and is ignored here. */
+int orc_stack_frames(const orc_params *p, const float *x, size_t n, double *frames)
+{
+    size_t flen, step, T;
+    int rc = orc_frame_sizes(p, &flen, &step);
+    if (rc) return rc;
+    rc = orc_num_frames(p, n, &T);
+    if (rc) return rc;
+    float *win = NULL;
+    if (p->mfcc_window != ORC_WINDOW_RECT) {
+        win = (float *)malloc(flen * sizeof(float));
+        if (p->mfcc_window == ORC_WINDOW_HANN) orc_hann_window(flen, win);
+        else orc_vorbis_window(flen, win);
+    }
+    for (size_t t = 0; t < T; ++t) {
+        double *row = frames + t * flen;
+        for (size_t i = 0; i < flen; ++i) row[i] = 0.0;
+        if (p->framing == ORC_FRAMING_LITERAL) {
+            /* processing.rs:110-120 as written (see orc_power_spectrum) */
+            if (T <= 2)
+                for (size_t i = 0; i < (flen & ~(size_t)1); ++i) row[i] = (double)x[i];
+        } else if (p->framing == ORC_FRAMING_CENTER) {
+            for (size_t i = 0; i < flen; ++i) {
+                long long pos = (long long)(t * step + i) - (long long)(flen / 2);
+                if (pos < 0 || pos >= (long long)n) {
+                    if (p->pad_mode != ORC_PAD_REFLECT) continue;
+                    pos = pos < 0 ? -pos : 2 * ((long long)n - 1) - pos;
+                }
+                row[i] = (double)x[pos];
+            }
+        } else {
+            /* contract framing frames[t, i] = x[t*step + i]; ORC_FRAMING_PADDED reads the appended zeros (processing.rs:93-96) */
+            for (size_t i = 0; i < flen; ++i) row[i] = t * step + i < n ? (double)x[t * step + i] : 0.0;
+        }
+        if (win) for (size_t i = 0; i < flen; ++i) row[i] *= (double)win[i];
+    }
+    free(win);
+    return ORC_OK;
+}
+
+/* power_spectrum(frames: Array2<f32>, fft_points) (processing.rs:179-181) -> fft_spectrum (:143-171): rows shorter than
+ * fft_points are zero-padded on the right (:147-156), R2C FFT of every row, sqrt(re^2 + im^2), times (1 / fft_points as f32). */
+int orc_power_spectrum_frames(const float *frames, size_t rows, size_t cols, size_t fft_points, double *P)
+{
+    if (!frames || !P || cols == 0 || fft_points < 2) return ORC_ERR_ARG;
+    if (cols > fft_points) return ORC_ERR_BAD_CONFIG; /* ndfft_r2c size assert */
+    const size_t N = fft_points, F = N / 2 + 1;
+    double *buf = (double *)calloc(N, sizeof(double));
+    double *re = (double *)malloc(F * sizeof(double)), *im = (double *)malloc(F * sizeof(double));
+    double *wre = (double *)malloc(N * sizeof(double)), *wim = (double *)malloc(N * sizeof(double));
+    const double inv_n = (double)(1.0f / (float)N);
+    for (size_t t = 0; t < rows; ++t) {
+        memset(buf, 0, N * sizeof(double));
+        for (size_t i = 0; i < cols; ++i) buf[i] = (double)frames[t * cols + i];
+        rfft_f64(buf, N, re, im, wre, wim);
+        for (size_t k = 0; k < F; ++k) P[t * F + k] = inv_n * sqrt(re[k] * re[k] + im[k] * im[k]);
+    }
+    free(buf); free(re); free(im); free(wre); free(wim);
+    return ORC_OK;
+}
+
 /* functions.rs:66-71: exact == 0.0 -> f32::EPSILON */
 static double zero_handling(double v) { return v == 0.0 ? (double)ORC_EPS_F32 : v; }
 

@@ -95,6 +95,8 @@ int  orc_filterbank(const orc_params *p, float *fb /* M x F */, int32_t *idx /* 
 
 /* stages, f64 accumulation on the reference's f32 constants */
 int orc_power_spectrum(const orc_params *p, const float *x, size_t n, double *P /* T x F */);
+int orc_stack_frames(const orc_params *p, const float *x, size_t n, double *frames /* T x flen */);
+int orc_power_spectrum_frames(const float *frames, size_t rows, size_t cols, size_t fft_points, double *P /* rows x F */);
 int orc_mfe(const orc_params *p, const float *x, size_t n, double *feat /* T x M */, double *energy /* T */);
 int orc_mfcc(const orc_params *p, const float *x, size_t n, double *out /* T x C */);
 int orc_stft(const orc_params *p, const float *x, size_t channels, size_t n,

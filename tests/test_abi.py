@@ -23,10 +23,15 @@ def _has_gpu():
         return False
 
 
-def _declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", text)))
+DEBUG_HEADER = os.path.join(ROOT, "include", "speechsauce_amd_debug.h")
+
+
+def _declared_symbols(headers=(HEADER, DEBUG_HEADER)):
+    names = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported(sslib):
@@ -37,7 +42,26 @@ def test_every_declared_symbol_is_exported(sslib):
     for n in names:
         assert hasattr(sslib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in the Python front"
-    assert sslib.ss_abi_version() == 3
+    assert sslib.ss_abi_version() == 4
+
+
+def test_the_product_library_exports_only_the_documented_abi():
+    """`nm -D` of the shipped library: every defined dynamic symbol is an ss_* entry point declared in one of the two
+    headers -- no C++ internals, no lab switches -- and no environment knob name is compiled in."""
+    import subprocess
+
+    from speechsauce_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    declared = set(_declared_symbols())
+    assert exported, "no dynamic symbols?"
+    stray = [n for n in exported if n not in declared]
+    assert not stray, f"exported but undocumented: {stray}"
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for knob in (b"SS_FORCE_GENERIC", b"SS_RES", b"SS_WAVES", b"SS_MEL_WAVES", b"SS_MEL_TILE", b"SS_HOST_CHUNK_MB", b"SS_HOST_SMALL_KB",
+                 b"SS_DEBUG_TIMES", b"SS_DEBUG_ROWS"):
+        assert knob + b"\0" not in blob, f"the product build still reads {knob.decode()}"
 
 
 def test_params_struct_matches_header(sslib):
@@ -124,7 +148,7 @@ def test_validation_mirrors_reference_panics(sslib):
         assert sslib.ss_last_error_string() != b""
     assert sslib.ss_params_validate(C.byref(make_params())) == 0
     assert sslib.ss_params_validate(C.byref(make_params(fft_points=400))) == 0  # 25 ms at 16 kHz: chirp-z
-    for s in range(6):
+    for s in range(7):
         assert sslib.ss_status_string(s) not in (b"", b"unknown status")
 
 

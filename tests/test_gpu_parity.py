@@ -1158,28 +1158,19 @@ def test_mfcc_256_kernel(ss, oracle, sslib):
     assert _rel(ss.mfcc(x1[1:], sr, fft_length=256), oracle.mfcc(p, x1[1:])) <= RTOL
 
 
-def test_kernel_variants_agree(ss):
-    """The generic kernel and the production kernel compute the same MFCCs (separate processes: the variant is chosen once
-    per process from the environment)."""
-    import subprocess
-    import sys
+def test_kernel_variants_agree(ss, sslib):
+    """The generic kernel and the production kernel compute the same MFCCs (ss_debug_force_generic, the test aid of
+    include/speechsauce_amd_debug.h, routes every configuration to ss_front_generic)."""
+    import torch
 
-    code = ("import sys, numpy as np; sys.path.insert(0, 'mfcc-rust_amd'); import speechsauce_amd as ss;"
-            "x=(np.random.default_rng(5).standard_normal((37,16000))*0.1).astype(np.float32);"
-            "import torch; o=ss.mfcc_batch(torch.from_numpy(x).cuda(),16000).cpu().numpy();"
-            "np.save(sys.argv[1], o); print(ss._lib.lib().ss_last_kernel_name().decode())")
-    import os
-    import tempfile
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    x = torch.from_numpy((np.random.default_rng(5).standard_normal((37, 16000)) * 0.1).astype(np.float32)).cuda()
     outs, names = [], []
-    with tempfile.TemporaryDirectory() as td:
-        for env in ({}, {"SS_FORCE_GENERIC": "1"}):
-            path = os.path.join(td, f"o{len(outs)}.npy")
-            r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env={**os.environ, **env},
-                               capture_output=True, text=True, check=True)
-            names.append(r.stdout.strip().splitlines()[-1])
-            outs.append(np.load(path))
+    try:
+        for force in (0, 1):
+            sslib.ss_debug_force_generic(force)
+            outs.append(ss.mfcc_batch(x, 16000).cpu().numpy())
+            names.append(sslib.ss_last_kernel_name().decode())
+    finally:
+        sslib.ss_debug_force_generic(0)
     assert names[0].startswith("ss_mfcc_c256<") and names[1].startswith("ss_front_generic")
-    for o in outs[1:]:
-        assert _rel(o, outs[0]) <= 2e-5
+    assert _rel(outs[1], outs[0]) <= 2e-5

@@ -105,6 +105,8 @@ def test_power_to_db(ss, top_db):
     np.testing.assert_array_equal(host, got)
     got2 = ss.power_to_db(S, ref=float(S.max()), amin=1e-6, top_db=top_db)
     np.testing.assert_allclose(got2, _power_to_db_ref(S, ref=float(S.max()), amin=1e-6, top_db=top_db), rtol=0, atol=2e-4)
+    # |ref| is what counts (librosa: np.abs(ref)); a negative reference is legal
+    np.testing.assert_array_equal(ss.power_to_db(S, ref=-float(S.max()), amin=1e-6, top_db=top_db), got2)
     with pytest.raises(ss.SpeechSauceError):
         ss.power_to_db(S, amin=0.0)
 
