@@ -1,28 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native speechsauce hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg4|cfg5] [--gather]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg4|cfg5] [--gather-mode root|all|none]
 
 Metric (BASELINE.json): frames/sec (+ real-time factor) for 16 kHz MFCC n_fft=512 at 1/2/4/8 MI355X.
 A "step" is one pass of the hot path over one batch of synthetic clips that already sit in HBM:
 cfg2 = 1024 x 1 s clips @16 kHz, SpeechConfig defaults (n_fft 512, hop 160, 40 mels, 13 ceps),
 one fused kernel launch per step.  To keep the 256 MiB Infinity Cache from serving the input,
-steps rotate over enough distinct input batches to exceed it (8 x 65.5 MB for cfg2).
+steps rotate over enough distinct input batches to exceed it (5 x 65.5 MB for cfg2).
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  `python bench.py --gpus N`
 starts the N ranks itself (fresh child processes, spawned before this process touches the GPU); under
 torch.distributed.run it uses the ranks it is given.  Clips are independent, so every rank processes its
-own batch of the same size (weak scaling) with no collective inside the path; the north-star's "RCCL
-gather over xGMI of the final [n_frames x n_mfcc] blocks" is part of every N > 1 step: the blocks of
---gather-every consecutive steps form one bucket that is all-gathered on a side stream while the next
-steps' kernels run (--no-gather switches it off).  cfg4 (the 100 h corpus, 360 000 clips) is the one
-strong-scaling workload: the corpus is split into contiguous clip shards
-(speechsauce_amd.distributed.shard_bounds), one per rank, one launch per shard per step.
+own batch of the same size (weak scaling) with no collective inside the path.  The north-star's "RCCL
+gather over xGMI of the final [n_frames x n_mfcc] blocks" follows the path: the blocks of --gather-every
+consecutive steps form one bucket that is gathered to rank 0 (--gather-mode root, the default: grouped
+ncclSend / ncclRecv, one direct link per peer) or to every rank (all: ncclAllGather) on a side stream while
+the next steps' kernels run.  An N > 1 run times TWO regions of K steps back to back, each between
+barrier + synchronize pairs: the path alone, then the path with the collective.  `value` is the second
+(the whole job the north-star describes), `value_path_only` the first; `gather` carries the collective's
+own time and the per-link rate it reached, so the line says how much of the step is interconnect.
+cfg4 (the 100 h corpus, 360 000 clips) is the one strong-scaling workload: the corpus is split into
+contiguous clip shards (speechsauce_amd.distributed.shard_bounds), one launch per shard per step.
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (4 B per input
 sample + 4 B per output element) / average launch duration measured with HIP events
-on the launch stream over the timed region.  `cpu_baseline` = the oracle's reference-shaped
-single-thread f32 port (oracle/ss_oracle.c, "port") timed on this host on a bounded sample.
+on the launch stream over the timed (path-only when N > 1) region.  `cpu_baseline` = the oracle's
+reference-shaped single-thread f32 port (oracle/ss_oracle.c, "port") timed on this host on a bounded sample.
 """
 from __future__ import annotations
 
@@ -89,6 +93,7 @@ def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
         "unit": "frames/s",
         "cores": 1,
         "kind": "port",
+        "note": "lower bound on the Rust crate: a textbook radix-2 FFT with a per-call plan where rustfft picks SIMD mixed-radix plans",
         "sample": f"{clips} x {n_samples}-sample clips ({clips * rows_per_clip} frames) in {el:.1f} s, single thread, "
                   f"oracle/ss_oracle.c port_{'mfcc' if kind == 'mfcc' else 'mel_spectrogram'}_f32; host has {os.cpu_count()} logical cores",
     }
@@ -150,9 +155,11 @@ def load_profile(kernel_name, workload, headline):
     out = {"traffic": e.get("hbm_bytes_per_launch"),
            "traffic_source": "profiles/pmc_traffic.json (stored: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                              f"{e.get('profiled', 'round 1')}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"}
-    for k in ("valu_insts_per_launch", "valu_floor_frac", "lds_busy_frac", "lds_bank_conflict_frac", "clock_ghz_assumed", "wave_time_shares"):
-        if k in e:
-            out[k] = e[k]
+    # the instruction count is a property of the kernel binary, not of the profiled run: it is what this run's VALU-floor
+    # fraction is computed from (with this run's duration and this run's clock).  The profiled run's own shares (LDS busy,
+    # wave-time shares, ...) stay in profiles/: they belong to that run's duration, not to this line.
+    if "valu_insts_per_launch" in e:
+        out["valu_insts_per_launch"] = e["valu_insts_per_launch"]
     return out
 
 
@@ -187,9 +194,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the workload's)")
-    ap.add_argument("--gather", action="store_true", help="(default for --gpus > 1) overlapped RCCL all-gather of the output blocks")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1 without the collective: independent shards only")
-    ap.add_argument("--gather-every", type=int, default=8, help="steps per all-gather bucket (fewer, larger collectives)")
+    ap.add_argument("--gather-mode", default="root", choices=["root", "all", "none"],
+                    help="N > 1: gather of the output blocks to rank 0 (grouped send / recv), to every rank (all-gather), or no collective")
+    ap.add_argument("--gather", action="store_true", help="(kept for old command lines; the gather is on by default for --gpus > 1)")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather-mode none")
+    ap.add_argument("--gather-every", type=int, default=8, help="steps per gather bucket (fewer, larger collectives)")
+    ap.add_argument("--force-generic", action="store_true", help="run on the generic kernel (ss_debug_force_generic): the 'generic us' columns of DESIGN.md")
     ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed launches before the warm-up steps, to leave the idle power state")
     ap.add_argument("--streams", type=int, default=1, help="issue successive steps round-robin on this many HIP streams "
                     "(independent batches in flight: one launch's tail overlaps the next one's head); the roofline block "
@@ -233,7 +243,12 @@ def main():
             backend = "gloo"
             print(f"[bench] rank {rank}: {world} ranks share {n_dev} device(s): gloo instead of RCCL, timings are not a scaling result",
                   file=sys.stderr, flush=True)
-    do_gather = world > 1 and not args.no_gather
+    gather_mode = "none" if (world == 1 or args.no_gather) else args.gather_mode
+    do_gather = gather_mode != "none"
+    if do_gather and args.streams > 1:
+        # a bucket's hand-off to the side stream is ordered by events on ONE launch stream; with steps spread over several
+        # streams the gather could read slots a kernel is still writing
+        raise SystemExit("bench.py: --streams > 1 cannot be combined with the gather (use --gather-mode none)")
 
     desc, pkw, n_samples, clips, kind = WORKLOADS[args.workload]
     if args.params:
@@ -252,6 +267,8 @@ def main():
         clips = hi - lo
     cfg = SpeechConfig(make_params(**pkw))
     lib = _lib.lib()
+    if args.force_generic or os.environ.get("SS_FORCE_GENERIC"):  # (the env spelling keeps the tools/*_rate.sh scripts working)
+        lib.ss_debug_force_generic(1)
 
     if kind == "mfcc":
         rows = cfg.num_frames(n_samples)
@@ -273,104 +290,130 @@ def main():
     outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(max(2, 2 * args.streams))]
 
     # The gather (north-star: "RCCL gather over xGMI of the final [n_frames x n_mfcc] blocks"): the outputs of
-    # `gather_every` consecutive steps land in one bucket [G, clips, rows, ceps]; a full bucket is all-gathered into
-    # [world, G, ...] on a side stream while the following steps compute into the other bucket.
-    from speechsauce_amd.distributed import all_gather_into
+    # `gather_every` consecutive steps land in one bucket [G, clips, rows, ceps]; a full bucket is gathered into
+    # [world, G, ...] (on rank 0, or on every rank) on a side stream while the following steps compute into the other bucket.
+    from speechsauce_amd.distributed import all_gather_into, gather_into
 
     G = 1 if strong else max(1, args.gather_every)  # a corpus shard's block is already a large message
     buckets = gathered = comm_stream = None
-    bucket_done = [None, None]
     if do_gather:
         buckets = [torch.empty((G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
-        gathered = [torch.empty((world * G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
+        if gather_mode == "all" or rank == 0:
+            gathered = [torch.empty((world * G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
         comm_stream = torch.cuda.Stream(device=device)
-        outs = None  # steps write straight into the bucket slots
 
-    def out_for(i):
-        if buckets is None:
-            return outs[i % len(outs)]
-        b = (i // G) % 2
-        if i % G == 0 and bucket_done[b] is not None:  # the bucket's previous gather must have read it
-            stream.wait_event(bucket_done[b])
-        return buckets[b][i % G]
+    class Region:
+        """One timed (or warm-up) sequence of steps; with_gather routes the outputs through the buckets and the collective."""
 
-    def after_step(i, last):
-        """Launch the all-gather of a bucket once its last step has been issued."""
-        if buckets is None or not ((i + 1) % G == 0 or last):
-            return
-        b = (i // G) % 2
-        n = i % G + 1  # filled slots (a run's last bucket may be partial: only what was computed is gathered)
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ev)
-            all_gather_into(gathered[b][: world * n], buckets[b][:n])
-            done = torch.cuda.Event()
-            done.record(comm_stream)
-        bucket_done[b] = done
+        def __init__(self, with_gather):
+            self.g = bool(with_gather and do_gather)
+            self.bucket_done = [None, None]
+            self.comm_events = []
 
-    def step(i):
-        x, o, sp = xs[i % n_buf], out_for(i), sptrs[i % len(sptrs)]
-        if kind == "mfcc":
-            rc = lib.ss_mfcc_batch_device(cfg.handle, x.data_ptr(), clips, n_samples, n_samples, o.data_ptr(), sp)
-        else:
-            rc = lib.ss_mel_spectrogram_device(cfg.handle, x.data_ptr(), clips, n_samples, n_samples, o.data_ptr(), sp)
-        if rc:
-            _lib.check(rc)
-        return o
+        def out_for(self, i):
+            if not self.g:
+                return outs[i % len(outs)]
+            b = (i // G) % 2
+            if i % G == 0 and self.bucket_done[b] is not None:  # the bucket's previous gather must have read it
+                stream.wait_event(self.bucket_done[b])
+            return buckets[b][i % G]
 
+        def after_step(self, i, last):
+            """Launch the gather of a bucket once its last step has been issued."""
+            if not self.g or not ((i + 1) % G == 0 or last):
+                return
+            b = (i // G) % 2
+            n = i % G + 1  # filled slots (a run's last bucket may be partial: only what was computed is gathered)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record(comm_stream)
+                if gather_mode == "all":
+                    all_gather_into(gathered[b][: world * n], buckets[b][:n])
+                else:
+                    gather_into(gathered[b][: world * n] if rank == 0 else None, buckets[b][:n], dst=0)
+                c1.record(comm_stream)
+            self.comm_events.append((c0, c1, n))
+            self.bucket_done[b] = c1
+
+        def step(self, i):
+            x, o, sp = xs[i % n_buf], self.out_for(i), sptrs[i % len(sptrs)]
+            if kind == "mfcc":
+                rc = lib.ss_mfcc_batch_device(cfg.handle, x.data_ptr(), clips, n_samples, n_samples, o.data_ptr(), sp)
+            else:
+                rc = lib.ss_mel_spectrogram_device(cfg.handle, x.data_ptr(), clips, n_samples, n_samples, o.data_ptr(), sp)
+            if rc:
+                _lib.check(rc)
+            return o
+
+        def drain(self):
+            if comm_stream is not None:
+                comm_stream.synchronize()
+            torch.cuda.synchronize()
+
+    def run_timed(with_gather, steps):
+        """barrier + synchronize, EXACTLY `steps` steps, barrier + synchronize; wall time is the MAX over ranks."""
+        reg = Region(with_gather)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # ten intermediate events on the launch stream: median / spread of the per-launch time over tenths of the timed region
+        seg_every = max(1, steps // 10)
+        seg_events = []
+        e0.record(stream)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            reg.step(i)
+            reg.after_step(i, i + 1 == steps)
+            if args.streams == 1 and steps >= 200 and (i + 1) % seg_every == 0 and i + 1 < steps:  # (an event between launches costs ~1 us)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream)
+                seg_events.append((i + 1, ev))
+        for st in extra_streams:  # the end event on the launch stream waits for the other streams' work
+            ev = torch.cuda.Event()
+            ev.record(st)
+            stream.wait_event(ev)
+        e1.record(stream)
+        while not e1.query():  # poll instead of sleeping in the driver: the blocking wait's wake-up latency is tens of microseconds,
+            pass               # which is several steps' worth when only a few steps are timed
+        reg.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        marks = [(0, e0)] + seg_events + [(steps, e1)]
+        segs = sorted(a_ev.elapsed_time(b_ev) * 1e3 / (b_i - a_i) for (a_i, a_ev), (b_i, b_ev) in zip(marks[:-1], marks[1:]) if b_i > a_i)
+        comm_ms = [c0.elapsed_time(c1) for c0, c1, _ in reg.comm_events]
+        comm_steps = sum(n for _, _, n in reg.comm_events)
+        return {"elapsed": elapsed, "dev_ms": e0.elapsed_time(e1), "segs": segs, "comm_ms": comm_ms, "comm_steps": comm_steps}
+
+    warm = Region(True)
     if args.prewarm_ms > 0:  # leave the idle power state before the (possibly few) warm-up steps
+        pre = Region(False)
         t_end = time.perf_counter() + args.prewarm_ms * 1e-3
         k = 0
         while time.perf_counter() < t_end:
             for _ in range(50):
-                step(k)
+                pre.step(k)
                 k += 1
             torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-        after_step(i, i + 1 == args.warmup)
-    if comm_stream is not None:
-        comm_stream.synchronize()
-    bucket_done = [None, None]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    for i in range(args.warmup):  # warm-up runs the full step (with the collective when there is one)
+        warm.step(i)
+        warm.after_step(i, i + 1 == args.warmup)
+    warm.drain()
 
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # ten intermediate events on the launch stream: median / spread of the per-launch time over tenths of the timed region
-    seg_every = max(1, args.steps // 10)
-    seg_events = []
-    e0.record(stream)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        after_step(i, i + 1 == args.steps)
-        if args.streams == 1 and args.steps >= 200 and (i + 1) % seg_every == 0 and i + 1 < args.steps:  # (an event between launches costs ~1 us)
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(stream)
-            seg_events.append((i + 1, ev))
-    for st in extra_streams:  # the end event on the launch stream waits for the other streams' work
-        ev = torch.cuda.Event()
-        ev.record(st)
-        stream.wait_event(ev)
-    e1.record(stream)
-    while not e1.query():  # poll instead of sleeping in the driver: the blocking wait's wake-up latency is tens of microseconds,
-        pass               # which is several steps' worth when only a few steps are timed
-    if comm_stream is not None:
-        comm_stream.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)  # HIP events on the launch stream over the timed region
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # N > 1 with a gather: the path alone first, then the path with the collective -- both K steps, both in this run
+    t_path = run_timed(False, args.steps)
+    t_full = run_timed(True, args.steps) if do_gather else t_path
+    elapsed, dev_ms, segs = t_full["elapsed"], t_path["dev_ms"], t_path["segs"]
 
     # Shader clock during the launches (512-point MFCC kernel only): thirty more steps right behind the timed ones, with the
     # kernel's per-wave stamps switched on (ss_debug_stamp_buffer): cycles a wave lived / its lifetime on the 100 MHz clock.
@@ -381,8 +424,9 @@ def main():
         torch.cuda.synchronize()
         lib.ss_debug_stamp_buffer(stamps.data_ptr())
         try:
+            reg = Region(False)
             for i in range(30):
-                step(i)
+                reg.step(i)
             torch.cuda.synchronize()
         finally:
             lib.ss_debug_stamp_buffer(None)
@@ -399,8 +443,23 @@ def main():
         value = total_frames / elapsed
         avg_launch_s = dev_ms * 1e-3 / args.steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        marks = [(0, e0)] + seg_events + [(args.steps, e1)]
-        segs = sorted(a_ev.elapsed_time(b_ev) * 1e3 / (b_i - a_i) for (a_i, a_ev), (b_i, b_ev) in zip(marks[:-1], marks[1:]) if b_i > a_i)
+        gather_info = None
+        if do_gather:
+            cm = sorted(t_full["comm_ms"])
+            step_s = t_full["elapsed"] / args.steps
+            gather_info = {
+                "mode": gather_mode,
+                "collective": "ncclAllGather (all_gather_into_tensor)" if gather_mode == "all" else "grouped ncclSend/ncclRecv to rank 0 (torch.distributed.gather)",
+                "bucket_steps": G,
+                "bytes_per_rank_per_step": 4 * out_elems,
+                "bytes_into_root_per_step" if gather_mode == "root" else "bytes_received_per_rank_per_step": 4 * out_elems * (world - 1),
+                # what one direct link (peer -> root, or peer -> peer in the all-gather) carried per second of the timed region
+                "achieved_gbps_per_link": 4 * out_elems / step_s / 1e9,
+                # the collective's own duration on the side stream (rank 0's events), per step of output it moved
+                "collective_ms_per_step_median": (cm[len(cm) // 2] * len(cm) / max(1, t_full["comm_steps"])) if cm else None,
+                "collectives_timed": len(cm),
+                "hardware": "unmeasured on a multi-GPU box until a SCALE record exists" if shared_device else "this run",
+            }
         res = {
             "metric": "mfcc_frames_per_sec" if kind == "mfcc" else "mel_rows_per_sec",
             "value": value,
@@ -420,15 +479,17 @@ def main():
                 "clips_per_gpu": clips,
                 "samples_per_clip": n_samples,
                 "frames_per_clip": rows,
-                "parallelism": f"clip-sharded x{world}" + (f" + all-gather of the output blocks over {backend} in buckets of {G} steps, overlapped"
+                "parallelism": f"clip-sharded x{world}" + (f" + gather of the output blocks ({gather_mode}) over {backend} in buckets of {G} steps, overlapped"
                                                               if do_gather else ", no collective")
                                + (f", {args.streams} streams" if args.streams > 1 else ""),
             },
             "backend": backend,
             "rccl_ranks": world if backend == "nccl" else 0,
             "ranks_share_a_device": bool(shared_device) if world > 1 else False,
-            "gather": ({"collective": "all_gather_into_tensor", "bucket_steps": G, "bytes_per_rank_per_step": 4 * out_elems,
-                        "bytes_received_per_rank_per_step": 4 * out_elems * (world - 1)} if do_gather else None),
+            # N > 1: the same K steps without the collective, timed in this run just before the region `value` comes from
+            "value_path_only": total_frames / t_path["elapsed"],
+            "ms_per_step_path_only": t_path["elapsed"] * 1e3 / args.steps,
+            "gather": gather_info,
             "prewarm_ms": args.prewarm_ms,
             "real_time_factor": value / rows * (n_samples / pkw["sample_rate"]),
             "roofline": {
@@ -438,7 +499,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                **load_profile(kernel, args.workload, headline=not (args.params or args.kind or args.clips)),
+                **load_profile(kernel, args.workload, headline=not (args.params or args.kind or args.clips or args.force_generic)),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launch_us_median_min_max_over_tenths": [segs[len(segs) // 2], segs[0], segs[-1]],
@@ -458,8 +519,9 @@ def main():
             rf = res["roofline"]
             rf["clock_ghz_measured"] = clock_ghz
             if rf.get("valu_insts_per_launch"):
-                # VALU issue floor (2.14 cycles per instruction per SIMD, 1024 SIMDs) at the clock this device held in this run
-                rf["valu_floor_frac_at_measured_clock"] = rf["valu_insts_per_launch"] / 1024.0 * 2.14 / (avg_launch_s * 1e9 * clock_ghz)
+                # ONE VALU-issue-floor fraction: the kernel's instruction count (2.14 cycles per instruction per SIMD, 1024 SIMDs;
+                # tools/ubench/valu_issue.hip) over THIS run's launch duration at the clock THIS device held in THIS run
+                rf["valu_floor_frac"] = rf["valu_insts_per_launch"] / 1024.0 * 2.14 / (avg_launch_s * 1e9 * clock_ghz)
         print(json.dumps(res), flush=True)
 
     if world > 1:

@@ -125,6 +125,9 @@ struct Fast512Args {
     unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
     // filled by launch_mfcc_c256: floor(x / n_frames) = umulhi(x, nf_magic) >> nf_shift for x < 2^31 (nf_magic = 0: divide)
     uint32_t nf_magic, nf_shift;
+    // filled by launch_mfcc_c256: workgroup b owns quads [b * q_base + min(b, q_rem), + q_base + (b < q_rem)) -- the balanced
+    // contiguous split without a division in the kernel's prologue (everything in front of the first loads is start-up latency)
+    uint32_t q_base, q_rem;
 };
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

@@ -72,12 +72,40 @@ __host__ __device__ __forceinline__ void fft_reg<8>(float2 *v)
 // The same 16-point DFT, handing each output to `emit(k, X[k])` as soon as its group of four is final (k = k2, k2 + 4, k2 + 8,
 // k2 + 12 after group k2) and calling `fence()` after every group: a kernel that stores the outputs to LDS can spread the
 // stores over the butterfly instead of issuing all of them behind it (the LDS queue then never sees a 16-store burst).
-template <class Emit, class Fence>
+// Forward 4-point DFT whose trailing inputs are known to be zero (zero-padded frames): Z3: v3 == 0; Z2: v2 == 0 as well.
+// Written out because the compiler may not fold x + 0.0f (it would turn -0.0f into +0.0f): each dropped term is one
+// instruction per component.
+template <bool Z2, bool Z3>
+__host__ __device__ __forceinline__ void fft4z(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
+{
+    if constexpr (!Z3) {
+        fft4(v0, v1, v2, v3);
+    } else if constexpr (!Z2) {
+        const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2);
+        const float2 a2 = v1, a3 = mul_mi(v1);
+        v0 = cadd(a0, a2);
+        v1 = cadd(a1, a3);
+        v2 = csub(a0, a2);
+        v3 = csub(a1, a3);
+    } else {
+        const float2 a0 = v0, a2 = v1, a3 = mul_mi(v1);
+        v0 = cadd(a0, a2);
+        v1 = cadd(a0, a3);
+        v2 = csub(a0, a2);
+        v3 = csub(a0, a3);
+    }
+}
+
+// NZ: the first NZ of the 16 inputs may be non-zero, v[NZ..15] are exactly zero (NZ >= 8: elements n1 and n1 + 4 always count)
+template <int NZ = 16, class Emit, class Fence>
 __device__ __forceinline__ void fft16_emit(float2 *v, Emit &&emit, Fence &&fence)
 {
+    static_assert(NZ >= 8 && NZ <= 16, "pruning covers the last two input quarters only");
     // step A: for each n1, 4-point DFT over n2 (elements n1, n1+4, n1+8, n1+12) -> Y[n1][k2] kept in v[n1 + 4 k2]
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) fft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+    fft4z<(0 + 8 >= NZ), (0 + 12 >= NZ)>(v[0], v[4], v[8], v[12]);
+    fft4z<(1 + 8 >= NZ), (1 + 12 >= NZ)>(v[1], v[5], v[9], v[13]);
+    fft4z<(2 + 8 >= NZ), (2 + 12 >= NZ)>(v[2], v[6], v[10], v[14]);
+    fft4z<(3 + 8 >= NZ), (3 + 12 >= NZ)>(v[3], v[7], v[11], v[15]);
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
     constexpr float t1 = 0.41421356237309504880f, t3 = 2.41421356237309504880f;  // tan(pi/8), cot(pi/8)
     constexpr float h = 0.70710678118654752440f;

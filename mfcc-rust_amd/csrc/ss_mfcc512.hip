@@ -219,8 +219,18 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
 
 template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, int OUTK = 0, int FRONT = 0, bool FULLP = false,
           bool CENTER = false>
-__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
+__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_in)
 {
+    // Everything in front of a wave's first sample loads is start-up latency of the launch (nothing can be computed before
+    // the samples are here), so the kernel arguments that lead to those loads are fetched by ONE batch of scalar loads at the
+    // very top (pinned: left alone, the compiler fetches them where they are first used -- three dependent scalar-memory
+    // round trips, the last one behind the table waves' vector loads).
+    Fast512Args a = a_in;
+    // (the pointers themselves are not pinned: behind an asm statement they would no longer be known to point to global
+    // memory and their loads would become flat_load; they sit in the same kernarg lines as the pinned scalars)
+    asm volatile("" : "+s"(a.ld));
+    asm volatile("" : "+s"(a.n_samples), "+s"(a.batch), "+s"(a.flen), "+s"(a.step), "+s"(a.n_frames), "+s"(a.mel_wpitch), "+s"(a.win_floats));
+    asm volatile("" : "+s"(a.nf_magic), "+s"(a.nf_shift), "+s"(a.q_base), "+s"(a.q_rem));
     constexpr bool PREFETCH = true;
     // more than 12 waves per CU (4 per SIMD, <= 128 VGPRs): the P / ln / sum-difference rows live inside the frame's own
     // exchange slot (9216 B per wave) and no table stays in registers
@@ -264,22 +274,41 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
 
     // quad range of this workgroup (contiguous, balanced to within one quad)
     const unsigned total = a.batch * a.n_frames;
-    const unsigned quads = (total + 3) / 4;
-    const unsigned q_lo = static_cast<unsigned>(static_cast<unsigned long long>(quads) * blockIdx.x / gridDim.x);
-    const unsigned q_hi = static_cast<unsigned>(static_cast<unsigned long long>(quads) * (blockIdx.x + 1) / gridDim.x);
+    const unsigned q_lo = blockIdx.x * a.q_base + min(blockIdx.x, a.q_rem);
+    const unsigned q_hi = q_lo + a.q_base + (blockIdx.x < a.q_rem ? 1u : 0u);
 
     // The table block (global layout == LDS layout) is fetched by the workgroup's first two waves only, before they ask
     // for their samples: behind the sample loads of the other waves (HBM misses that fill the CU's miss queue) a table load
     // takes 3-4 us instead of 1, and the barrier below waits for the slowest one.
     constexpr int kTabWaves = 2;
     const int n4 = (L::kMelW + 16 * a.mel_wpitch + (WIN ? a.win_floats : 0)) / 4;
+    constexpr int kBatch = 6;  // loads in flight per lane (768 float4s cover every 512-point table block with <= 80 floats per mel row)
+    float4 tv[kBatch];
     if (wave < kTabWaves) {
-        constexpr int kBatch = 6;  // loads in flight per lane (768 float4s cover every 512-point table block with <= 80 floats per mel row)
-        for (int base = 0; base < n4; base += kBatch * kTabWaves * 64) {
-            float4 tv[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) tv[k] = reinterpret_cast<const float4 *>(a.tab)[min(tid + k * (kTabWaves * 64), n4 - 1)];
+    }
+    // first quad of this wave; its loads are in flight across the barrier (a wave without a quad loads the block's last
+    // one: no branch around the loads).  The table waves ask for their samples right behind their table loads, before they
+    // wait for the tables: vector loads return in order, so the tables still come first.
+    unsigned quad = q_lo + wave;
+    float2 vin[NE];
+    float2 pin[PRE ? NE : 1];
+    unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
+    t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
+    if (wave < kTabWaves) {
+        // (pinned: the compiler otherwise sinks each load next to its store, one memory round trip per float4)
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) asm volatile("" : "+v"(tv[k].x), "+v"(tv[k].y), "+v"(tv[k].z), "+v"(tv[k].w));
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int idx = tid + k * (kTabWaves * 64);
+            if (idx < n4) reinterpret_cast<float4 *>(s_tab)[idx] = tv[k];
+        }
+        // table blocks of more than 768 float4s (mel rows wider than 80 floats): the rest, behind the samples
+        for (int base = kBatch * kTabWaves * 64; base < n4; base += kBatch * kTabWaves * 64) {
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) tv[k] = reinterpret_cast<const float4 *>(a.tab)[min(base + tid + k * (kTabWaves * 64), n4 - 1)];
-            // (pinned: the compiler otherwise sinks each load next to its store, one memory round trip per float4)
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) asm volatile("" : "+v"(tv[k].x), "+v"(tv[k].y), "+v"(tv[k].z), "+v"(tv[k].w));
 #pragma unroll
@@ -290,13 +319,6 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         }
         if (a.dbg) stamp(5, __builtin_amdgcn_s_memrealtime());  // table waves: when the tables were in LDS
     }
-    // first quad of this wave; its loads are in flight across the barrier (a wave without a quad loads the block's last
-    // one: no branch around the loads)
-    unsigned quad = q_lo + wave;
-    float2 vin[NE];
-    float2 pin[PRE ? NE : 1];
-    unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
-    t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
     {
         if (tid == 0) *s_next = q_lo + WAVES;
         if (!FULLP && !ALIAS && j < 3) prow[129 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage; never written again
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a)
         // ---- 256-point complex FFT: radix-16, transpose through LDS, twiddle, radix-16 ----
         if (!(SS_ABLATE & 4)) {
             // the exchange stores leave group by group while the butterfly is still computing (no 16-store burst into the LDS queue)
-            fft16_emit(
+            fft16_emit<(NE >= 8 ? NE : 16)>(
                 v, [&](int r, float2 val) { zh[wbase1 + 2 * r] = val; }, [] { __builtin_amdgcn_sched_barrier(0); });
         } else {
             fft16_reg(v);
@@ -652,6 +674,8 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
     const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
     if (blocks > cap) blocks = cap;
     const unsigned grid = static_cast<unsigned>(blocks);
+    a.q_base = static_cast<uint32_t>(quads / grid);
+    a.q_rem = static_cast<uint32_t>(quads % grid);
     auto go = [&](auto kern, const char *name) {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

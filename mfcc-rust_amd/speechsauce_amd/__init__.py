@@ -410,8 +410,11 @@ def power_spectrum(frames, fft_points=512):
             raise TypeError(f"power_spectrum: frames must be float32, got {fr.dtype}")
         if fr.ndim != 2:
             raise ValueError("power_spectrum: frames must be 2d")
-    # only fft_points of the config matters here; the other fields are the defaults at a rate that validates with it
-    config = _cfg(16000, 0.020, 0.01, 13, 40, int(fft_points), 0, None, True, {}, fr)
+    # only fft_points of the config matters here; the other fields are chosen so that the config validates with it
+    # (a frame of half the FFT length, a bank that fits the spectrum)
+    n = int(fft_points)
+    nf = max(1, min(40, n // 8))
+    config = _cfg(16000, n / 32000.0, n / 64000.0, min(13, nf), nf, n, 0, None, True, {}, fr)
     lib = _lib.lib()
     rows, cols = fr.shape
     F = int(fft_points) // 2 + 1

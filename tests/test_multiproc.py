@@ -18,14 +18,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_clips, result_dir):
+def _worker(rank, world, port, n_clips, result_dir, mode="all"):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "mfcc-rust_amd"), os.path.join(root, "oracle")):
         sys.path.insert(0, p)
     import oracle_c
-    from speechsauce_amd.distributed import all_gather_features, shard_bounds
+    from speechsauce_amd.distributed import all_gather_features, gather_features, shard_bounds
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,9 +35,14 @@ def _worker(rank, world, port, n_clips, result_dir):
         p = oracle_c.make_params()
         lo, hi = shard_bounds(n_clips, world, rank)
         local = np.stack([oracle_c.port_mfcc(p, x[b]) for b in range(lo, hi)]) if hi > lo else np.zeros((0, 23, 13), np.float32)
-        full = all_gather_features(torch.from_numpy(local), n_clips)
+        if mode == "root":  # the north-star's gather: only the root (here the LAST rank, to exercise dst != 0) receives
+            full = gather_features(torch.from_numpy(local), n_clips, dst=world - 1)
+            assert (full is None) == (rank != world - 1)
+        else:
+            full = all_gather_features(torch.from_numpy(local), n_clips)
         dist.barrier()
-        np.save(os.path.join(result_dir, f"rank{rank}.npy"), full.numpy())
+        if full is not None:
+            np.save(os.path.join(result_dir, f"rank{rank}.npy"), full.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -53,6 +58,19 @@ def test_sharded_gather_matches_single_process(tmp_path, oracle, world, n_clips)
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npy"))
         assert got.shape == want.shape
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,n_clips", [(2, 6), (2, 7), (3, 7), (2, 1), (3, 2)])
+def test_sharded_gather_to_root_matches_single_process(tmp_path, oracle, world, n_clips):
+    """gather_features (grouped send / recv to one rank): even, uneven and empty shards; only the root holds the result."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_clips, str(tmp_path), "root"), nprocs=world, join=True)
+    x = (np.random.default_rng(42).standard_normal((n_clips, 4000)) * 0.1).astype(np.float32)
+    p = oracle.make_params()
+    want = np.stack([oracle.port_mfcc(p, x[b]) for b in range(n_clips)])
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("rank"))
+    assert files == [f"rank{world - 1}.npy"]
+    np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), files[0])), want)
 
 
 def test_shard_bounds_cover_exactly():
@@ -79,7 +97,7 @@ def test_sharded_gather_with_an_empty_shard(tmp_path, oracle):
         np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), f"rank{r}.npy")), want)
 
 
-def _gpu_worker(rank, world, port, n_clips, result_dir):
+def _gpu_worker(rank, world, port, n_clips, result_dir, mode=True):
     """One rank of the HIP path: both ranks share cuda:0 (RCCL refuses that, so the collective runs over gloo with the
     device blocks staged through host memory -- speechsauce_amd.distributed.all_gather_into)."""
     import sys
@@ -95,18 +113,20 @@ def _gpu_worker(rank, world, port, n_clips, result_dir):
     try:
         torch.cuda.set_device(0)
         x = torch.from_numpy((np.random.default_rng(7).standard_normal((n_clips, 16000)) * 0.1).astype(np.float32)).cuda()
-        full = mfcc_sharded(x, 16000)  # this rank's contiguous shard on the HIP kernels, then the gather
-        assert "ss_mfcc_c256" in ss._lib.lib().ss_last_kernel_name().decode() or full.shape[0] < world
+        full = mfcc_sharded(x, 16000, gather=mode)  # this rank's contiguous shard on the HIP kernels, then the gather
+        assert "ss_mfcc_c256" in ss._lib.lib().ss_last_kernel_name().decode() or n_clips < world
         torch.cuda.synchronize()
         dist.barrier()
-        np.save(os.path.join(result_dir, f"gpu_rank{rank}.npy"), full.cpu().numpy())
+        assert (full is None) == (mode == "root" and rank != 0)
+        if full is not None:
+            np.save(os.path.join(result_dir, f"gpu_rank{rank}.npy"), full.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_clips", [9, 1])
-def test_two_ranks_hip_path_gather_is_bit_identical_to_one_process(tmp_path, n_clips):
+@pytest.mark.parametrize("n_clips,mode", [(9, True), (1, True), (9, "root"), (1, "root")])
+def test_two_ranks_hip_path_gather_is_bit_identical_to_one_process(tmp_path, n_clips, mode):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -114,17 +134,18 @@ def test_two_ranks_hip_path_gather_is_bit_identical_to_one_process(tmp_path, n_c
     import speechsauce_amd as ss
 
     port = _free_port()
-    mp.spawn(_gpu_worker, args=(2, port, n_clips, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, port, n_clips, str(tmp_path), mode), nprocs=2, join=True)
     x = torch.from_numpy((np.random.default_rng(7).standard_normal((n_clips, 16000)) * 0.1).astype(np.float32)).cuda()
     want = ss.mfcc_batch(x, 16000).cpu().numpy()
-    for r in range(2):
+    for r in range(1 if mode == "root" else 2):
         got = np.load(os.path.join(str(tmp_path), f"gpu_rank{r}.npy"))
         assert got.shape == want.shape
         np.testing.assert_array_equal(got, want)  # same kernel, same frames: bit for bit
 
 
 @pytest.mark.gpu
-def test_bench_launches_its_own_ranks():
+@pytest.mark.parametrize("mode", ["root", "all"])
+def test_bench_launches_its_own_ranks(mode):
     """`python bench.py --gpus 2` must run by itself (the driver's multi-GPU invocation without a launcher); on a one-GPU box
     the two ranks share the device and the collective runs over gloo -- the control flow is what is checked."""
     import json
@@ -136,12 +157,15 @@ def test_bench_launches_its_own_ranks():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--clips", "64",
-                        "--no-cpu-baseline", "--prewarm-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-cpu-baseline", "--prewarm-ms", "0", "--gather-mode", mode], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0
-    assert d["gather"] and d["gather"]["bucket_steps"] >= 1
+    # both regions of the same run: the path alone, and the path with the collective
+    assert d["value_path_only"] > 0 and d["ms_per_step_path_only"] > 0 and d["ms_per_step"] > 0
+    g = d["gather"]
+    assert g and g["mode"] == mode and g["bucket_steps"] >= 1 and g["achieved_gbps_per_link"] > 0 and g["collectives_timed"] >= 1
     assert d["backend"] in ("nccl", "gloo")
     assert d["rccl_ranks"] == (2 if d["backend"] == "nccl" else 0)
 
@@ -188,5 +212,12 @@ def test_abi_rccl_all_gather_single_rank(ss, sslib):
         assert sslib.ss_all_gather_features(comm, block.data_ptr(), block.numel(), out.data_ptr(), C.c_void_p(stream)) == 0
         torch.cuda.synchronize()
         assert torch.equal(out, block)
+        # the gather to a root on the same communicator: with one rank it is the root's own device copy inside an empty group
+        out.zero_()
+        assert sslib.ss_gather_features(comm, block.data_ptr(), block.numel(), out.data_ptr(), 0, 0, 1, C.c_void_p(stream)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, block)
+        assert sslib.ss_gather_features(comm, block.data_ptr(), block.numel(), out.data_ptr(), 1, 0, 1, C.c_void_p(stream)) == 3  # bad root
+        assert sslib.ss_rccl_library(b"/nonexistent/librccl.so") == 3  # too late: RCCL is already resolved in this process
     finally:
         rccl.ncclCommDestroy(comm)
