@@ -482,13 +482,15 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
 #else
         constexpr const char *rows_path = nullptr;
 #endif
-        if (rows_path) (void)hipMalloc(reinterpret_cast<void **>(&f.dbg), (1028 + 256 + 4 * 4096) * sizeof(float));
+        constexpr size_t kDbgFloats = 131072;  // >= 1028 + 256 + 4 * 4096 (stage dumps) and >= waves x 16 x 2 (SS_PROF5 phase sums)
+        if (rows_path && hipMalloc(reinterpret_cast<void **>(&f.dbg), kDbgFloats * sizeof(float)) == hipSuccess)
+            (void)hipMemsetAsync(f.dbg, 0, kDbgFloats * sizeof(float), stream);
         const hipError_t e4 = ss::launch_mfcc_c2048(f, stream, cfg->num_cus, &info);
         if (e4 != hipSuccess && f.dbg) (void)hipFree(f.dbg);
         // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> generic kernel
         if (e4 != hipSuccess && e4 != hipErrorInvalidValue) return hip_fail(e4, "launch_mfcc_c2048");
         if (e4 == hipSuccess && f.dbg) {
-            std::vector<float> rows(1028 + 256 + 4 * 4096);
+            std::vector<float> rows(kDbgFloats);
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(rows.data(), f.dbg, rows.size() * sizeof(float), hipMemcpyDeviceToHost);
             (void)hipFree(f.dbg);

@@ -40,6 +40,35 @@
 #ifndef SS_ABL5
 #define SS_ABL5 0
 #endif
+// experiment switches (lab builds): bit 0 the next frame's samples are requested from inside the untangle, two loads per
+// step, into the (dead) input registers of the transform
+#if !SS_LAB
+#undef SS_X5
+#endif
+#ifndef SS_X5
+#define SS_X5 0
+#endif
+// SS_PROF5 (lab builds, with SS_DEBUG_ROWS=<file>): every wave sums the shader-clock ticks it spends in each phase of its
+// iterations (s_memtime at the phase boundaries; the wait for the stamp also drains the phase's LDS operations) and writes 16
+// 64-bit words at the end: [0] iterations, [1..] phase sums.  tools/prof5.py prints the table.
+#if !SS_LAB
+#undef SS_PROF5
+#endif
+#ifndef SS_PROF5
+#define SS_PROF5 0
+#endif
+#if SS_PROF5
+#define SS_PH(k)                                                   \
+    do {                                                           \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        pacc[k] += tn_ - tprev;                                    \
+        tprev = tn_;                                               \
+    } while (0)
+#else
+#define SS_PH(k) do { } while (0)
+#endif
 
 namespace ss {
 
@@ -65,7 +94,7 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
 
 
 
-template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false>
+template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false, bool FIXMEL = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -124,18 +153,47 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 
     unsigned frame = f_lo + wave;
     float touch = 0.f;
+    constexpr bool PF = (SS_X5 & 1) && EXACT && !PRE && !WIN;
+    // bit 1: only the part of the next frame that is new to the CU's caches (its last flen - (flen - step) samples: register
+    // pairs 24..31 at hop = flen / 4) is requested early; the overlap with the frames before it loads at the top as before
+    constexpr bool PQ = (SS_X5 & 2) && EXACT && !PRE && !WIN;
+    auto frame_src = [&](unsigned fr) {
+        const unsigned c = fr / a.n_frames;
+        return reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(c) * a.ld + (fr - c * a.n_frames) * a.step) + lane;
+    };
+    float2 v[32];
+    if (PF || PQ) {
+        const float2 *s0 = frame_src(min(frame, f_hi - 1));
+#pragma unroll
+        for (int e = PQ ? 24 : 0; e < 32; ++e) v[e] = s0[64 * e];
+    }
+#if SS_PROF5
+    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
     while (frame < f_hi) {
-        unsigned next = 0;
-        if (lane == 0) next = atomicAdd(s_next, 1u);
-        next = __builtin_amdgcn_readfirstlane(next);
+        // the claim of the next frame is issued here and read where it is needed (the end of the iteration): the LDS atomic's
+        // round trip hides behind the transform
+        unsigned next_v = 0;
+        if (lane == 0) next_v = atomicAdd(s_next, 1u);
+#if SS_PROF5
+        pacc[0] += 1;
+#endif
+        SS_PH(1);  // claim
 
         const unsigned clip = frame / a.n_frames;
         const unsigned t = frame - clip * a.n_frames;
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
-        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step) + lane;
-        float2 v[32];
+        // (SS_ABL5 & 16: every frame reads clip 0 -- L2-resident samples; & 32: no sample loads at all)
+        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step) + lane;
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
+            if (PF || (PQ && e >= 24)) break;
+            if (SS_ABL5 & 32) {
+                v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(frame & 255u));
+                continue;
+            }
             if (EXACT) v[e] = src[64 * e];
             else {  // zero pad, processing.rs:147-156; an odd frame length ends in a half pair
                 const int rem = static_cast<int>(a.flen) - 2 * (lane + 64 * e);
@@ -155,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             // the sample loads at the top of an iteration hit instead of waiting for HBM.
             asm volatile("" ::"v"(touch));  // the previous touch has long returned; keeps its register live until here
             // (no branch around the load: behind a conditional load the compiler has to wait for vmcnt(0), i.e. for the touch)
-            const unsigned tf = min(next + WAVES, total - 1);
+            const unsigned tf = min(__builtin_amdgcn_readfirstlane(next_v) + WAVES, total - 1);
             const unsigned clip_t = tf / a.n_frames, t_t = tf - clip_t * a.n_frames;
             const float *pt = a.x + static_cast<unsigned long long>(clip_t) * a.ld + t_t * a.step + (a.flen > a.step ? a.flen - a.step : 0u) + (lane & 31) * 32;
             const float *last = a.x + static_cast<unsigned long long>(a.batch - 1) * a.ld + a.n_samples - 1;
@@ -169,8 +227,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
             }
         }
+#if SS_PROF5
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        SS_PH(2);  // sample loads arrived
         // ---- pass 1: radix-32 over n2 ----
         fft_reg<32>(v);
+        SS_PH(3);  // pass 1
+
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 0 * 4096)[lane * 32 + e] = v[e];
@@ -210,14 +274,24 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
 #pragma unroll
             for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 1 * 4096)[lane * 32 + e] = u[e];
         }
+        // The pass-2 twiddles are all requested here, right behind the exchange's reads and in front of the first product: read
+        // where they are used, they came two at a time, each pair one exposed LDS round trip (nobody hides it with two waves per
+        // SIMD).  (Requested before the exchange they are live across it and 19 loop invariants spill.)
+        float4 tw1[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) tw1[p] = s_t1[p * 32 + k1];
+        __builtin_amdgcn_sched_barrier(0);
+        SS_PH(4);  // exchange
         // ---- twiddle W1024^(b k1), radix-32 over b, twiddle W2048^(a (k1 + 32 c)) ----
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const float4 w2 = s_t1[p * 32 + k1];
+            const float4 w2 = tw1[p];
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
         }
+        SS_PH(5);  // twiddles
         fft_reg<32>(u);  // u[c] = G_a[c], a = lane >> 5
+        SS_PH(6);  // pass 2
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) reinterpret_cast<float2 *>(a.dbg + 1284 + 2 * 4096)[lane * 32 + e] = u[e];
@@ -244,30 +318,39 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             }
         }
 
+        SS_PH(7);  // radix-2 across the half-waves (permlane32 swaps + twiddles)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // Lane (k1, h) register r0[i] holds bin k = k1 + 32 i + 512 h (< 1024); its partner 2048 - k is r1[15 - i] of lane
         // (32 - k1, 1 - h).  The k1 = 0 lanes pair with r1[16 - i] of the other k1 = 0 lane (they expose r1 shifted by one);
         // their i = 0 pairs are in-lane: lane 0 has k = 0 (X[0] and X[2048] come from Z[0] alone), lane 32 has
         // (512, 1536) = (r0[0], r1[0]).  Z[1024] = lane 0's r1[0] is the one bin left over.
-        if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
         float esum = 0.f;
         float *pdst = prow + k1 + 512 * d;
+        // All 16 untangle twiddles and all 32 partner values are requested here, before the stage's first LDS write: a read
+        // may not move above an earlier write of the same wave, so twiddles fetched inside the loop below came one LDS round
+        // trip per bin pair (16 dependent round trips per frame, a quarter of the wave's time with two waves per SIMD).
+        float2 twn[16];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            float2 zcs[8];
+        for (int i = 0; i < 16; ++i) twn[i] = s_twn[i * 64 + lane];
+        if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = 8 * hb + q;
+        for (int hb = 0; hb < 1; ++hb) {
+            float2 zcs[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = q;
                 const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
                 zcs[q] = (SS_ABL5 & 4) ? sv : make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
             }
+            __builtin_amdgcn_sched_barrier(0);  // all 32 fetches are in flight before the first bin pair is formed (the scheduler
+                                                // otherwise sinks each next to its use: one exposed round trip per pair)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = 8 * hb + q;
+            for (int q = 0; q < 16; ++q) {
+                const int i = q;
                 const float2 zk = r0[i];
                 float2 zc = zcs[q];
                 if (i == 0) zc = k1z ? (d ? r1[0] : zk) : zc;
-                const float2 w = s_twn[i * 64 + lane];
+                const float2 w = twn[i];
                 const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
                 const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
                 // 2 X[k] = s - i w dd, 2 conj X[2048-k] = s + i w dd = 2 s - 2 X[k]
@@ -279,6 +362,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 const float pb = POW2 ? nb : __builtin_amdgcn_sqrtf(nb);
                 pdst[32 * i] = pa;  // bins 0..1023 carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70), as does 1024 below
                 esum += pa + pb;
+
             }
         }
         if (lane == 0) {
@@ -288,22 +372,39 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             prow[1024] = p1024;
             esum += p1024;
         }
-        float energy = hscale32 * wave_sum(esum);          // E * 2^32 (see ln_scaled_h)
+        float energy = hscale32 * wave_sum_dpp(esum);      // E * 2^32 (see ln_scaled_h)
         energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
+        SS_PH(8);  // untangle + magnitudes + energy
+        auto prefetch_next = [&]() {
+            // the transform's registers are free: the next frame's samples are requested now and arrive under the stages that
+            // follow (a wave's last iteration fetches its range's last frame again and drops it)
+            const float2 *nsrc = frame_src(min(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)), f_hi - 1));
+#pragma unroll
+            for (int e = PQ ? 24 : 0; e < 32; ++e) v[e] = nsrc[64 * e];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if ((PF || PQ) && !(SS_X5 & 8)) prefetch_next();
 
         if (SS_ABL5 & 2) {
             if (lane < Cc) a.out[static_cast<unsigned long long>(frame) * Cc + lane] = energy;
             wave_order();
-            frame = next;
+            frame = __builtin_amdgcn_readfirstlane(next_v);
             continue;
         }
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) -> row in filter order ----
         {
+            // the default bank shape of cfg5 (256 filters up to fs/2: 8 / 3 / 2 / 1 float4s per slot) has every tap count at
+            // compile time: one LDS wait for the whole stage; other shapes take the run-time loops
+            float mfix[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr bool fixed8321 = FIXMEL;  // the launcher checked a.mel_q4 == {8, 3, 2, 1}
+            if (fixed8321)
+                mel4_fixed<8, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
+                                       reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mfix);
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float m = hscale32 * mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                float m = hscale32 * (fixed8321 ? mfix[s] : mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]));
                 m = m == 0.f ? kEps * kTwo32 : m;
                 if (fi[s] >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
                     if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32);  // exact: power of two
@@ -315,11 +416,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         if (MFE) {  // mfe (feature.rs:200-233): mel energies (written above) and the frame energy
             if (lane == 0) a.out_energy[frame] = energy * (1.0f / kTwo32);
             wave_order();
-            frame = next;
+            frame = __builtin_amdgcn_readfirstlane(next_v);
             continue;
         }
         wave_order();
-        if (a.dbg && frame == 0) {
+        if ((PF || PQ) && (SS_X5 & 8)) prefetch_next();
+        SS_PH(9);  // mel + ln
+        if (!SS_PROF5 && a.dbg && frame == 0) {
             for (int i = lane; i < 1028; i += 64) a.dbg[i] = prow[i];
             for (int i = lane; i < 256; i += 64) a.dbg[1028 + i] = frow[i];
         }
@@ -327,7 +430,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         if (SS_ABL5 & 1) {
             if (lane < Cc) a.out[static_cast<unsigned long long>(frame) * Cc + lane] = frow[lane] + energy;
             wave_order();
-            frame = next;
+            frame = __builtin_amdgcn_readfirstlane(next_v);
             continue;
         }
         // ---- DCT-II (feature.rs:120-123), folded twice.  cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M): with
@@ -361,19 +464,24 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             const int sk = even ? (min(lane, ne - 1) & 1) : 2 + (lp & 1);
             const float4 *r4 = reinterpret_cast<const float4 *>(seg + sk * kSegPitch);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosLanePitch);
-            float4 rq[16], cq[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                rq[i] = r4[i];
-                cq[i] = c4[i];
-            }
             float acc = 0.f;
+            constexpr int kChunk = (SS_X5 & 4) ? 4 : 16;  // float4 pairs fetched per LDS wait (16: one wait, 128 registers)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc = fmaf(rq[i].x, cq[i].x, acc);
-                acc = fmaf(rq[i].y, cq[i].y, acc);
-                acc = fmaf(rq[i].z, cq[i].z, acc);
-                acc = fmaf(rq[i].w, cq[i].w, acc);
+            for (int c0 = 0; c0 < 16; c0 += kChunk) {
+                float4 rq[kChunk], cq[kChunk];
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    rq[i] = r4[c0 + i];
+                    cq[i] = c4[c0 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    acc = fmaf(rq[i].x, cq[i].x, acc);
+                    acc = fmaf(rq[i].y, cq[i].y, acc);
+                    acc = fmaf(rq[i].z, cq[i].z, acc);
+                    acc = fmaf(rq[i].w, cq[i].w, acc);
+                }
+                if (kChunk < 16) __builtin_amdgcn_sched_barrier(0);
             }
             if (!even) acc += dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the coefficient's other half (nep is even)
             if (lane < ne || (!even && !(lp & 1) && lp < Cc - 1)) {  // the lanes that hold a whole coefficient
@@ -383,7 +491,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
                 a.out[static_cast<unsigned long long>(frame) * Cc + (even ? 2 * lane : lp + 1)] = o;
             }
             wave_order();
-            frame = next;
+            SS_PH(10);  // DCT + store
+            frame = __builtin_amdgcn_readfirstlane(next_v);
             continue;
         }
         // Other shapes (n_filters not a multiple of 4, more than 43 coefficients): one fold, cosine rows [c][kCosPitch].
@@ -454,8 +563,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             }
         }
         wave_order();
-        frame = next;
+        frame = __builtin_amdgcn_readfirstlane(next_v);
     }
+#if SS_PROF5
+    if (a.dbg && lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg) + 16ull * (blockIdx.x * WAVES + wave);
+        pacc[11] = __builtin_amdgcn_s_memtime() - tstart;  // main loop lifetime
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = pacc[k];
+    }
+#endif
 }
 
 // ss_mel_c2048: the mel-spectrogram path (frame_analysis + |X wnorm|^2 + mel einsum, functions.rs:125-170, feature.rs:151-174)
@@ -704,6 +821,8 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES, true>, "ss_mfcc_c2048<exact,pow2,mfe>") : go(ss_mfcc_c2048<true, false, WAVES, true>, "ss_mfcc_c2048<exact,mfe>");
         return pow2 ? go(ss_mfcc_c2048<false, true, WAVES, true>, "ss_mfcc_c2048<pow2,mfe>") : go(ss_mfcc_c2048<false, false, WAVES, true>, "ss_mfcc_c2048<mfe>");
     }
+    const bool m8321 = a.mel_q4[0] == 8 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+    if (exact && m8321 && !pow2) return go(ss_mfcc_c2048<true, false, WAVES, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321>");
     if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
     return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
 }

@@ -60,6 +60,63 @@ __device__ __forceinline__ float half_sum(float v)
     return v;
 }
 
+// sum over the wave without an LDS round trip: four DPP adds give every lane its row's sum, the four row sums are read as
+// scalars and added; every lane ends with the same bits.  (The __shfl_xor form below is six dependent ds_bpermute round trips:
+// ~1200 cycles of a wave's time where only two waves share a SIMD.)
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v = row16_sum(v);
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (s0 + s1) + (s2 + s3);
+}
+
+// sum over the 32 lanes of a half-wave (lanes 0..31 / 32..63) the same way; every lane of the half ends with the same bits
+__device__ __forceinline__ float half_sum_dpp(float v, int half)
+{
+    v = row16_sum(v);
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return half ? s2 + s3 : s0 + s1;
+}
+
+// One lane's mel slots with compile-time tap counts (float4 units per slot): every weight and every P tap of all four slots is
+// requested before the first FMA -- one LDS wait for the stage instead of one per chunk of the run-time loops below (with two
+// waves per SIMD nobody hides those round trips).  w4: the lane's weight row; p0..p3: the P row at each slot's first bin.
+template <int Q0, int Q1, int Q2, int Q3>
+__device__ __forceinline__ void mel4_fixed(const float4 *w4, const float4 *p0, const float4 *p1, const float4 *p2, const float4 *p3, float (&m)[4])
+{
+    constexpr int QT = Q0 + Q1 + Q2 + Q3;
+    float4 w[QT], t[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) w[i] = w4[i];
+#pragma unroll
+    for (int i = 0; i < Q0; ++i) t[i] = p0[i];
+#pragma unroll
+    for (int i = 0; i < Q1; ++i) t[Q0 + i] = p1[i];
+#pragma unroll
+    for (int i = 0; i < Q2; ++i) t[Q0 + Q1 + i] = p2[i];
+#pragma unroll
+    for (int i = 0; i < Q3; ++i) t[Q0 + Q1 + Q2 + i] = p3[i];
+    constexpr int lo[5] = {0, Q0, Q0 + Q1, Q0 + Q1 + Q2, QT};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = lo[s]; i < lo[s + 1]; ++i) {
+            acc = fmaf(w[i].x, t[i].x, acc);
+            acc = fmaf(w[i].y, t[i].y, acc);
+            acc = fmaf(w[i].z, t[i].z, acc);
+            acc = fmaf(w[i].w, t[i].w, acc);
+        }
+        m[s] = acc;
+    }
+}
+
 // sum over the wave
 __device__ __forceinline__ float wave_sum(float v)
 {
