@@ -21,7 +21,8 @@ int ss_debug_poison_lds(void *stream);
 
 /* While `d_stamps` is non-null, every launch of the 512-point MFCC kernel writes six 64-bit words per wave into it
  * (16 waves x CUs x 6 words, overwritten by each launch): [0] s_memrealtime (100 MHz) at wave start, [2] at wave end,
- * [5] shader-clock cycles the wave lived | 1 << 40 (table waves: a realtime stamp instead), [1] / [3] / [4] prologue end,
+ * [5] shader-clock cycles the wave lived | 1 << 40 (the two table waves of a workgroup: ticks from their start until the tables
+ * were in LDS | 2 << 40), [1] / [3] / [4] prologue end,
  * quads done << 32 | XCC id, first samples arrived.  bench.py uses it to report the shader clock the part held during the
  * timed launches (`roofline.clock_ghz_measured`).  Pass NULL to switch it off. */
 int ss_debug_stamp_buffer(unsigned long long *d_stamps);
@@ -34,9 +35,10 @@ int ss_debug_force_generic(int on);
  * comparison of the two builds); on != 0: default selection. */
 int ss_debug_mel_tile(int on);
 
-/* on != 0: the next launches of ss_mel_c1024<tile> withhold wave 0's row pairs in every workgroup and poll only 4096
- * times before giving up, so that the tile hand-off time-out path runs: the launch must end (no hang) and the config must
- * report SS_ERR_DEVICE.  on == 0: normal operation. */
+/* on != 0: the next launches of ss_mel_c1024<tile> do not poll at all -- a wave whose tile hand-off (a clip's last row pair,
+ * a buffer's release) is not there the moment it looks takes the lost-hand-off path: it sets the config's device error
+ * word and ends.  The launch must end (no hang) and the config must report SS_ERR_DEVICE.  on == 0: normal operation
+ * (2^24 polls, about half a second, before a hand-off counts as lost). */
 int ss_debug_tile_fault(int on);
 
 #ifdef __cplusplus

@@ -81,6 +81,8 @@ struct ss_config {
     // result (today: a tile hand-off of ss_mel_c1024<tile> that never came).  The host reads it without a copy; a non-zero
     // word turns into SS_ERR_DEVICE at the next launch or synchronisation point on this config (pending_device_error).
     unsigned *h_err = nullptr, *d_err = nullptr;
+    mutable unsigned tile_spin_limit = 1u << 24;  // what the word behind the 2048-point mel table block holds (test aid toggles it)
+    mutable unsigned tile_spin_stage[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -90,9 +92,8 @@ extern std::atomic<unsigned> g_tile_fault;
 namespace ss {
 bool dbg_force_generic() { return g_force_generic.load(std::memory_order_relaxed) != 0; }
 bool dbg_mel_tile_off() { return g_mel_tile_off.load(std::memory_order_relaxed) != 0; }
-unsigned dbg_tile_fault() { return g_tile_fault.load(std::memory_order_relaxed); }
-// a forced fault polls 4096 times only (the test must not take seconds per wave)
-unsigned dbg_tile_spin_limit() { return g_tile_fault.load(std::memory_order_relaxed) ? 4096u : (1u << 24); }
+// a forced fault: no polling at all -- the first hand-off that is not there at once counts as lost
+unsigned dbg_tile_spin_limit() { return g_tile_fault.load(std::memory_order_relaxed) ? 0u : (1u << 24); }
 }  // namespace ss
 
 namespace {
@@ -566,9 +567,19 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.n_filters = a.n_filters;
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
-        m.err = cfg->d_err;
-        m.spin_limit = ss::dbg_tile_spin_limit();
-        m.fault = ss::dbg_tile_fault();
+        m.ctl = cfg->d_err;
+        {
+            // the poll bound lives behind the table block in device memory; it changes only when the test aid is toggled
+            const unsigned lim = ss::dbg_tile_spin_limit();
+            if (lim != cfg->tile_spin_limit && cfg->d_mel2048_tab) {
+                unsigned *h = static_cast<unsigned *>(static_cast<void *>(cfg->tile_spin_stage));
+                SS_HIP(hipStreamSynchronize(stream));  // (debug toggle only) the staging word may still be in flight
+                *h = lim;
+                SS_HIP(hipMemcpyAsync(cfg->d_mel2048_tab + ss::mel2048_layout::kMelW + 32 * cfg->mel2048.wpitch, h, sizeof(unsigned),
+                                      hipMemcpyHostToDevice, stream));
+                cfg->tile_spin_limit = lim;
+            }
+        }
         const hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
             g_last_kernel = info.kernel_name;

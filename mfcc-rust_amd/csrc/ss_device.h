@@ -22,8 +22,7 @@ namespace ss {
 // Process-wide test aids set through include/speechsauce_amd_debug.h (ss_api.hip)
 bool dbg_force_generic();        // ss_debug_force_generic: every configuration on the generic kernel
 bool dbg_mel_tile_off();         // ss_debug_mel_tile(0): direct stores instead of the whole-line tile
-unsigned dbg_tile_spin_limit();  // polls before a tile hand-off counts as a protocol error (ss_debug_tile_fault shortens it)
-unsigned dbg_tile_fault();       // != 0: wave 0 of every workgroup withholds its hand-off (forces the time-out path)
+unsigned dbg_tile_spin_limit();  // polls before a tile hand-off counts as a protocol error (ss_debug_tile_fault: 0)
 
 enum OutKind : int32_t {
     OUT_MFCC = 0,   // [frames x num_cepstral]                    feature.rs:99-148
@@ -149,11 +148,10 @@ struct Mel2048Args {
     float *out;       // [batch][n_filters][rows], or (out_stft) [batch][rows][1025][2]
     int32_t out_stft; // 1: write the scaled complex spectrum stft2 returns (functions.rs:86-123) instead of the mel rows
     int32_t fullp;    // the bank reaches past (F+1)/2: P rows hold every bin (not in the 4096-point kernel)
-    // whole-line tile build (ss_mel_c1024<tile>): where a wave reports a hand-off that never came (device view of the
-    // config's pinned error word; the host turns it into SS_ERR_DEVICE), and how long it polls before it does
-    unsigned *err;
-    uint32_t spin_limit;
-    uint32_t fault;   // test aid (ss_debug_tile_fault): wave 0 of every workgroup withholds its row pairs
+    // whole-line tile build (ss_mel_c1024<tile>): device view of the config's pinned error word, or null -- a wave sets it
+    // when a tile hand-off never came (the host turns it into SS_ERR_DEVICE).  Touched on the cold path only; how long a wave
+    // polls before it gives up is the word behind the table block.
+    unsigned *ctl;
 };
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

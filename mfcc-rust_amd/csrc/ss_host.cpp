@@ -756,7 +756,13 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
     if (f.wpitch == 0) f.wpitch = 4;
     if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the lanes' ds_read_b128 of their rows spread over all banks
     if (f.wpitch > 256) return;
-    f.tab.assign(static_cast<size_t>(L::kMelW) + 32 * f.wpitch, 0.0f);
+    // (+4 words behind the block: [0] = how many polls the whole-line tile build waits for a hand-off before it reports a
+    // protocol error, as an integer -- device-resident so that the kernel's cold path reads it from L2, not over PCIe)
+    f.tab.assign(static_cast<size_t>(L::kMelW) + 32 * f.wpitch + 4, 0.0f);
+    {
+        const uint32_t lim = 1u << 24;
+        std::memcpy(&f.tab[static_cast<size_t>(L::kMelW) + 32 * f.wpitch], &lim, sizeof lim);
+    }
     const double pi = 3.14159265358979323846;
     for (int r = 1; r < 32; ++r)
         for (int j = 0; j < 32; ++j) {  // exp(-2 pi i j r / 1024) = tw_c[j r]
@@ -1028,7 +1034,8 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
     // DCT stage: with n_filters % 4 == 0 the 256-term product folds twice (an even coefficient is 64 terms, an odd one two
     // halves of 64) and 64 lanes cover up to 43 coefficients in one pass; the cosine block is then one 64-term row per lane
     f.dct_fold2 = !mel && M % 4 == 0 && Cc >= 1 && Cc <= 43;
-    f.cos_floats = static_cast<int32_t>(f.dct_fold2 ? 64 * L::kCosLanePitch : Cc * L::kCosPitch);
+    // (fold2: the last lane's row needs no pad behind it -- those 16 bytes are what lets a 12-wave workgroup fit 160 KB of LDS)
+    f.cos_floats = static_cast<int32_t>(f.dct_fold2 ? 63 * L::kCosLanePitch + 64 : Cc * L::kCosPitch);
     const size_t melw0 = static_cast<size_t>(L::kCos) + f.cos_floats;
     f.tab.assign(melw0 + 64 * static_cast<size_t>(f.wpitch), 0.0f);
     const double pi = 3.14159265358979323846;

@@ -51,7 +51,7 @@ constexpr int kTileRows = 32, kTileMels = 128, kTilePitch = 36;  // [mel][row], 
 constexpr int kTileBufs = 3;  // clips a CU may have open at once (its waves run ahead of the slowest by up to kTileBufs - 1 clips)
 constexpr int kTileFloats = kTileBufs * kTileMels * kTilePitch;
 
-template <int kWavesM, bool STFT, bool FULLP = false, bool TILE = false>
+template <int kWavesM, bool STFT, bool FULLP = false, bool TILE = false, bool FIXMEL = false>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
     constexpr bool PREFETCH_M = kWavesM <= 8;  // the next unit's samples are requested while the current one is in its second pass
@@ -75,7 +75,9 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_melw = s_tab + L::kMelW;
-    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+    // behind the table block: 4 words copied with it ([0] = the poll bound of the tile hand-offs), then the unit counter
+    const unsigned *s_ctl = reinterpret_cast<const unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
     float *s_tile = reinterpret_cast<float *>(s_next + 4);                        // TILE: [kTileBufs][32][129]
     // both counters only ever grow, so nobody needs the value its own increment returned: clip c (the g-th user of its
     // buffer, g = (c - c_lo) / kTileBufs) may write the tile once s_fd == kWavesM g, and is complete at s_cnt == pairs (g + 1)
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const unsigned c_hi = static_cast<unsigned>(static_cast<unsigned long long>(a.batch) * (blockIdx.x + 1) / gridDim.x);
 
     {
-        const int n4 = (L::kMelW + 32 * a.mel_wpitch) / 4;
+        const int n4 = (L::kMelW + 32 * a.mel_wpitch + 4) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) {
             const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
@@ -144,29 +146,33 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     // A hand-off that never comes (a protocol error: it cannot happen unless a wave of this workgroup died or the counters
     // were corrupted) must neither hang nor pass for a result.  The waits are bounded; a wave that runs into the bound sets
     // the config's device error word (pinned host memory, so the host sees it without a copy: ss_api.hip turns it into
-    // SS_ERR_DEVICE at the next launch / synchronisation point on the config) and stops producing: it writes nothing more
-    // into the tile, flushes nothing, takes no further unit.  Its peers then run into their own bounds and stop as well.
+    // SS_ERR_DEVICE at the next launch / synchronisation point on the config) and ends (s_endpgm): it writes nothing more
+    // into the tile, flushes nothing, takes no further unit.  Its peers then run into their own bounds and end as well.
     // (A trap measured 2 us on the whole launch; NaNs in the output could be overwritten by a later flush.)
-    bool dead = false;  // wave-uniform
+    // (Everything about this lives on the cold side of a branch, behind ONE kernel argument: the kernel sits at the SGPR limit
+    // and every extra argument or flag on the hot path measured +1 us of 49.)
     auto protocol_error = [&]() {
-        if (lane == 0 && a.err) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        dead = true;
+        if (lane == 0 && a.ctl) __hip_atomic_store(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);  // the store has left the wave
+        __builtin_amdgcn_endpgm();       // the wave ends here: no flag to test anywhere on the hot path
     };
+    // polls before a hand-off counts as lost: the word behind the table block, copied into LDS with it (2^24 in normal operation:
+    // ~0.5 s; ss_debug_tile_fault sets 0, so that the first wait that is not satisfied at once takes the error path).  An LDS
+    // read on purpose: a global load here would wait on vmcnt, i.e. for this wave's outstanding output stores (+2 us of 49).
+    auto spin_limit = [&]() { return peek(s_ctl); };
     auto flush_share = [&](unsigned upto, bool wait) {
         while (fl_next < upto) {
             const unsigned fb = (fl_next - c_lo) % kTileBufs;
             const unsigned full = tile_full(fl_next);
             if (peek(s_cnt + fb) != full) {
                 if (!wait) return;
+                const unsigned lim = spin_limit();
                 unsigned tries = 0;
-                while (peek(s_cnt + fb) != full && tries < a.spin_limit) {
+                while (peek(s_cnt + fb) != full && tries < lim) {
                     __builtin_amdgcn_s_sleep(1);
                     ++tries;
                 }
-                if (tries >= a.spin_limit) {
-                    protocol_error();
-                    return;
-                }
+                if (peek(s_cnt + fb) != full) protocol_error();
             }
             flush_one();
         }
@@ -272,9 +278,15 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     }
                 }
                 wave_order();
+                // The pass-2 twiddles are all requested here, right behind the exchange's reads and in front of the first product:
+                // read where they are used they came a pair at a time, each one exposed LDS round trip (with two waves per SIMD
+                // nobody hides it).
                 // the window registers are dead now: the next unit's samples load into them while this one is finished
                 if (TILE && fl_next < clip && seen_cnt == tile_full(fl_next)) flush_one();
                 if (PREFETCH_M && next < u_hi) load_unit(next, v);
+                // (Requesting the sixteen twiddle pairs in one or two batches in front of the products, or reading the unit claim
+                // late, measured within +-0.3 us here -- unlike in the 4096-point kernel -- and perturbs this kernel's register
+                // allocation, which is at the SGPR limit: left as the compiler schedules it.)
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {  // two twiddles per ds_read_b128: W^(j(2p+1)), W^(j(2p+2))
                     const float4 w2 = s_tw2[p];
@@ -345,7 +357,12 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 if (TILE) {
                     const unsigned b = (clip - c_lo) % kTileBufs;
                     float mv[4];
-                    {
+                    if constexpr (FIXMEL) {
+                        // cfg3's bank shape (128 filters up to 8 kHz: 6 / 3 / 2 / 1 float4s per slot): every weight and tap is
+                        // requested before the first FMA -- one LDS wait for the stage
+                        mel4_fixed2<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
+                                               reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mv);
+                    } else {
                         int off = 0;
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
@@ -358,16 +375,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     for (unsigned tries = 0; seen_fd != freed && peek(s_fd + b) != freed; ++tries) {
                         flush_share(clip, false);  // the buffer may be waiting for this very wave's share of an older clip
                         __builtin_amdgcn_s_sleep(1);
-                        if (tries > a.spin_limit) {  // the buffer still belongs to an older clip: do not touch it
-                            protocol_error();
-                            break;
-                        }
-                    }
-                    if (dead) break;
-                    if (a.fault && wave == 0) {  // test aid: this wave's row pairs never arrive
-                        if (!PREFETCH_M && next < u_hi) load_unit(next, v);
-                        unit = next;
-                        continue;
+                        if (tries > (1u << 24)) protocol_error();  // the buffer still belongs to an older clip: do not touch it
                     }
                     float *tcol = s_tile + b * (kTileMels * kTilePitch) + r;
                     if (in_rows) {
@@ -379,10 +387,14 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     if (lane == 0) atomicAdd(s_cnt + b, 1u);
                 } else if (in_rows) {
                     float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+                    float mfix[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FIXMEL)
+                        mel4_fixed2<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
+                                               reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mfix);
                     int off = 0;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float m = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                        const float m = FIXMEL ? mfix[s] : mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                         off += a.mel_q4[s];
                     }
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         if (!PREFETCH_M && next < u_hi) load_unit(next, v);
         unit = next;
     }
-    if (TILE && !dead) {
+    if (TILE) {
         // out of units: what is left of the range's last clips (bounded wait for rows other waves are still computing)
         flush_share(c_hi, true);
     }
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 template <int kWavesM>
 hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 4 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // whole-line stores through the CU-wide tile: mel output, every CU at least one clip, the tile fits next to everything else
     const size_t lds_tile = lds + (kTileFloats + 2 * kTileBufs + 2) * sizeof(float);
@@ -422,9 +434,13 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
         return hipGetLastError();
     };
+    const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+    // (the fixed-shape mel stage costs this kernel 84 bytes of scratch per lane beside the prefetched unit: measured 77 us against
+    // 50; the run-time loops stay, with their remainders fetched in one batch)
     if (tile) return go(ss_mel_c1024<kWavesM, false, false, true>, "ss_mel_c1024<tile>");
     if (a.out_stft) return go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>");
     if (a.fullp) return go(ss_mel_c1024<kWavesM, false, true>, "ss_mel_c1024<fullp>");
+    (void)m6321;
     return go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
 }
 

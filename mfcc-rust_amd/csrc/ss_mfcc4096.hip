@@ -95,7 +95,7 @@ __device__ __forceinline__ void swap_halves(float &a, float &b)
 
 
 template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false, bool FIXMEL = false>
-__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a)
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfcc4096Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -104,6 +104,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
     const int k1 = lane & 31, d = lane >> 5;  // reader view: column k1, half a = d
     const int cls = lane & 1, bw = lane >> 1; // writer view: n1 = lane = cls + 2 bw
 
+    // (12-wave experiment: no pad between the two class slices, so that 12 regions + the tables are exactly 160 KB)
+    constexpr int kClsStride = WAVES > 8 ? 16 * 34 : ss::kClsStride;
+    constexpr int kExFloats = (kClsStride + 16 * 34) * 2;
     float *wbase = reinterpret_cast<float *>(smem) + wave * kExFloats;
     float2 *ex = reinterpret_cast<float2 *>(wbase);
     float *prow = wbase;             // P[0..1024] + zero pad bins, after the exchange
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
         // (The stage's lane-dependent addresses are loop invariants: the compiler keeps them across the transform and spills
         // three of them to scratch -- 1.5 MB of extra writes per cfg5 launch.  Re-deriving them per frame from an opaque copy
         // of the lane number removes the spills and measured 1.1 us slower, so they stay.)
-        if (a.dct_fold2) {
+        if (FIXMEL || a.dct_fold2) {  // (the FIXMEL build is only launched with the twice-folded table: no generic DCT code in it)
             float *seg = wbase + kSRowOff;
             {
                 const int m2 = lane + 64;
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c2048(const Mfcc4096Args a
             frame = __builtin_amdgcn_readfirstlane(next_v);
             continue;
         }
+        if constexpr (FIXMEL) continue;  // (unreachable: the twice-folded path above always leaves the iteration)
         // Other shapes (n_filters not a multiple of 4, more than 43 coefficients): one fold, cosine rows [c][kCosPitch].
         // ---- DCT-II (feature.rs:120-123) with cos(pi c (2(M-1-m)+1) / 2M) = (-1)^c cos(pi c (2m+1) / 2M), M = 256:
         // the wave first forms s[m] = L[m] + L[255-m] and d[m] = L[m] - L[255-m] once (2 + 2 values per lane); an even
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
 template <int WAVES>
 hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.cos_floats) +
+    const size_t lds = (static_cast<size_t>(WAVES) * (WAVES > 8 ? 16 * 34 * 4 : kExFloats) + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.cos_floats) +
                         64 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
@@ -822,7 +826,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         return pow2 ? go(ss_mfcc_c2048<false, true, WAVES, true>, "ss_mfcc_c2048<pow2,mfe>") : go(ss_mfcc_c2048<false, false, WAVES, true>, "ss_mfcc_c2048<mfe>");
     }
     const bool m8321 = a.mel_q4[0] == 8 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
-    if (exact && m8321 && !pow2) return go(ss_mfcc_c2048<true, false, WAVES, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321>");
+    if (exact && m8321 && !pow2 && a.dct_fold2) return go(ss_mfcc_c2048<true, false, WAVES, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321>");
     if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
     return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
 }
@@ -831,6 +835,13 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
 
 hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
+#if SS_LAB
+    static const char *w = std::getenv("SS_WAVES5");  // A/B knob (lab build): 12 waves per CU at <= 168 VGPRs
+    if (w && std::atoi(w) == 12) {
+        const hipError_t e = launch_h<12>(a, stream, num_cus, info);
+        if (e != hipErrorInvalidValue) return e;
+    }
+#endif
     return launch_h<8>(a, stream, num_cus, info);
 }
 

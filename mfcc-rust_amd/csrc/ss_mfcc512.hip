@@ -317,7 +317,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
                 if (idx < n4) reinterpret_cast<float4 *>(s_tab)[idx] = tv[k];
             }
         }
-        if (a.dbg) stamp(5, __builtin_amdgcn_s_memrealtime());  // table waves: when the tables were in LDS
+        // table waves: when the tables were in LDS, as 100 MHz ticks since this wave's start stamp, flagged 2 in bits 40..41 (the
+        // other waves flag their cycle count 1 there; an absolute stamp would carry either flag by accident, depending on uptime)
+        if (a.dbg && lane == 0) {
+            unsigned long long *d = a.dbg + 6ull * (blockIdx.x * WAVES + wave);
+            d[5] = ((__builtin_amdgcn_s_memrealtime() - d[0]) & ((1ull << 40) - 1)) | (2ull << 40);
+        }
     }
     {
         if (tid == 0) *s_next = q_lo + WAVES;

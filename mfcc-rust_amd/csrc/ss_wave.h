@@ -117,6 +117,54 @@ __device__ __forceinline__ void mel4_fixed(const float4 *w4, const float4 *p0, c
     }
 }
 
+// The same in two groups (slot 0, then slots 1..3): two LDS waits, half the registers in flight -- for kernels that hold a
+// prefetched unit in registers across the mel stage.
+template <int Q0, int Q1, int Q2, int Q3>
+__device__ __forceinline__ void mel4_fixed2(const float4 *w4, const float4 *p0, const float4 *p1, const float4 *p2, const float4 *p3, float (&m)[4])
+{
+    {
+        float4 w[Q0], t[Q0];
+#pragma unroll
+        for (int i = 0; i < Q0; ++i) {
+            w[i] = w4[i];
+            t[i] = p0[i];
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < Q0; ++i) {
+            acc = fmaf(w[i].x, t[i].x, acc);
+            acc = fmaf(w[i].y, t[i].y, acc);
+            acc = fmaf(w[i].z, t[i].z, acc);
+            acc = fmaf(w[i].w, t[i].w, acc);
+        }
+        m[0] = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int QR = Q1 + Q2 + Q3;
+    float4 w[QR], t[QR];
+#pragma unroll
+    for (int i = 0; i < QR; ++i) w[i] = w4[Q0 + i];
+#pragma unroll
+    for (int i = 0; i < Q1; ++i) t[i] = p1[i];
+#pragma unroll
+    for (int i = 0; i < Q2; ++i) t[Q1 + i] = p2[i];
+#pragma unroll
+    for (int i = 0; i < Q3; ++i) t[Q1 + Q2 + i] = p3[i];
+    constexpr int lo[4] = {0, Q1, Q1 + Q2, QR};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = lo[s]; i < lo[s + 1]; ++i) {
+            acc = fmaf(w[i].x, t[i].x, acc);
+            acc = fmaf(w[i].y, t[i].y, acc);
+            acc = fmaf(w[i].z, t[i].z, acc);
+            acc = fmaf(w[i].w, t[i].w, acc);
+        }
+        m[1 + s] = acc;
+    }
+}
+
 // sum over the wave
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -154,12 +202,26 @@ __device__ __forceinline__ float mel_slot4(const float4 *w4, const float4 *p4, i
             acc = fmaf(w[u].w, t[u].w, acc);
         }
     }
-    for (; i < q4; ++i) {
-        const float4 w = w4[i], t = p4[i];
-        acc = fmaf(w.x, t.x, acc);
-        acc = fmaf(w.y, t.y, acc);
-        acc = fmaf(w.z, t.z, acc);
-        acc = fmaf(w.w, t.w, acc);
+    // the remainder (1..3 pairs) in ONE batch as well: a pair at a time it was one exposed LDS round trip per pair
+    const int rem = q4 - i;
+    if (rem > 0) {
+        float4 w[3], t[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (u < rem) {
+                w[u] = w4[i + u];
+                t[u] = p4[i + u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (u < rem) {
+                acc = fmaf(w[u].x, t[u].x, acc);
+                acc = fmaf(w[u].y, t[u].y, acc);
+                acc = fmaf(w[u].z, t[u].z, acc);
+                acc = fmaf(w[u].w, t[u].w, acc);
+            }
+        }
     }
     return acc;
 }

@@ -18,7 +18,9 @@ if d.shape[1] >= 8:
         cycles = (raw[cyc] - (1 << 40)).astype(np.float64)
         life_us = (d[cyc, 3] - d[cyc, 1]) / 100.0
         print(f"shader clock over the waves' lifetime: mean {np.mean(cycles / life_us):.0f} MHz  (min {np.min(cycles / life_us):.0f}, max {np.max(cycles / life_us):.0f})")
-    tab = last[~cyc & (d[:, 7] != 0)]  # only the workgroup's table waves stamp this
+    # only the workgroup's table waves stamp this: ticks since the wave's start, flagged 2 in bits 40..41
+    tabm = (raw >> 40) == 2
+    tab = (st + (raw & ((1 << 40) - 1)) / 100.0)[tabm]
     if len(tab):
         cols += [("table_in_lds", np.pad(tab, (0, len(first) - len(tab)), mode="edge"))]
 for name, v in cols:
