@@ -1055,8 +1055,8 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
             cis(static_cast<double>(k1 + 32 * (i + 16 * hh)), 2048.0, &f.tab[L::kT2 + (i * 64 + lane) * 2]);
             cis(static_cast<double>(k1 + 32 * i + 512 * hh), 4096.0, &f.tab[L::kTwn + (i * 64 + lane) * 2]);
         }
-    int32_t *start = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
-    int32_t *filt = reinterpret_cast<int32_t *>(f.tab.data() + L::kFilt);
+    // one word per (slot, lane): first P bin | filter index << 16 (one register in the kernel; one table less in its LDS)
+    std::vector<int32_t> start(256, 0), filt(256, -1);
     int32_t off = 0;
     for (int s = 0; s < 4; ++s) {
         const int32_t span = 4 * f.q4[s];
@@ -1085,6 +1085,10 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
                 f.tab[melw0 + static_cast<size_t>(j) * f.wpitch + off + shift + i] = t.bank.w[t.bank.off[m] + i];
         }
         off += span;
+    }
+    {
+        int32_t *packed = reinterpret_cast<int32_t *>(f.tab.data() + L::kStart);
+        for (int q = 0; q < 256; ++q) packed[q] = (start[q] & 0xffff) | static_cast<int32_t>(static_cast<uint32_t>(filt[q]) << 16);
     }
     if (f.dct_fold2) {
         // lane assignment of ss_mfcc_c2048's product stage: lanes 0 .. ne-1 the even coefficients 2 lane (filters 0 .. M/4-1),

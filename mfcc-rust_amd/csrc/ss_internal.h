@@ -224,9 +224,8 @@ namespace mfcc4096_layout {
 constexpr int kT1 = 0;                    // [16][32] float4: (W^(k1(2p+1)), W^(k1(2p+2))), W = exp(-2 pi i / 1024)
 constexpr int kT2 = kT1 + 16 * 128;       // [16][64] float2: exp(-2 pi i (k1 + 32 (i + 16 h)) / 2048), lane = k1 + 32 h
 constexpr int kTwn = kT2 + 16 * 128;      // [16][64] float2: exp(-2 pi i (k1 + 32 i + 512 h) / 4096)
-constexpr int kStart = kTwn + 16 * 128;   // [4][64] int32: first P bin of the filter owned by (slot, lane)
-constexpr int kFilt = kStart + 256;       // [4][64] int32: filter index of (slot, lane), -1 if none
-constexpr int kCos = kFilt + 256;         // [n_ceps][132]: cos(pi c (2m+1) / 2M), m < 128 (the other half by symmetry)
+constexpr int kStart = kTwn + 16 * 128;   // [4][64] int32: (slot, lane) -> first P bin of its filter (low 16 bits) | filter index << 16 (-1: none)
+constexpr int kCos = kStart + 256;        // [n_ceps][132]: cos(pi c (2m+1) / 2M), m < 128 (the other half by symmetry)
 constexpr int kCosPitch = 132;
 constexpr int kCosLanePitch = 68;         // dct_fold2 layout: [64 lanes][68], the 64 cosines of the lane's share of its coefficient
 constexpr int kPRow = 1032;               // floats per P row: bins 0..1024 + zero pad bins

@@ -25,28 +25,14 @@
 #include <cstdlib>
 #include <type_traits>
 
-// SS_TOUCH=1: one load per 128-byte line of the frame that is claimed about one iteration from now (pulls its new samples
-// into L2 ahead of the sample loads).  Measured: -0.9 % time, but +57 % HBM fetch traffic (lines evicted again before their
-// use: 8 waves x 16 KB per CU against a 4 MB L2 shared by 32 CUs) -- off.
 // timing-attribution builds (lab build only, tools/ablate.sh; results wrong by design): 1 no DCT, 2 no mel + DCT, 4 no partner
-// fetch, 8 no exchange.  The product build compiles both switches out.
+// fetch, 8 no exchange, 16 every frame reads clip 0 (L2-resident samples), 32 no sample loads.  The product build compiles the
+// switch out.
 #if !SS_LAB
-#undef SS_TOUCH
 #undef SS_ABL5
-#endif
-#ifndef SS_TOUCH
-#define SS_TOUCH 0
 #endif
 #ifndef SS_ABL5
 #define SS_ABL5 0
-#endif
-// experiment switches (lab builds): bit 0 the next frame's samples are requested from inside the untangle, two loads per
-// step, into the (dead) input registers of the transform
-#if !SS_LAB
-#undef SS_X5
-#endif
-#ifndef SS_X5
-#define SS_X5 0
 #endif
 // SS_PROF5 (lab builds, with SS_DEBUG_ROWS=<file>): every wave sums the shader-clock ticks it spends in each phase of its
 // iterations (s_memtime at the phase boundaries; the wait for the stamp also drains the phase's LDS operations) and writes 16
@@ -101,12 +87,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
-    const int k1 = lane & 31, d = lane >> 5;  // reader view: column k1, half a = d
-    const int cls = lane & 1, bw = lane >> 1; // writer view: n1 = lane = cls + 2 bw
-
-    // (12-wave experiment: no pad between the two class slices, so that 12 regions + the tables are exactly 160 KB)
-    constexpr int kClsStride = WAVES > 8 ? 16 * 34 : ss::kClsStride;
-    constexpr int kExFloats = (kClsStride + 16 * 34) * 2;
+    // LEAN: twelve waves per CU (three per SIMD) at <= 168 VGPRs.  Every table read comes in batches of at most eight float4s
+    // (a third wave on the SIMD hides the round trips the 8-wave build has to avoid) and what depends on the lane number only
+    // is derived again in every iteration instead of living in registers: twelve exchange regions + the tables are 163 584 of
+    // the 163 840 bytes of LDS.
+    constexpr bool LEAN = WAVES > 8;
     float *wbase = reinterpret_cast<float *>(smem) + wave * kExFloats;
     float2 *ex = reinterpret_cast<float2 *>(wbase);
     float *prow = wbase;             // P[0..1024] + zero pad bins, after the exchange
@@ -116,7 +101,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
-    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_cos = s_tab + L::kCos;
     const int Cc = static_cast<int>(a.n_ceps);
     const int melw0 = L::kCos + a.cos_floats;
@@ -138,38 +122,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         if (tid == 0) *s_next = f_lo + WAVES;
     }
     __syncthreads();
-    int st[4], fi[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        st[s] = s_start[s * 64 + lane];
-        fi[s] = s_filt[s * 64 + lane];
-    }
-    const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * a.mel_wpitch);
-    const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
-    float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
-    const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
     const float hscale32 = (POW2 ? 0.25f * a.scale : 0.5f * a.scale) * kTwo32;
-    const bool k1z = k1 == 0;
     const int M = static_cast<int>(a.n_filters), Mh = M / 2;
     constexpr bool pre = PRE;  // fused pre-emphasis: builds of their own (the taps cost registers the plain builds do not have)
     const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
     unsigned frame = f_lo + wave;
-    float touch = 0.f;
-    constexpr bool PF = (SS_X5 & 1) && EXACT && !PRE && !WIN;
-    // bit 1: only the part of the next frame that is new to the CU's caches (its last flen - (flen - step) samples: register
-    // pairs 24..31 at hop = flen / 4) is requested early; the overlap with the frames before it loads at the top as before
-    constexpr bool PQ = (SS_X5 & 2) && EXACT && !PRE && !WIN;
-    auto frame_src = [&](unsigned fr) {
-        const unsigned c = fr / a.n_frames;
-        return reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(c) * a.ld + (fr - c * a.n_frames) * a.step) + lane;
-    };
-    float2 v[32];
-    if (PF || PQ) {
-        const float2 *s0 = frame_src(min(frame, f_hi - 1));
-#pragma unroll
-        for (int e = PQ ? 24 : 0; e < 32; ++e) v[e] = s0[64 * e];
-    }
 #if SS_PROF5
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -178,6 +136,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     while (frame < f_hi) {
         // the claim of the next frame is issued here and read where it is needed (the end of the iteration): the LDS atomic's
         // round trip hides behind the transform
+        // What depends on the lane number only.  8 waves per CU: loop invariants, the compiler keeps them in registers across
+        // the iterations.  LEAN: the lane number is made opaque here, so that they are derived again in every iteration
+        // (~40 integer instructions per frame) instead of occupying ~40 of the 168 registers for the whole kernel.
+        int lane_it = static_cast<int>(threadIdx.x) & 63;
+        if (LEAN) asm volatile("" : "+v"(lane_it));
+        const int lane = lane_it;
+        const int k1 = lane & 31, d = lane >> 5;   // reader view: column k1, half a = d
+        const int cls = lane & 1, bw = lane >> 1;  // writer view: n1 = lane = cls + 2 bw
+        const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * a.mel_wpitch);
+        const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
+        float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
+        const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
+        const bool k1z = k1 == 0;
         unsigned next_v = 0;
         if (lane == 0) next_v = atomicAdd(s_next, 1u);
 #if SS_PROF5
@@ -190,9 +161,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
         // (SS_ABL5 & 16: every frame reads clip 0 -- L2-resident samples; & 32: no sample loads at all)
         const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step) + lane;
+        float2 v[32];
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
-            if (PF || (PQ && e >= 24)) break;
             if (SS_ABL5 & 32) {
                 v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(frame & 255u));
                 continue;
@@ -208,19 +179,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
                 if (rem >= 1) v[e].x = fmaf(-a.preemph, preemph_tap(xc, pos, psh, a.n_samples), v[e].x);
                 if (rem >= 2) v[e].y = fmaf(-a.preemph, preemph_tap(xc, pos + 1, psh, a.n_samples), v[e].y);
             }
-        }
-        if (SS_TOUCH) {
-            // The frames of a workgroup's range are claimed in order, so frame next + WAVES is asked for about one iteration
-            // from now by a wave of this CU; of its samples only the last `step` are new to the CU's caches.  One load per
-            // 128-byte line pulls them into L2 now (issued behind this frame's own loads: loads return in order), so that
-            // the sample loads at the top of an iteration hit instead of waiting for HBM.
-            asm volatile("" ::"v"(touch));  // the previous touch has long returned; keeps its register live until here
-            // (no branch around the load: behind a conditional load the compiler has to wait for vmcnt(0), i.e. for the touch)
-            const unsigned tf = min(__builtin_amdgcn_readfirstlane(next_v) + WAVES, total - 1);
-            const unsigned clip_t = tf / a.n_frames, t_t = tf - clip_t * a.n_frames;
-            const float *pt = a.x + static_cast<unsigned long long>(clip_t) * a.ld + t_t * a.step + (a.flen > a.step ? a.flen - a.step : 0u) + (lane & 31) * 32;
-            const float *last = a.x + static_cast<unsigned long long>(a.batch - 1) * a.ld + a.n_samples - 1;
-            touch = *(pt < last ? pt : last);
         }
         if (WIN) {
             // optional frame window (mfcc_window switch): sample pairs from the copy in LDS
@@ -244,6 +202,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         }
         // ---- transpose (two 32 x 32 problems: even and odd n1), in two register halves ----
         float2 u[32];
+        if (LEAN) {
+            // Every lane fills u in ONE of the two half-wave phases below.  Left half-defined, the "undefined" halves are carried
+            // around the loop and spilled (132 bytes of scratch at 168 VGPRs); sixty-four moves in front define them.  (Running
+            // the first phase's reads on all lanes instead -- lanes k1 >= 16 reading the column of lane k1 - 16, a broadcast --
+            // needs no moves and 14 registers fewer, and measured 1.7 % slower.)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) u[k] = make_float2(0.f, 0.f);
+        }
         if (SS_ABL5 & 8) {
 #pragma unroll
             for (int k = 0; k < 32; ++k) u[k] = v[k];
@@ -280,17 +246,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // The pass-2 twiddles are all requested here, right behind the exchange's reads and in front of the first product: read
         // where they are used, they came two at a time, each pair one exposed LDS round trip (nobody hides it with two waves per
         // SIMD).  (Requested before the exchange they are live across it and 19 loop invariants spill.)
-        float4 tw1[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) tw1[p] = s_t1[p * 32 + k1];
-        __builtin_amdgcn_sched_barrier(0);
+        // (LEAN: two batches of eight)
         SS_PH(4);  // exchange
         // ---- twiddle W1024^(b k1), radix-32 over b, twiddle W2048^(a (k1 + 32 c)) ----
+        constexpr int kTwBatch = LEAN ? 8 : 16;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const float4 w2 = tw1[p];
-            u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
-            if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
+        for (int pb = 0; pb < 16; pb += kTwBatch) {
+            float4 tw1[kTwBatch];
+#pragma unroll
+            for (int p = 0; p < kTwBatch; ++p) tw1[p] = s_t1[(pb + p) * 32 + k1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < kTwBatch; ++p) {
+                const float4 w2 = tw1[p];
+                u[2 * (pb + p) + 1] = cmul(u[2 * (pb + p) + 1], make_float2(w2.x, w2.y));
+                if (pb + p < 15) u[2 * (pb + p) + 2] = cmul(u[2 * (pb + p) + 2], make_float2(w2.z, w2.w));
+            }
         }
         SS_PH(5);  // twiddles
         fft_reg<32>(u);  // u[c] = G_a[c], a = lane >> 5
@@ -332,28 +303,37 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // All 16 untangle twiddles and all 32 partner values are requested here, before the stage's first LDS write: a read
         // may not move above an earlier write of the same wave, so twiddles fetched inside the loop below came one LDS round
         // trip per bin pair (16 dependent round trips per frame, a quarter of the wave's time with two waves per SIMD).
-        float2 twn[16];
+        // first P bin (low 16 bits) and filter index (high 16 bits, -1: none) of this lane's four slots, one register each
+        // (requested here, with the untangle's table reads, for the mel stage behind it)
+        int sf[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) twn[i] = s_twn[i * 64 + lane];
-        if (lane < 3) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        for (int s = 0; s < 4; ++s) sf[s] = s_start[s * 64 + lane];
+        auto st = [&](int s) { return sf[s] & 0xffff; };
+        auto fi = [&](int s) { return sf[s] >> 16; };
+        // (LEAN: two batches of eight bin pairs, each with its own twiddle and partner fetches)
+        constexpr int kUb = LEAN ? 8 : 16;
+        if (lane < 3 && !LEAN) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
 #pragma unroll
-        for (int hb = 0; hb < 1; ++hb) {
-            float2 zcs[16];
+        for (int hb = 0; hb < 16 / kUb; ++hb) {
+            float2 twn[kUb];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i = q;
+            for (int q = 0; q < kUb; ++q) twn[q] = s_twn[(kUb * hb + q) * 64 + lane];
+            float2 zcs[kUb];
+#pragma unroll
+            for (int q = 0; q < kUb; ++q) {
+                const int i = kUb * hb + q;
                 const float2 sv = k1z ? r1[(16 - i) & 15] : r1[15 - i];
                 zcs[q] = (SS_ABL5 & 4) ? sv : make_float2(bperm(paddr, sv.x), bperm(paddr, sv.y));
             }
             __builtin_amdgcn_sched_barrier(0);  // all 32 fetches are in flight before the first bin pair is formed (the scheduler
                                                 // otherwise sinks each next to its use: one exposed round trip per pair)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i = q;
+            for (int q = 0; q < kUb; ++q) {
+                const int i = kUb * hb + q;
                 const float2 zk = r0[i];
                 float2 zc = zcs[q];
                 if (i == 0) zc = k1z ? (d ? r1[0] : zk) : zc;
-                const float2 w = twn[i];
+                const float2 w = twn[q];
                 const float2 s = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
                 const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
                 // 2 X[k] = s - i w dd, 2 conj X[2048-k] = s + i w dd = 2 s - 2 X[k]
@@ -368,6 +348,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
 
             }
         }
+        if (lane < 3 && LEAN) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
         if (lane == 0) {
             const float2 z = r1[0];  // X[1024] = conj Z[1024]
             const float n = 4.f * (z.x * z.x + z.y * z.y);
@@ -379,15 +360,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
         SS_PH(8);  // untangle + magnitudes + energy
-        auto prefetch_next = [&]() {
-            // the transform's registers are free: the next frame's samples are requested now and arrive under the stages that
-            // follow (a wave's last iteration fetches its range's last frame again and drops it)
-            const float2 *nsrc = frame_src(min(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)), f_hi - 1));
-#pragma unroll
-            for (int e = PQ ? 24 : 0; e < 32; ++e) v[e] = nsrc[64 * e];
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if ((PF || PQ) && !(SS_X5 & 8)) prefetch_next();
 
         if (SS_ABL5 & 2) {
             if (lane < Cc) a.out[static_cast<unsigned long long>(frame) * Cc + lane] = energy;
@@ -402,16 +374,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             float mfix[4] = {0.f, 0.f, 0.f, 0.f};
             constexpr bool fixed8321 = FIXMEL;  // the launcher checked a.mel_q4 == {8, 3, 2, 1}
             if (fixed8321)
-                mel4_fixed<8, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
-                                       reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mfix);
+                mel4_fixed<8, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st(0)), reinterpret_cast<const float4 *>(prow + st(1)),
+                                       reinterpret_cast<const float4 *>(prow + st(2)), reinterpret_cast<const float4 *>(prow + st(3)), mfix);
             int off = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float m = hscale32 * (fixed8321 ? mfix[s] : mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]));
+                float m = hscale32 * (fixed8321 ? mfix[s] : mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st(s)), a.mel_q4[s]));
                 m = m == 0.f ? kEps * kTwo32 : m;
-                if (fi[s] >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
-                    if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi[s]] = m * (1.0f / kTwo32);  // exact: power of two
-                    else frow[fi[s]] = ln_scaled(m);
+                if (fi(s) >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
+                    if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi(s)] = m * (1.0f / kTwo32);  // exact: power of two
+                    else frow[fi(s)] = ln_scaled(m);
                 }
                 off += a.mel_q4[s];
             }
@@ -423,7 +395,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             continue;
         }
         wave_order();
-        if ((PF || PQ) && (SS_X5 & 8)) prefetch_next();
         SS_PH(9);  // mel + ln
         if (!SS_PROF5 && a.dbg && frame == 0) {
             for (int i = lane; i < 1028; i += 64) a.dbg[i] = prow[i];
@@ -468,7 +439,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             const float4 *r4 = reinterpret_cast<const float4 *>(seg + sk * kSegPitch);
             const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + lane * L::kCosLanePitch);
             float acc = 0.f;
-            constexpr int kChunk = (SS_X5 & 4) ? 4 : 16;  // float4 pairs fetched per LDS wait (16: one wait, 128 registers)
+            constexpr int kChunk = LEAN ? 8 : 16;  // float4 pairs fetched per LDS wait (16: one wait, 128 registers)
 #pragma unroll
             for (int c0 = 0; c0 < 16; c0 += kChunk) {
                 float4 rq[kChunk], cq[kChunk];
@@ -602,7 +573,6 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
     const float2 *s_t2 = reinterpret_cast<const float2 *>(s_tab + L::kT2);
     const float2 *s_twn = reinterpret_cast<const float2 *>(s_tab + L::kTwn);
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
-    const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_melw = s_tab + L::kCos;
     const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + L::kCos + 64 * a.mel_wpitch);
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kCos + 64 * a.mel_wpitch + 4096);
@@ -617,11 +587,12 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
         if (tid == 0) *s_next = f_lo + WAVES;
     }
     __syncthreads();
-    int st[4], fi[4];
+    int st[4], fi[4];  // first P bin and filter index (-1: none) of this lane's four slots (one packed table word each)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        st[s] = s_start[s * 64 + lane];
-        fi[s] = s_filt[s * 64 + lane];
+        const int pk = s_start[s * 64 + lane];
+        st[s] = pk & 0xffff;
+        fi[s] = pk >> 16;
     }
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * a.mel_wpitch);
     const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
@@ -784,7 +755,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
 template <int WAVES>
 hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(WAVES) * (WAVES > 8 ? 16 * 34 * 4 : kExFloats) + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.cos_floats) +
+    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + (a.window ? 4096 : 0) + L::kCos + static_cast<size_t>(a.cos_floats) +
                         64 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned long long total = static_cast<unsigned long long>(a.batch) * a.n_frames;
@@ -803,6 +774,14 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096 && a.preemph == 0.f;
+    if constexpr (WAVES == 12) {
+        // only the default cfg5 shape (exact frames, magnitude spectrum, 8/3/2/1 bank, twice-folded DCT, no window / mfe) has a
+        // 12-wave build
+        const bool lean_ok = exact && !pow2 && !a.window && !a.out_mfe && a.dct_fold2 && a.mel_q4[0] == 8 && a.mel_q4[1] == 3 &&
+                             a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+        if (!lean_ok) return hipErrorInvalidValue;
+        return go(ss_mfcc_c2048<true, false, 12, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321,w12>");
+    } else {
     if (a.preemph != 0.f) {  // fused pre-emphasis builds (run-time frame length)
 #define SS_HP(P2, MF, WN, NAME) go(ss_mfcc_c2048<false, P2, WAVES, MF, WN, true>, NAME)
         if (a.window) {
@@ -829,19 +808,19 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
     if (exact && m8321 && !pow2 && a.dct_fold2) return go(ss_mfcc_c2048<true, false, WAVES, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321>");
     if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
     return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
+    }
 }
 
 }  // namespace
 
 hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-#if SS_LAB
-    static const char *w = std::getenv("SS_WAVES5");  // A/B knob (lab build): 12 waves per CU at <= 168 VGPRs
-    if (w && std::atoi(w) == 12) {
+    // the default cfg5 shape has a build with three waves per SIMD (12 per CU, <= 168 VGPRs): 63.4 us against 72.1 for the
+    // 8-wave build on one box; everything else (and that shape where 12 regions do not fit the LDS) takes the 8-wave builds
+    {
         const hipError_t e = launch_h<12>(a, stream, num_cus, info);
         if (e != hipErrorInvalidValue) return e;
     }
-#endif
     return launch_h<8>(a, stream, num_cus, info);
 }
 

@@ -42,8 +42,14 @@ static void check_mel_block(const std::string &what, const ss::HostTables &t, co
                             int LANES, const int32_t *q4, int wpitch, int prow_bins)
 {
     const size_t M = t.params.num_filters, F = t.d.n_bins;
-    const int32_t *start = reinterpret_cast<const int32_t *>(tab.data() + k_start);
-    const int32_t *filt = reinterpret_cast<const int32_t *>(tab.data() + k_filt);
+    // k_filt < 0: one packed word per (slot, lane) at k_start -- first bin | filter index << 16 (the 4096-point layout)
+    std::vector<int32_t> start_v(static_cast<size_t>(S) * LANES), filt_v(static_cast<size_t>(S) * LANES);
+    for (size_t q = 0; q < start_v.size(); ++q) {
+        const int32_t w = reinterpret_cast<const int32_t *>(tab.data() + k_start)[q];
+        start_v[q] = k_filt < 0 ? (w & 0xffff) : w;
+        filt_v[q] = k_filt < 0 ? (w >> 16) : reinterpret_cast<const int32_t *>(tab.data() + k_filt)[q];
+    }
+    const int32_t *start = start_v.data(), *filt = filt_v.data();
     CHECK(melw0 + static_cast<size_t>(LANES) * wpitch <= tab.size(), "mel block past the table (%zu + %d x %d > %zu)", melw0, LANES, wpitch, tab.size());
     if (melw0 + static_cast<size_t>(LANES) * wpitch > tab.size()) return;
     std::vector<int> seen(M, 0);
@@ -179,7 +185,7 @@ int main(int argc, char **argv)
             ++built[8 + mel];
             namespace L = ss::mfcc4096_layout;
             const std::string what = std::string(name) + (mel ? " mel4096" : " mfcc4096");
-            check_mel_block(what, t, f.tab, L::kStart, L::kFilt, static_cast<size_t>(L::kCos) + f.cos_floats, 4, 64, f.q4, f.wpitch, 1028);
+            check_mel_block(what, t, f.tab, L::kStart, -1, static_cast<size_t>(L::kCos) + f.cos_floats, 4, 64, f.q4, f.wpitch, 1028);
             if (mel) continue;
             // cosine block: what the kernel's DCT stage multiplies must be the host DCT table
             if (f.dct_fold2) {

@@ -76,7 +76,9 @@ int main()
         if (ss::build_tables(p, t) == 0) ss::build_mfcc4096(t, f);
         if (!f.ok) { std::printf("cfg5: no table\n"); rc = 1; }
         else {
-            const int32_t *start = reinterpret_cast<const int32_t *>(f.tab.data() + ss::mfcc4096_layout::kStart);
+            // (this layout packs the filter index into the upper half of each word)
+            int32_t start[256];
+            for (int q = 0; q < 256; ++q) start[q] = reinterpret_cast<const int32_t *>(f.tab.data() + ss::mfcc4096_layout::kStart)[q] & 0xffff;
             for (int s = 0; s < 4; ++s) {
                 const int cyc = b128_cycles(start, s, 64);
                 std::printf("cfg5 slot %d (q4 %d): %d LDS cycles per tap chunk (4 conflict-free)\n", s, f.q4[s], cyc);
