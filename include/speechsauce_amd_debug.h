@@ -31,9 +31,10 @@ int ss_debug_stamp_buffer(unsigned long long *d_stamps);
  * cross-check of tests/test_gpu_parity.py::test_kernel_variants_agree and the "generic us" columns of DESIGN.md. */
 int ss_debug_force_generic(int on);
 
-/* on == 0: ss_mel_c1024 stores its rows directly instead of through the CU-wide whole-line tile (A/B and the bit-for-bit
- * comparison of the two builds); on != 0: default selection. */
-int ss_debug_mel_tile(int on);
+/* Which build of the 2048-point mel-spectrogram kernel runs (A/B and the bit-for-bit comparison of the builds):
+ * mode 1: automatic (default); 0: eight waves per CU with direct stores (no whole-line tile); 2: the eight-wave builds only
+ * (whole-line tile when the batch allows it); 3: the twelve-wave build wherever it exists. */
+int ss_debug_mel_tile(int mode);
 
 /* on != 0: the next launches of ss_mel_c1024<tile> do not poll at all -- a wave whose tile hand-off (a clip's last row pair,
  * a buffer's release) is not there the moment it looks takes the lost-hand-off path: it sets the config's device error

@@ -91,7 +91,8 @@ extern std::atomic<unsigned> g_tile_fault;
 }  // namespace
 namespace ss {
 bool dbg_force_generic() { return g_force_generic.load(std::memory_order_relaxed) != 0; }
-bool dbg_mel_tile_off() { return g_mel_tile_off.load(std::memory_order_relaxed) != 0; }
+bool dbg_mel_tile_off() { return g_mel_tile_off.load(std::memory_order_relaxed) == 1; }
+int dbg_mel_build() { return g_mel_tile_off.load(std::memory_order_relaxed); }
 // a forced fault: no polling at all -- the first hand-off that is not there at once counts as lost
 unsigned dbg_tile_spin_limit() { return g_tile_fault.load(std::memory_order_relaxed) ? 0u : (1u << 24); }
 }  // namespace ss
@@ -1386,9 +1387,11 @@ int ss_debug_force_generic(int on)
     return SS_OK;
 }
 
-int ss_debug_mel_tile(int on)
+int ss_debug_mel_tile(int mode)
 {
-    g_mel_tile_off.store(on ? 0 : 1, std::memory_order_relaxed);
+    // stored: 0 automatic, 1 eight waves + direct stores, 2 eight-wave builds only (tile when the batch allows), 3 twelve waves
+    if (mode < 0 || mode > 3) return ss::fail(SS_ERR_ARG, "ss_debug_mel_tile: mode must be 0 .. 3");
+    g_mel_tile_off.store(mode == 0 ? 1 : (mode == 1 ? 0 : mode), std::memory_order_relaxed);
     return SS_OK;
 }
 

@@ -21,7 +21,8 @@ namespace ss {
 
 // Process-wide test aids set through include/speechsauce_amd_debug.h (ss_api.hip)
 bool dbg_force_generic();        // ss_debug_force_generic: every configuration on the generic kernel
-bool dbg_mel_tile_off();         // ss_debug_mel_tile(0): direct stores instead of the whole-line tile
+bool dbg_mel_tile_off();         // ss_debug_mel_tile(0): eight waves, direct stores instead of the whole-line tile
+int dbg_mel_build();             // 0 automatic, 1 = the above, 2 eight-wave builds only, 3 the twelve-wave build where it exists
 unsigned dbg_tile_spin_limit();  // polls before a tile hand-off counts as a protocol error (ss_debug_tile_fault: 0)
 
 enum OutKind : int32_t {

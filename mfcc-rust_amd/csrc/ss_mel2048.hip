@@ -411,6 +411,219 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     }
 }
 
+// ss_mel_c1024_w12: the same mel-spectrogram path with THREE waves per SIMD (12 per CU, <= 168 VGPRs) for the reference bank
+// shape (P rows of bins 0..512), direct stores.  What makes 168 registers enough: no unit is prefetched across the second pass
+// (the third wave on the SIMD hides the load latency instead), every table read comes in batches of at most eight float4s,
+// what depends on the lane number only is derived again in every iteration (the lane number is made opaque at the top of the
+// loop) instead of living in ~40 registers for the whole kernel, and u is defined on every lane before the two half-wave
+// phases of the exchange fill it (left half-defined, the "undefined" halves are carried around the loop and spilled).
+// Twelve exchange regions + the tables are 134 KB of LDS, so the CU-wide whole-line tile of the 8-wave build (55 KB) does not
+// fit beside them: the rows leave as 8-byte pieces of lines (HBM writes 1.4x the output, traffic 1.09x the algorithmic bytes).
+template <bool FIXMEL>
+__global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a)
+{
+    constexpr int kWavesM = 12;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
+    unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
+    const unsigned pairs = (a.rows + 1) / 2;
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    {
+        const int n4 = (L::kMelW + 32 * a.mel_wpitch + 4) / 4;
+        for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
+        if (tid == 0) *s_next = u_lo + kWavesM;
+    }
+    __syncthreads();
+    const float hs = 0.25f * a.scale * a.scale;  // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
+    const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
+    const int M = static_cast<int>(a.n_filters);
+
+    unsigned unit = u_lo + wave;
+    while (unit < u_hi) {
+        int lane_it = static_cast<int>(threadIdx.x) & 63;
+        asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
+        const int lane = lane_it;
+        const int half = lane >> 5;  // frame within the wave
+        const int j = lane & 31;     // lane within the frame
+        float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsM;
+        float *prow = wbase + half * L::kPRow;
+        const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2 + j * L::kTw2Pitch);
+        const float4 *s_twn4 = reinterpret_cast<const float4 *>(s_tab + L::kTwn + j * L::kTwnPitch);
+        const float4 *s_win4 = reinterpret_cast<const float4 *>(s_tab + L::kWin + j * L::kWinPitch);
+        // the claim of the next unit is issued here and read at the end of the iteration
+        unsigned next_v = 0;
+        if (lane == 0) next_v = atomicAdd(s_next, 1u);
+
+        const unsigned clip = unit / pairs;
+        const int r = static_cast<int>(unit - clip * pairs) * 2 + half;
+        const bool in_rows = r < R;
+        // ---- the window of this half-wave's row (functions.rs:137-151: the last W samples ending at chunk r + n_pad) ----
+        float2 v[32];
+        {
+            const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+            const bool active = r < Rreal;
+            const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
+            const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
+            const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
+            if (__all(inside)) {
+#pragma unroll
+                for (int e = 0; e < 32; ++e) v[e] = src[32 * e];
+            } else {
+                // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows: see ss_mel_c1024
+                const int base = start + 2 * j;
+                const int n = static_cast<int>(a.n_samples);
+                if (((start | n) & 1) == 0) {
+                    int e_lo = base >= 0 ? 0 : (63 - base) >> 6;
+                    int e_hi = base >= n ? 0 : min(32, (n - base + 63) >> 6);
+                    if (!active) e_hi = 0;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        float2 sv = make_float2(0.f, 0.f);
+                        if (e >= e_lo && e < e_hi) sv = src[32 * e];
+                        v[e] = sv;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int p0 = base + 64 * e;
+                        v[e] = make_float2(active && p0 >= 0 && p0 < n ? xc[p0] : 0.f, active && p0 + 1 >= 0 && p0 + 1 < n ? xc[p0 + 1] : 0.f);
+                    }
+                }
+            }
+        }
+        // Vorbis window (config.rs:151-160): two batches of eight reads, each in front of its products
+#pragma unroll
+        for (int eb = 0; eb < 16; eb += 8) {
+            float4 w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = s_win4[eb + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 2 * (eb + i);
+                v[e] = make_float2(v[e].x * w[i].x, v[e].y * w[i].y);
+                v[e + 1] = make_float2(v[e + 1].x * w[i].z, v[e + 1].y * w[i].w);
+            }
+        }
+        // ---- 1024-point complex FFT: radix-32, transpose through LDS in two register halves, twiddle, radix-32 ----
+        fft_reg<32>(v);
+        float2 u[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) u[k] = make_float2(0.f, 0.f);  // defined on every lane before the half-wave phases fill it
+        {
+            float2 *exf = reinterpret_cast<float2 *>(wbase) + half * (16 * 34);
+            const int wbh = 34 * (j >> 1) + (j & 1);
+            const int jl = j & 15;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[k];
+            wave_order();
+            if (j < 16) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(&exf[34 * p + 2 * jl]);
+                    u[2 * p] = make_float2(t4.x, t4.y);
+                    u[2 * p + 1] = make_float2(t4.z, t4.w);
+                }
+            }
+            wave_order();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[16 + k];
+            wave_order();
+            if (j >= 16) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(&exf[34 * p + 2 * jl]);
+                    u[2 * p] = make_float2(t4.x, t4.y);
+                    u[2 * p + 1] = make_float2(t4.z, t4.w);
+                }
+            }
+            wave_order();
+        }
+#pragma unroll
+        for (int pb = 0; pb < 16; pb += 8) {  // pass-2 twiddles, two per ds_read_b128, eight reads per batch
+            float4 tw2[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) tw2[p] = s_tw2[pb + p];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                u[2 * (pb + p) + 1] = cmul(u[2 * (pb + p) + 1], make_float2(tw2[p].x, tw2[p].y));
+                if (pb + p < 15) u[2 * (pb + p) + 2] = cmul(u[2 * (pb + p) + 2], make_float2(tw2[p].z, tw2[p].w));
+            }
+        }
+        fft_reg<32>(u);  // u[q] = Z[j + 32 q]
+
+        // ---- untangle bins k = j + 32 q, q < 16, and k = 512; (|X| wnorm)^2 -> P row (functions.rs:166-169, feature.rs:164) ----
+        const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
+        // first P bin and filter index of this lane's four slots: requested here, used by the mel stage below
+        int st[4], fi[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st[s] = reinterpret_cast<const int *>(s_tab + L::kStart)[s * 32 + j];
+            fi[s] = reinterpret_cast<const int *>(s_tab + L::kFilt)[s * 32 + j];
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
+            float2 zcs[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zcs[q] = make_float2(bperm(paddr, u[31 - (8 * hb + q)].x), bperm(paddr, u[31 - (8 * hb + q)].y));
+            float4 tw4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tw4[i] = s_twn4[4 * hb + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const int q = 8 * hb + qq;
+                const float2 zk = u[q];
+                // lane 0 pairs with itself: Z[1024 - 32 q] = own register (32 - q) & 31
+                const float2 zc = j == 0 ? u[(32 - q) & 31] : zcs[qq];
+                const float2 w = (qq & 1) ? make_float2(tw4[qq >> 1].z, tw4[qq >> 1].w) : make_float2(tw4[qq >> 1].x, tw4[qq >> 1].y);
+                const float2 sm = make_float2(zk.x + zc.x, zk.y - zc.y);  // 2 E[k]
+                const float2 df = make_float2(zk.x - zc.x, zk.y + zc.y);
+                // 2 X[k] = s - i w d: two chained FMAs per component
+                const float xr = fmaf(w.y, df.x, fmaf(w.x, df.y, sm.x));
+                const float xi = fmaf(w.y, df.y, fmaf(-w.x, df.x, sm.y));
+                prow[j + 32 * q] = hs * (xr * xr + xi * xi);
+            }
+        }
+        if (j == 0) {
+            const float2 z = u[16];  // X[512] = conj Z[512]
+            prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
+        }
+        if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
+        wave_order();
+        // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are adjacent words of
+        //      out[clip][m][.] ----
+        {
+            const float4 *w4 = reinterpret_cast<const float4 *>(s_tab + L::kMelW + j * a.mel_wpitch);
+            float mv[4];
+            if constexpr (FIXMEL) {
+                mel4_fixed<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
+                                       reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mv);
+            } else {
+                int off = 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    mv[s] = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                    off += a.mel_q4[s];
+                }
+            }
+            if (in_rows) {
+                float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = mv[s];
+            }
+        }
+        wave_order();
+        unit = __builtin_amdgcn_readfirstlane(next_v);
+    }
+}
+
 template <int kWavesM>
 hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
@@ -444,10 +657,48 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
     return go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
 }
 
+// three waves per SIMD, direct stores (see ss_mel_c1024_w12): mel output with the reference bank shape
+hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    constexpr int kWavesM = 12;
+    if (a.out_stft || a.fullp || a.batch == 0) return hipErrorInvalidValue;
+    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    if (units >= 0xffffffffull) return hipErrorInvalidValue;
+    const unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
+    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
+    auto go = [&](auto kern, const char *name) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kWavesM * 64), lds};
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
+        return hipGetLastError();
+    };
+    const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+    return m6321 ? go(ss_mel_c1024_w12<true>, "ss_mel_c1024<w12,mel6321>") : go(ss_mel_c1024_w12<false>, "ss_mel_c1024<w12>");
+}
+
 }  // namespace
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
+    // Eight waves per CU (whole-line tile when the batch allows it) or twelve (direct stores)?  A unit (two rows) takes a wave
+    // 1.29 x as long with three waves on its SIMD as with two (cfg3, one box: 8.0 us against 6.2), and a CU's units go round in
+    // ceil(units / waves) rounds: twelve waves win unless the CU's share of units fits eight waves much better (cfg3: 64 units
+    // per CU, 8 rounds of 8 against 5.3 -> 6 of 12: 46.5 us against 49.7).  ss_debug_mel_tile(0) keeps its meaning (8 waves,
+    // direct stores).
+    if (!a.out_stft && !a.fullp && (dbg_mel_build() == 0 || dbg_mel_build() == 3)) {
+        const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+        const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+        const unsigned long long per_cu = (units + cus - 1) / cus;
+        const double r8 = static_cast<double>((per_cu + 7) / 8), r12 = 1.29 * static_cast<double>((per_cu + 11) / 12);
+        if (r12 < r8 || dbg_mel_build() == 3) {
+            const hipError_t e = launch_mel_w12(a, stream, num_cus, info);
+            if (e != hipErrorInvalidValue) return e;
+        }
+    }
 #if SS_LAB
     static const char *w = std::getenv("SS_MEL_WAVES");  // A/B knob (lab build)
     if (w && std::atoi(w) == 12) return launch_mel_w<12>(a, stream, num_cus, info);

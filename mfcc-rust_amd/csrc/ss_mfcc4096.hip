@@ -86,7 +86,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
-    const int lane = tid & 63;
     // LEAN: twelve waves per CU (three per SIMD) at <= 168 VGPRs.  Every table read comes in batches of at most eight float4s
     // (a third wave on the SIMD hides the round trips the 8-wave build has to avoid) and what depends on the lane number only
     // is derived again in every iteration instead of living in registers: twelve exchange regions + the tables are 163 584 of

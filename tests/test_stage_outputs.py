@@ -181,6 +181,7 @@ def test_a_lost_tile_hand_off_becomes_a_status(ss, sslib):
     def launch():
         return sslib.ss_mel_spectrogram_device(cfg.handle, x.data_ptr(), x.shape[0], 16000, 16000, out.data_ptr(), stream)
 
+    sslib.ss_debug_mel_tile(2)  # the eight-wave builds: this batch takes the whole-line tile
     assert launch() == 0 and sslib.ss_last_kernel_name() == b"ss_mel_c1024<tile>"
     torch.cuda.synchronize()
     assert sslib.ss_config_device_status(cfg.handle) == 0
@@ -201,27 +202,34 @@ def test_a_lost_tile_hand_off_becomes_a_status(ss, sslib):
         assert sslib.ss_mel_spectrogram(cfg.handle, xh.ctypes.data, x.shape[0], 16000, oh.ctypes.data) == 6
     finally:
         sslib.ss_debug_tile_fault(0)
+        sslib.ss_debug_mel_tile(1)
+    sslib.ss_debug_mel_tile(2)
     out.zero_()
     assert launch() == 0
     torch.cuda.synchronize()
     assert sslib.ss_config_device_status(cfg.handle) == 0
     assert torch.equal(out, good)
+    sslib.ss_debug_mel_tile(1)
 
 
 @pytest.mark.gpu
-def test_mel_tile_switch_is_bit_identical(ss, sslib):
-    """ss_debug_mel_tile(0) selects the direct-store build on the same batch: same bits as the whole-line tile."""
+def test_mel_build_switch_is_bit_identical(ss, sslib):
+    """ss_debug_mel_tile selects the build of the 2048-point mel kernel on one batch: the whole-line tile, eight waves with
+    direct stores give the same bits, twelve waves the same values to f32 rounding."""
     import torch
 
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     x = torch.from_numpy(_signal(9, (2 * ncu + 5, 16000))).cuda()
     kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
-    a = ss.mel_spectrogram(x, 16000, **kw)
-    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<tile>"
-    sslib.ss_debug_mel_tile(0)
+    outs = {}
     try:
-        b = ss.mel_spectrogram(x, 16000, **kw)
-        assert sslib.ss_last_kernel_name() == b"ss_mel_c1024"
+        for mode, name in ((2, b"ss_mel_c1024<tile>"), (0, b"ss_mel_c1024"), (3, b"ss_mel_c1024<w12,mel6321>")):
+            sslib.ss_debug_mel_tile(mode)
+            outs[mode] = ss.mel_spectrogram(x, 16000, **kw)
+            assert sslib.ss_last_kernel_name() == name, (mode, sslib.ss_last_kernel_name())
+        assert sslib.ss_debug_mel_tile(7) == 3  # SS_ERR_ARG
     finally:
         sslib.ss_debug_mel_tile(1)
-    assert torch.equal(a, b)
+    assert torch.equal(outs[2], outs[0])
+    scale = outs[2].abs().amax(dim=(1, 2), keepdim=True)  # the twelve-wave kernel: same arithmetic, FMA fusion may differ in the last bit
+    assert ((outs[3] - outs[2]).abs() <= 1e-6 * scale).all()
