@@ -63,6 +63,29 @@
 // of as bursts behind them -- a wave issues in order, so a burst of 8..16 memory instructions holds back its own VALU work
 // while the LDS / vector-memory queue drains (-1.0 us of 30.8 on one box against the round-1 bursts).
 
+// SS_PROF2 (lab builds): every wave sums the shader-clock ticks it spends in each phase of its iterations (s_memtime at the
+// phase boundaries, pinned by scheduling barriers; the wait for a stamp also drains the phase's LDS operations) and writes 16
+// 64-bit words into the stamp buffer at the end: [0] iterations, [1..10] phase sums, [11] main-loop lifetime.  The buffer of
+// ss_debug_stamp_buffer then needs 16 words per wave (tools/prof2.py); the ordinary stamps are off in such a build.
+#if !SS_LAB
+#undef SS_PROF2
+#endif
+#ifndef SS_PROF2
+#define SS_PROF2 0
+#endif
+#if SS_PROF2
+#define SS_PH(k)                                                     \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        pacc[k] += tn_ - tprev;                                      \
+        tprev = tn_;                                                 \
+    } while (0)
+#else
+#define SS_PH(k) do { } while (0)
+#endif
+
 namespace ss {
 
 namespace {
@@ -246,9 +269,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     // diagnostic stamps (tools/dbg_times.py) go to memory where they are taken: kept in registers until the end they cost the
     // production path two spilled VGPRs (1.5 MB of scratch writes per cfg2 launch)
     auto stamp = [&](int k, unsigned long long v) {
-        if (a.dbg && lane == 0) a.dbg[6ull * (blockIdx.x * WAVES + wave) + k] = v;
+        if (!SS_PROF2 && a.dbg && lane == 0) a.dbg[6ull * (blockIdx.x * WAVES + wave) + k] = v;
     };
-    if (a.dbg) {
+    if (!SS_PROF2 && a.dbg) {
         stamp(0, __builtin_amdgcn_s_memrealtime());
         stamp(5, __builtin_amdgcn_s_memtime());  // shader-clock ticks: replaced by the cycles lived at the end
         stamp(4, 0ull);
@@ -319,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         }
         // table waves: when the tables were in LDS, as 100 MHz ticks since this wave's start stamp, flagged 2 in bits 40..41 (the
         // other waves flag their cycle count 1 there; an absolute stamp would carry either flag by accident, depending on uptime)
-        if (a.dbg && lane == 0) {
+        if (!SS_PROF2 && a.dbg && lane == 0) {
             unsigned long long *d = a.dbg + 6ull * (blockIdx.x * WAVES + wave);
             d[5] = ((__builtin_amdgcn_s_memrealtime() - d[0]) & ((1ull << 40) - 1)) | (2ull << 40);
         }
@@ -373,20 +396,31 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
 #pragma unroll
         for (int p = 0; p < 8; ++p) tw2r[p] = s_tw2[p * 16 + j];
     }
-    if (a.dbg) stamp(1, __builtin_amdgcn_s_memrealtime());
+    if (!SS_PROF2 && a.dbg) stamp(1, __builtin_amdgcn_s_memrealtime());
+#if SS_PROF2
+    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
     unsigned n_done = 0;
 
     while (quad < q_hi) {
         // claim the next quad now so that its samples can be prefetched during this one
-        unsigned next = 0;
-        if (lane == 0) next = atomicAdd(s_next, 1u);
-        next = __builtin_amdgcn_readfirstlane(next);
+        // (the claim is issued here and read behind the first butterfly, where the prefetch needs it: read at once, the LDS
+        // atomic's round trip was exposed at the top of every iteration)
+        unsigned next_v = 0;
+        if (lane == 0) next_v = atomicAdd(s_next, 1u);
         ++n_done;
 
+        SS_PH(1);  // claim
         if (!PREFETCH && n_done > 1) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, quad, total, f, j, vin, pin);
         const unsigned t_cur = t_next;
+#if SS_PROF2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        SS_PH(2);  // the prefetched samples are here
         float2 v[16];
-        if (a.dbg && n_done == 1) {
+        if (!SS_PROF2 && a.dbg && n_done == 1) {
             // diagnostic runs: when this wave's first samples have arrived
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(4, __builtin_amdgcn_s_memrealtime());
@@ -411,6 +445,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             fft16_reg(v);
         }
         wave_order();
+        const unsigned next = __builtin_amdgcn_readfirstlane(next_v);
+        SS_PH(3);  // pass 1 + exchange stores
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
         // SPREAD: the ten sample loads of the next quad go out one per twiddle step instead of as a burst (a wave issues in
@@ -447,6 +483,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SS_PH(4);  // exchange reads + twiddles (+ prefetch issue)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // the partner of bin j + 16 r is register 15 - r of lane 16 - j: fetched with ds_bpermute
         float2 zcs[8];
@@ -467,6 +504,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
 #pragma unroll
             for (int r = 0; r < 8; ++r) zcs[r] = (SS_ABLATE & 1) ? u[15 - r] : make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         }
+        SS_PH(5);  // pass 2 + partner fetches
         float esum = 0.f;
         // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
         // per register and frame on either side of the spectrum
@@ -523,6 +561,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         float energy = hscale32 * row16_sum(esum);      // E * 2^32
         energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
+        SS_PH(6);  // untangle + magnitudes + energy
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
         float m0, m1, m2;
@@ -561,6 +600,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             quad = next;
             continue;
         }
+        SS_PH(7);  // mel
         m0 *= hscale32;  // mel energies * 2^32 (see ln_scaled)
         m1 *= hscale32;
         m2 *= hscale32;
@@ -625,6 +665,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             }
         }
         }
+        SS_PH(8);  // ln + DCT
         // ---- scaling + column-0 replacement (feature.rs:126-146) and the store ----
         {
             const unsigned gf = quad * 4 + f;
@@ -639,9 +680,19 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
         }
         wave_order();
+        SS_PH(9);  // store
         quad = next;
     }
+#if SS_PROF2
     if (a.dbg && lane == 0) {
+        unsigned long long *o = a.dbg + 16ull * (blockIdx.x * WAVES + wave);
+        pacc[11] = __builtin_amdgcn_s_memtime() - tstart;
+        pacc[0] = n_done;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = pacc[k];
+    }
+#endif
+    if (!SS_PROF2 && a.dbg && lane == 0) {
         unsigned long long *d = a.dbg + 6ull * (blockIdx.x * WAVES + wave);
         d[2] = __builtin_amdgcn_s_memrealtime();
         if (wave >= kTabWaves) d[5] = (__builtin_amdgcn_s_memtime() - d[5]) | (1ull << 40);  // the other waves: cycles lived

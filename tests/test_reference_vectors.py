@@ -63,6 +63,16 @@ def test_power_spectrum_frames(ref, oracle):
     _close(want, ref["pspec_out"], 1e-5)
 
 
+def test_column_zero_scaling_without_dc_elimination(ref, oracle):
+    """num_cepstral == num_filters = 40, dc_elimination = false: column 0 keeps its DCT value, scaled by 1/sqrt(4n) in `[0, 0]`
+    only (feature.rs:126-131) -- the quirk the default configuration hides behind the ln(energy) replacement."""
+    if "mfcc1_full_in" not in ref:
+        pytest.skip("reference_v1.npz predates the `full` vector (re-run tools/ref_dump)")
+    p = oracle.make_params(sample_rate=16000, fft_points=512, frame_length=0.02, frame_stride=0.01, num_cepstral=40, num_filters=40,
+                           high_frequency=8000.0, dc_elimination=False)
+    _close(oracle.mfcc(p, ref["mfcc1_full_in"]), ref["mfcc1_full_out"], 1e-4)
+
+
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg5"])
 def test_single_frame_clips_pin_the_whole_chain(ref, oracle, cfg):
     """One frame is the one case where the reference's stack_frames copies the signal (processing.rs:110-120): filterbank,

@@ -6,6 +6,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/skew.txt"
 os.environ["SS_DEBUG_TIMES"] = out
+# SS_DEBUG_TIMES exists in the LAB build of the library only (`make -C mfcc-rust_amd/csrc lab`)
+os.environ.setdefault("SS_LIB_PATH", os.path.join(ROOT, "mfcc-rust_amd", "lib", "libspeechsauce_amd_lab.so"))
 os.environ["SS_DEBUG_TIMES_REPS"] = os.environ.get("SS_DEBUG_TIMES_REPS", "12")
 sys.path.insert(0, os.path.join(ROOT, "mfcc-rust_amd"))
 import numpy as np

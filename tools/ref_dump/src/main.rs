@@ -5,7 +5,8 @@
 //! What each vector pins:
 //!   dct2_*          ndrustfft::nddct2 on known rows: the DCT-II gain `g` (feature.rs:120-123)
 //!   pspec_*         processing::power_spectrum on two hand-made frames: rustfft's forward convention + the 1/N scale
-//!   mfcc1_* / mfe1_* feature::mfcc / mfe on clips that give exactly ONE frame (stack_frames copies the signal correctly
+//!   mfcc1_* / mfe1_* feature::mfcc / mfe on clips that give exactly ONE frame (`full`: all 40 cepstra, dc_elimination = false --
+//!                   pins the `[0, 0]`-only scaling of column 0); (stack_frames copies the signal correctly
 //!                   only then, processing.rs:110-120): the whole chain filterbank -> ln -> DCT -> scaling on real data
 //!   mfcc_* / mfe_*  the same on 1 s clips: the literal behaviour (all frames zero for more than two frames)
 //!   stft_* / mel_*  functions::stft2 and feature::mel_spectrogram2 on a two-channel clip with a FRESH SpeechConfig
@@ -42,6 +43,9 @@ fn cfg(which: &str) -> SpeechConfig {
         "cfg1" => SpeechConfig::new(16000, 512, 0.02, 0.01, 13, 40, 0.0, 8000.0, true),
         "cfg3" => SpeechConfig::new(16000, 2048, 0.032, 0.032, 13, 128, 0.0, 8000.0, true),
         "cfg5" => SpeechConfig::new(44100, 4096, 4096.0 / 44100.0, 1024.0 / 44100.0, 40, 256, 0.0, 22050.0, true),
+        // num_cepstral == num_filters and no dc elimination: column 0 keeps its DCT value, so the `[0, 0]`-only 1/sqrt(4n)
+        // scaling of feature.rs:126-131 shows in the output
+        "full" => SpeechConfig::new(16000, 512, 0.02, 0.01, 40, 40, 0.0, 8000.0, false),
         _ => panic!("unknown config"),
     }
 }
@@ -78,7 +82,7 @@ fn main() {
     }
 
     // ---- single-frame clips: the whole MFCC chain on real data ----
-    for (which, n) in [("cfg1", 500usize), ("cfg5", 5200usize)] {
+    for (which, n) in [("cfg1", 500usize), ("cfg5", 5200usize), ("full", 500usize)] {
         let c = cfg(which);
         let x = lcg_signal(21, n, 0.1);
         dump(&dir, &format!("mfcc1_{}_in", which), &[n], x.as_slice().unwrap(), &mut man);
