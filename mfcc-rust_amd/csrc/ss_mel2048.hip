@@ -512,8 +512,6 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         // ---- 1024-point complex FFT: radix-32, transpose through LDS in two register halves, twiddle, radix-32 ----
         fft_reg<32>(v);
         float2 u[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) u[k] = make_float2(0.f, 0.f);  // defined on every lane before the half-wave phases fill it
         {
             float2 *exf = reinterpret_cast<float2 *>(wbase) + half * (16 * 34);
             const int wbh = 34 * (j >> 1) + (j & 1);
@@ -521,6 +519,9 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #pragma unroll
             for (int k = 0; k < 16; ++k) exf[wbh + 2 * k] = v[k];
             wave_order();
+            // every lane fills u in ONE of the two half-wave phases: "defined" here (an empty asm per register, no instruction)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) u[k] = make_float2(defined_garbage(), defined_garbage());
             if (j < 16) {
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {

@@ -201,14 +201,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         }
         // ---- transpose (two 32 x 32 problems: even and odd n1), in two register halves ----
         float2 u[32];
-        if (LEAN) {
-            // Every lane fills u in ONE of the two half-wave phases below.  Left half-defined, the "undefined" halves are carried
-            // around the loop and spilled (132 bytes of scratch at 168 VGPRs); sixty-four moves in front define them.  (Running
-            // the first phase's reads on all lanes instead -- lanes k1 >= 16 reading the column of lane k1 - 16, a broadcast --
-            // needs no moves and 14 registers fewer, and measured 1.7 % slower.)
-#pragma unroll
-            for (int k = 0; k < 32; ++k) u[k] = make_float2(0.f, 0.f);
-        }
         if (SS_ABL5 & 8) {
 #pragma unroll
             for (int k = 0; k < 32; ++k) u[k] = v[k];
@@ -216,6 +208,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
 #pragma unroll
         for (int k = 0; k < 16; ++k) exw[2 * k] = v[k];
         wave_order();
+        if (LEAN) {
+            // Every lane fills u in ONE of the two half-wave phases below.  Left half-defined, the "undefined" halves are carried
+            // around the loop and spilled (132 bytes of scratch at 168 VGPRs); an empty asm statement per register defines them
+            // at no cost.  (Sixty-four moves did the same for 4 % more instructions; running the first phase's reads on all
+            // lanes -- lanes k1 >= 16 reading the column of lane k1 - 16, a broadcast -- measured 1.7 % slower.)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) u[k] = make_float2(defined_garbage(), defined_garbage());
+        }
         if (k1 < 16) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -273,13 +273,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // column i and the upper half-wave both halves' column 16 + i; each lane then forms BOTH outputs
         //   Z[k1 + 32 c + 1024 d] = G0[c] + (-1)^d W2048^(k1 + 32 c) G1[c],  c = i + 16 h, h = lane >> 5
         // r0[i] (d = 0) and r1[i] (d = 1): half the swaps, half the twiddle products, no copies ----
+        // (all sixteen twiddles are requested in front of the swaps: read inside the loop they came one iteration ahead of their
+        // use -- less than an LDS round trip -- and every iteration waited: 3.4 k of a wave's 20 k cycles per frame)
+        float2 t2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t2[i] = s_t2[i * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
         float2 r0[16], r1[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float px = u[i].x, qx = u[16 + i].x, py = u[i].y, qy = u[16 + i].y;
             swap_halves(px, qx);
             swap_halves(py, qy);
-            const float2 wq = cmul(make_float2(qx, qy), s_t2[i * 64 + lane]);
+            const float2 wq = cmul(make_float2(qx, qy), t2[i]);
             r0[i] = make_float2(px + wq.x, py + wq.y);
             r1[i] = make_float2(px - wq.x, py - wq.y);
         }
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         frame = __builtin_amdgcn_readfirstlane(next_v);
     }
 #if SS_PROF5
-    if (a.dbg && lane == 0) {
+    if (a.dbg && (threadIdx.x & 63) == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg) + 16ull * (blockIdx.x * WAVES + wave);
         pacc[11] = __builtin_amdgcn_s_memtime() - tstart;  // main loop lifetime
 #pragma unroll
@@ -679,13 +685,19 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
             if (p < 15) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
         }
         fft_reg<32>(u);
+        // (all sixteen twiddles are requested in front of the swaps: read inside the loop they came one iteration ahead of their
+        // use -- less than an LDS round trip -- and every iteration waited: 3.4 k of a wave's 20 k cycles per frame)
+        float2 t2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t2[i] = s_t2[i * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
         float2 r0[16], r1[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float px = u[i].x, qx = u[16 + i].x, py = u[i].y, qy = u[16 + i].y;
             swap_halves(px, qx);
             swap_halves(py, qy);
-            const float2 wq = cmul(make_float2(qx, qy), s_t2[i * 64 + lane]);
+            const float2 wq = cmul(make_float2(qx, qy), t2[i]);
             r0[i] = make_float2(px + wq.x, py + wq.y);
             r1[i] = make_float2(px - wq.x, py - wq.y);
         }

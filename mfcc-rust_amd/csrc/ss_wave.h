@@ -60,6 +60,16 @@ __device__ __forceinline__ float half_sum(float v)
     return v;
 }
 
+// A register that the compiler has to treat as defined, at no cost: an empty asm statement "writes" it.  For arrays that are
+// filled under complementary lane masks (the two half-wave phases of the transposing exchange): left half-defined, the
+// "undefined" halves are carried around the loop as if they were values and spilled.
+__device__ __forceinline__ float defined_garbage()
+{
+    float v;
+    asm volatile("" : "=v"(v));
+    return v;
+}
+
 // sum over the wave without an LDS round trip: four DPP adds give every lane its row's sum, the four row sums are read as
 // scalars and added; every lane ends with the same bits.  (The __shfl_xor form below is six dependent ds_bpermute round trips:
 // ~1200 cycles of a wave's time where only two waves share a SIMD.)
