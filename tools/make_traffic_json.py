@@ -12,7 +12,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLOCK_GHZ = 1.974  # measured during a cfg2 launch (profiles/r02/wave_timeline_cfg2.txt)
+# shader clock the profiled box held under the load (SS_PROFILE_CLOCK_GHZ: bench.py's clock_ghz_measured of the same box;
+# default: the 1.974 GHz of profiles/r02/wave_timeline_cfg2.txt)
+CLOCK_GHZ = float(os.environ.get("SS_PROFILE_CLOCK_GHZ", "1.974"))
 out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for arg in sys.argv[1:]:
