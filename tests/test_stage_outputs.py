@@ -233,3 +233,67 @@ def test_mel_build_switch_is_bit_identical(ss, sslib):
     assert torch.equal(outs[2], outs[0])
     scale = outs[2].abs().amax(dim=(1, 2), keepdim=True)  # the twelve-wave kernel: same arithmetic, FMA fusion may differ in the last bit
     assert ((outs[3] - outs[2]).abs() <= 1e-6 * scale).all()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_stage_outputs(tmp_path, oracle):
+    """The C++ mirror of the crate's API (include/speechsauce_amd.hpp), built with plain g++ against the library:
+    stack_frames -> power_spectrum(frames), stft2 and stft1 on seeded clips, compared with the oracle."""
+    import os
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    x = _signal(61, (2, 16000))
+    x.tofile(tmp_path / "x.f32")
+    src = tmp_path / "t.cpp"
+    src.write_text(
+        '#include "speechsauce_amd.hpp"\n#include <cstdio>\n'
+        "template <class T> static void put(FILE *f, const std::vector<T> &v) { std::fwrite(v.data(), sizeof(T), v.size(), f); }\n"
+        "int main(int argc, char **argv) {\n"
+        "  if (argc < 3) return 1;\n"
+        "  std::vector<float> x(2 * 16000); FILE *f = std::fopen(argv[1], \"rb\");\n"
+        "  if (!f || std::fread(x.data(), 4, x.size(), f) != x.size()) return 2; std::fclose(f);\n"
+        "  speechsauce::SpeechConfig cfg = speechsauce::SpeechConfigBuilder(16000).build();\n"
+        "  auto fr = speechsauce::stack_frames(x.data(), 16000, cfg);\n"
+        "  auto ps = speechsauce::power_spectrum(fr, cfg);\n"
+        "  speechsauce::SpeechConfig sc = speechsauce::SpeechConfigBuilder(16000).fft_points(2048).frame_length(0.032f).frame_stride(0.032f).num_filters(128).build();\n"
+        "  auto s2 = speechsauce::stft2(x.data(), 2, 16000, sc);\n"
+        "  auto s1 = speechsauce::stft1(x.data() + 16000, 16000, sc);\n"
+        "  if (fr.rows != 98 || fr.cols != 320 || ps.rows != 98 || ps.cols != 257) return 3;\n"
+        "  if (s2.d0 != 2 || s2.d1 != 32 || s2.d2 != 1025 || s1.d0 != 1 || s1.d1 != 32) return 4;\n"
+        "  f = std::fopen(argv[2], \"wb\"); put(f, fr.data); put(f, ps.data); put(f, s2.data); put(f, s1.data); std::fclose(f);\n"
+        "  return 0; }\n")
+    libdir = os.path.join(root, "mfcc-rust_amd", "lib")
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-L", libdir, "-lspeechsauce_amd",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    subprocess.run([str(exe), str(tmp_path / "x.f32"), str(tmp_path / "o.bin")], check=True)
+    raw = (tmp_path / "o.bin").read_bytes()
+    o = 0
+
+    def take(count, dtype):
+        nonlocal o
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=o)
+        o += a.nbytes
+        return a
+
+    fr = take(98 * 320, np.float32).reshape(98, 320)
+    ps = take(98 * 257, np.float32).reshape(98, 257)
+    s2 = take(2 * 32 * 1025, np.complex64).reshape(2, 32, 1025)
+    s1 = take(32 * 1025, np.complex64).reshape(32, 1025)
+    assert o == len(raw)
+    p = oracle.make_params()
+    np.testing.assert_array_equal(fr.astype(np.float64), oracle.stack_frames(p, x[0]))
+    want = oracle.power_spectrum_frames(fr, 512)
+    assert np.abs(ps - want).max() <= 1e-5 * want.max()
+    ps_sig = oracle.power_spectrum(p, x[0])  # the frames came from the signal: the fused form must agree as well
+    assert np.abs(ps - ps_sig).max() <= 1e-5 * ps_sig.max()
+    sp = oracle.make_params(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=128)
+    ws = oracle.stft(sp, x)
+    assert np.abs(s2 - ws).max() <= 1e-5 * np.abs(ws).max()
+    np.testing.assert_array_equal(s1, s2[1])
+    rows, real_rows = oracle.stft_rows(sp, 16000)
+    assert rows == 32 and not s2[:, real_rows:].any()
