@@ -470,8 +470,18 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
             const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
             if (__all(inside)) {
+#if SS_LAB && defined(SS_ABL3)
+                // timing attribution only (lab builds, results wrong by design): bit 0 no sample loads at all, bit 1 every second one
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    if (SS_ABL3 & 1) v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(unit & 255u));
+                    else if ((SS_ABL3 & 2) && (e & 1)) v[e] = make_float2(v[e - 1].y, v[e - 1].x);
+                    else v[e] = src[32 * e];
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 32; ++e) v[e] = src[32 * e];
+#endif
             } else {
                 // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows: see ss_mel_c1024
                 const int base = start + 2 * j;
