@@ -32,6 +32,28 @@ namespace {
 
 using namespace wv;
 
+// Issue priorities of the twelve-wave kernel's phases (s_setprio; the SIMD's arbiter takes the highest priority first, the oldest
+// wave among equals).  The butterflies are pure VALU streams and run at the lowest priority: a wave that is about to request
+// samples, exchange through LDS or read tables gets its requests out in front of them, and their round trips pass while the
+// butterflies of the other waves fill the SIMD.  Measured on cfg3 (same box, profiles/r03/ab_cfg3_priorities.txt): 47.2 us with
+// no priorities, 45.6 with 3 / 1 / 0 (loop top / every other phase / butterflies), 46.7 with the loop top alone raised,
+// 46.8 with the butterflies raised instead.  SS_PRIOS (lab builds): five decimal digits, priority at the loop top (sample
+// request, window), exchange, twiddles, untangle, mel + stores.
+#if SS_LAB && defined(SS_PRIOS)
+#define SS_P_TOP ((SS_PRIOS / 10000) % 10)
+#define SS_P_EX ((SS_PRIOS / 1000) % 10)
+#define SS_P_TW ((SS_PRIOS / 100) % 10)
+#define SS_P_UN ((SS_PRIOS / 10) % 10)
+#define SS_P_MEL (SS_PRIOS % 10)
+#else
+#define SS_P_TOP 3
+#define SS_P_EX 1
+#define SS_P_TW 1
+#define SS_P_UN 1
+#define SS_P_MEL 1
+#endif
+#define SS_P_FFT 0
+#define SS_PRIOL(x) __builtin_amdgcn_s_setprio(x)
 namespace L = mel2048_layout;
 constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     const int M = static_cast<int>(a.n_filters);
 
     unsigned unit = u_lo + wave;
+    SS_PRIOL(SS_P_TOP);
     while (unit < u_hi) {
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
@@ -520,7 +543,9 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             }
         }
         // ---- 1024-point complex FFT: radix-32, transpose through LDS in two register halves, twiddle, radix-32 ----
+        SS_PRIOL(SS_P_FFT);
         fft_reg<32>(v);
+        SS_PRIOL(SS_P_EX);
         float2 u[32];
         {
             float2 *exf = reinterpret_cast<float2 *>(wbase) + half * (16 * 34);
@@ -554,6 +579,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             }
             wave_order();
         }
+        SS_PRIOL(SS_P_TW);
 #pragma unroll
         for (int pb = 0; pb < 16; pb += 8) {  // pass-2 twiddles, two per ds_read_b128, eight reads per batch
             float4 tw2[8];
@@ -566,7 +592,9 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 if (pb + p < 15) u[2 * (pb + p) + 2] = cmul(u[2 * (pb + p) + 2], make_float2(tw2[p].z, tw2[p].w));
             }
         }
+        SS_PRIOL(SS_P_FFT);
         fft_reg<32>(u);  // u[q] = Z[j + 32 q]
+        SS_PRIOL(SS_P_UN);
 
         // ---- untangle bins k = j + 32 q, q < 16, and k = 512; (|X| wnorm)^2 -> P row (functions.rs:166-169, feature.rs:164) ----
         const int paddr = ((lane & 32) | ((32 - j) & 31)) << 2;  // lane holding Z[1024 - k]
@@ -607,6 +635,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         }
         if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
         wave_order();
+        SS_PRIOL(SS_P_MEL);
         // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are adjacent words of
         //      out[clip][m][.] ----
         {
@@ -631,6 +660,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             }
         }
         wave_order();
+        SS_PRIOL(SS_P_TOP);
         unit = __builtin_amdgcn_readfirstlane(next_v);
     }
 }

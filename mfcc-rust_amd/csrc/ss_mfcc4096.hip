@@ -62,6 +62,29 @@ namespace {
 
 using namespace wv;
 
+// Issue priorities of the phases (s_setprio; see ss_mel2048.hip): the butterflies lowest, whatever requests samples, exchanges
+// through LDS or reads tables in front of them.  cfg5, same box (profiles/r03/ab_cfg2_cfg5_priorities*.txt): 64.1 us without, 61.2
+// with 3 / 1 / 1 / 2 / 3.  SS_PRIOS5 (lab builds): five decimal digits -- loop top (sample request),
+// exchange + twiddles, radix-2 stage, untangle, mel + DCT + store.  Only the twelve-wave build sets priorities.
+#if SS_LAB && defined(SS_PRIOS5)
+#define SS_P5_TOP ((SS_PRIOS5 / 10000) % 10)
+#define SS_P5_EX ((SS_PRIOS5 / 1000) % 10)
+#define SS_P5_R2 ((SS_PRIOS5 / 100) % 10)
+#define SS_P5_UN ((SS_PRIOS5 / 10) % 10)
+#define SS_P5_MEL (SS_PRIOS5 % 10)
+#else
+#define SS_P5_TOP 3
+#define SS_P5_EX 1
+#define SS_P5_R2 1
+#define SS_P5_UN 2
+#define SS_P5_MEL 3
+#endif
+#define SS_PRIOL(x) do { if (LEAN && !kNoPrio) __builtin_amdgcn_s_setprio(x); } while (0)
+#if SS_LAB && defined(SS_NOPRIO5)
+constexpr bool kNoPrio = true;
+#else
+constexpr bool kNoPrio = false;
+#endif
 namespace L = mfcc4096_layout;
 constexpr int kClsStride = 16 * 34 + 8;    // float2 per class slice: +8 keeps the two classes of a write group 16 banks apart
 constexpr int kExFloats = (kClsStride + 16 * 34) * 2;  // exchange region (two classes x half the columns, 8768 B); P row + ln(mel) row reuse it
@@ -132,6 +155,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tprev;
 #endif
+    SS_PRIOL(SS_P5_TOP);
     while (frame < f_hi) {
         // the claim of the next frame is issued here and read where it is needed (the end of the iteration): the LDS atomic's
         // round trip hides behind the transform
@@ -191,8 +215,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         SS_PH(2);  // sample loads arrived
+        SS_PRIOL(0);
         // ---- pass 1: radix-32 over n2 ----
         fft_reg<32>(v);
+        SS_PRIOL(SS_P5_EX);
         SS_PH(3);  // pass 1
 
         if (kDbgStages && a.dbg && frame == 0) {
@@ -263,7 +289,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             }
         }
         SS_PH(5);  // twiddles
+        SS_PRIOL(0);
         fft_reg<32>(u);  // u[c] = G_a[c], a = lane >> 5
+        SS_PRIOL(SS_P5_R2);
         SS_PH(6);  // pass 2
         if (kDbgStages && a.dbg && frame == 0) {
 #pragma unroll
@@ -297,6 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             }
         }
 
+        SS_PRIOL(SS_P5_UN);
         SS_PH(7);  // radix-2 across the half-waves (permlane32 swaps + twiddles)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // Lane (k1, h) register r0[i] holds bin k = k1 + 32 i + 512 h (< 1024); its partner 2048 - k is r1[15 - i] of lane
@@ -364,6 +393,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         float energy = hscale32 * wave_sum_dpp(esum);      // E * 2^32 (see ln_scaled_h)
         energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
+        SS_PRIOL(SS_P5_MEL);
         SS_PH(8);  // untangle + magnitudes + energy
 
         if (SS_ABL5 & 2) {
@@ -471,6 +501,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             }
             wave_order();
             SS_PH(10);  // DCT + store
+            SS_PRIOL(SS_P5_TOP);
             frame = __builtin_amdgcn_readfirstlane(next_v);
             continue;
         }

@@ -96,6 +96,29 @@ constexpr int kZStride = 288;           // float2 per frame exchange slot (2304 
 constexpr int kPRow = 144;              // floats per P row: bins 0..128, 3 zero pad bins, padding
 constexpr int kPOff = 4 * kZStride * 2;  // P rows sit behind the exchange slots: their zero pad bins persist
 constexpr int kWaveFloats = 4 * kZStride * 2 + 4 * kPRow;  // four exchange slots (log-mel rows reuse them) + four P rows
+// Issue priorities of the phases (s_setprio; the reasoning is in ss_mel2048.hip): the two butterflies run at the lowest priority,
+// so that a wave that is about to claim, exchange through LDS, fetch partners or read tables gets those requests out in front of
+// the pure VALU streams of the waves beside it.  cfg2, same box (profiles/r03/ab_cfg2_cfg5_priorities*.txt): 30.8 us without
+// priorities, 29.4 with 3 / 1 / 1 / 2 / 2; every assignment with the butterflies lowest is within 0.3 us of that.
+// SS_PRIOS2 (lab builds): five decimal digits -- loop top (claim, samples), exchange reads + twiddles, untangle, mel, ln + DCT + store.
+#if SS_LAB && defined(SS_PRIOS2)
+#define SS_P2_TOP ((SS_PRIOS2 / 10000) % 10)
+#define SS_P2_EX ((SS_PRIOS2 / 1000) % 10)
+#define SS_P2_UN ((SS_PRIOS2 / 100) % 10)
+#define SS_P2_MEL ((SS_PRIOS2 / 10) % 10)
+#define SS_P2_DCT (SS_PRIOS2 % 10)
+#else
+#define SS_P2_TOP 3
+#define SS_P2_EX 1
+#define SS_P2_UN 1
+#define SS_P2_MEL 2
+#define SS_P2_DCT 2
+#endif
+#if SS_LAB && defined(SS_NOPRIO2)
+#define SS_PRIOL(x) do { } while (0)
+#else
+#define SS_PRIOL(x) __builtin_amdgcn_s_setprio(x)
+#endif
 namespace L = fast512_layout;
 
 
@@ -404,6 +427,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
 #endif
     unsigned n_done = 0;
 
+    SS_PRIOL(SS_P2_TOP);
     while (quad < q_hi) {
         // claim the next quad now so that its samples can be prefetched during this one
         // (the claim is issued here and read behind the first butterfly, where the prefetch needs it: read at once, the LDS
@@ -419,6 +443,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         SS_PH(2);  // the prefetched samples are here
+        SS_PRIOL(0);
         float2 v[16];
         if (!SS_PROF2 && a.dbg && n_done == 1) {
             // diagnostic runs: when this wave's first samples have arrived
@@ -446,6 +471,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         }
         wave_order();
         const unsigned next = __builtin_amdgcn_readfirstlane(next_v);
+        SS_PRIOL(SS_P2_EX);
         SS_PH(3);  // pass 1 + exchange stores
         // the input registers are dead now: the next quad's samples load into them (no copies), three quarters of an
         // iteration ahead of their use
@@ -483,6 +509,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SS_PRIOL(0);
         SS_PH(4);  // exchange reads + twiddles (+ prefetch issue)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // the partner of bin j + 16 r is register 15 - r of lane 16 - j: fetched with ds_bpermute
@@ -504,6 +531,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
 #pragma unroll
             for (int r = 0; r < 8; ++r) zcs[r] = (SS_ABLATE & 1) ? u[15 - r] : make_float2(bperm(paddr, u[15 - r].x), bperm(paddr, u[15 - r].y));
         }
+        SS_PRIOL(SS_P2_UN);
         SS_PH(5);  // pass 2 + partner fetches
         float esum = 0.f;
         // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
@@ -561,6 +589,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         float energy = hscale32 * row16_sum(esum);      // E * 2^32
         energy = energy == 0.f ? kEps * kTwo32 : energy;  // zero_handling, feature.rs:219
         wave_order();
+        SS_PRIOL(SS_P2_MEL);
         SS_PH(6);  // untangle + magnitudes + energy
 
         // ---- banded mel reduction (feature.rs:229), zero handling (:230), ln (:105) ----
@@ -600,6 +629,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             quad = next;
             continue;
         }
+        SS_PRIOL(SS_P2_DCT);
         SS_PH(7);  // mel
         m0 *= hscale32;  // mel energies * 2^32 (see ln_scaled)
         m1 *= hscale32;
@@ -681,6 +711,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         }
         wave_order();
         SS_PH(9);  // store
+        SS_PRIOL(SS_P2_TOP);
         quad = next;
     }
 #if SS_PROF2
