@@ -107,7 +107,11 @@ constexpr int kWaveFloats = 4 * kZStride * 2 + 4 * kPRow;  // four exchange slot
 #define SS_P2_UN ((SS_PRIOS2 / 100) % 10)
 #define SS_P2_MEL ((SS_PRIOS2 / 10) % 10)
 #define SS_P2_DCT (SS_PRIOS2 % 10)
+#define SS_P2_F1 ((SS_PRIOS2 / 1000000) % 10)
+#define SS_P2_F2 ((SS_PRIOS2 / 100000) % 10)
 #else
+#define SS_P2_F1 0
+#define SS_P2_F2 0
 #define SS_P2_TOP 3
 #define SS_P2_EX 1
 #define SS_P2_UN 1
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         SS_PH(2);  // the prefetched samples are here
-        SS_PRIOL(0);
+        SS_PRIOL(SS_P2_F1);
         float2 v[16];
         if (!SS_PROF2 && a.dbg && n_done == 1) {
             // diagnostic runs: when this wave's first samples have arrived
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        SS_PRIOL(0);
+        SS_PRIOL(SS_P2_F2);
         SS_PH(4);  // exchange reads + twiddles (+ prefetch issue)
         // ---- untangle Z -> X; |X| (processing.rs:168) * 1/N (:180); row sum (feature.rs:216) ----
         // the partner of bin j + 16 r is register 15 - r of lane 16 - j: fetched with ds_bpermute
