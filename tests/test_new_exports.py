@@ -3,6 +3,8 @@
 import numpy as np
 import pytest
 
+from common import rel as _rel
+
 
 def _signal(seed, shape, scale=0.1):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
@@ -153,3 +155,34 @@ def test_stamp_buffer_reports_a_plausible_clock_and_leaves_results_alone(ss, ssl
     ss.mfcc_batch(x, 16000)                                         # switched off again: nothing is written
     torch.cuda.synchronize()
     assert int(stamps.abs().sum().item()) == 0
+
+
+@pytest.mark.gpu
+def test_device_entry_points_are_graph_capturable(ss, oracle, sslib):
+    """The device-pointer entry points queue work on the caller's stream and nothing else (no synchronisation, no allocation,
+    no host read of device results), so a caller can capture a whole feature pipeline into a HIP graph and replay it:
+    MFCC (the 512-point kernel) and the 2048-point mel spectrogram, captured once, replayed on new inputs."""
+    import torch
+
+    x = torch.from_numpy(_signal(71, (8, 16000))).cuda()
+    ss.mfcc_batch(x, 16000)  # configs and tables are created outside the capture (the lru-cached config does allocate)
+    kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048)
+    ss.mel_spectrogram(x, 16000, **kw)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        feat = ss.mfcc_batch(x, 16000)
+        mel = ss.mel_spectrogram(x, 16000, **kw)
+    names = set()
+    for seed in (72, 73):
+        x.copy_(torch.from_numpy(_signal(seed, (8, 16000))).cuda())
+        g.replay()
+        torch.cuda.synchronize()
+        xn = x.cpu().numpy()
+        want = oracle.mfcc(oracle.make_params(), xn[3])
+        assert _rel(feat[3].cpu().numpy(), want) <= 1e-4
+        pm = oracle.make_params(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=128)
+        wm = oracle.mel_spectrogram(pm, xn[5:6])[0]
+        assert _rel(mel[5].cpu().numpy(), wm) <= 1e-4
+        names.add(sslib.ss_last_kernel_name())
+    assert feat.shape == (8, 98, 13) and mel.shape == (8, 128, 32)
