@@ -265,10 +265,13 @@ def main():
 
         lo, hi = shard_bounds(clips, world, rank)
         clips = hi - lo
+    if args.force_generic or os.environ.get("SS_FORCE_GENERIC"):  # (the env spelling keeps the tools/*_rate.sh scripts working)
+        # a process-wide kernel-selection override: a test aid of the LAB library (include/speechsauce_amd_debug.h), so this
+        # measurement aid runs the whole bench on that build
+        _lib._lib = _lib.lab()
+        _lib._lib.ss_debug_force_generic(1)
     cfg = SpeechConfig(make_params(**pkw))
     lib = _lib.lib()
-    if args.force_generic or os.environ.get("SS_FORCE_GENERIC"):  # (the env spelling keeps the tools/*_rate.sh scripts working)
-        lib.ss_debug_force_generic(1)
 
     if kind == "mfcc":
         rows = cfg.num_frames(n_samples)
@@ -281,7 +284,8 @@ def main():
     frames_per_launch = clips * rows
 
     # distinct input batches totalling > 256 MiB so the Infinity Cache cannot hold the stream
-    n_buf = max(1 if strong else 2, -(-300 * 1024 * 1024 // (4 * clips * n_samples)))
+    ring_mib = int(os.environ.get("SS_BENCH_RING_MIB", "300"))  # (measurement aid: size of the rotated input ring)
+    n_buf = max(1 if strong else 2, -(-ring_mib * 1024 * 1024 // (4 * clips * n_samples)))
     xs = [synth_batch(torch, clips, n_samples, 1 + rank * 100 + i, device) for i in range(n_buf)]
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
@@ -415,27 +419,16 @@ def main():
     t_full = run_timed(True, args.steps) if do_gather else t_path
     elapsed, dev_ms, segs = t_full["elapsed"], t_path["dev_ms"], t_path["segs"]
 
-    # Shader clock during the launches (512-point MFCC kernel only): thirty more steps right behind the timed ones, with the
-    # kernel's per-wave stamps switched on (ss_debug_stamp_buffer): cycles a wave lived / its lifetime on the 100 MHz clock.
+    # Shader clock during the launches (512-point MFCC kernel only): thirty more launches right behind the timed ones through the
+    # library's per-call diagnostic ss_mfcc_shader_clock (per-wave lifetime in shader cycles / on the 100 MHz clock, written into
+    # a buffer that call owns)
     clock_ghz = None
-    if world == 1 and lib.ss_last_kernel_name().decode().startswith("ss_mfcc_c256<") and args.streams == 1:
-        ncu = torch.cuda.get_device_properties(device).multi_processor_count
-        stamps = torch.zeros((ncu * 16, 6), dtype=torch.int64, device=device)
+    if world == 1 and kind == "mfcc" and lib.ss_last_kernel_name().decode().startswith("ss_mfcc_c256<") and args.streams == 1:
+        g = C.c_float(0.0)
         torch.cuda.synchronize()
-        lib.ss_debug_stamp_buffer(stamps.data_ptr())
-        try:
-            reg = Region(False)
-            for i in range(30):
-                reg.step(i)
-            torch.cuda.synchronize()
-        finally:
-            lib.ss_debug_stamp_buffer(None)
-        w = stamps.cpu().numpy()
-        live = (w[:, 2] != 0) & ((w[:, 5] >> 40) == 1)  # the waves that report cycles (the two table waves per workgroup do not)
-        if live.any():
-            cycles = (w[live, 5] - (1 << 40)).astype("float64")
-            life_us = (w[live, 2] - w[live, 0]).astype("float64") / 100.0
-            clock_ghz = float((cycles / life_us).mean() / 1000.0)
+        rc = lib.ss_mfcc_shader_clock(cfg.handle, xs[0].data_ptr(), clips, n_samples, n_samples, outs[0].data_ptr(), sptr, 30, C.byref(g))
+        if rc == 0 and g.value > 0:
+            clock_ghz = float(g.value)
 
     if rank == 0:
         kernel = lib.ss_last_kernel_name().decode()

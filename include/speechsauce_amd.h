@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 4
+#define SS_ABI_VERSION 5 /* 5: config-free stack_frames entry points, ss_mfcc_shader_clock; the ss_debug_* test aids left the product library */
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -161,6 +161,16 @@ int ss_stft(const ss_config *cfg, const float *x, size_t channels, size_t n_samp
  * (processing.rs:65-129) with the config's framing switch (contract / literal / padded = zero_padding) and frame window
  * (the `filter` argument; mfcc_window switch): frames [n_frames x frame_len], sizes from ss_num_frames / ss_frame_sizes. */
 int ss_stack_frames(const ss_config *cfg, const float *x, size_t n_samples, float *frames);
+/* The same function with the reference's own argument list and nothing else -- no SpeechConfig, no FFT length (the reference's
+ * stack_frames has no FFT dependency: 44.1 kHz x 25 ms frames of 1102 samples are fine): contract framing
+ * frames[t][i] = x[t * step + i], frame_len = round(sample_rate * frame_length), step likewise (processing.rs:77-78),
+ * floor((n - frame_len) / step) frames, or ceil with the tail reading appended zeros when zero_padding != 0 (:85-106).
+ * `window`: frame_len floats that multiply every frame -- row 0 of the Array2 the reference's `filter(frame_len)` returns
+ * (processing.rs:122-126) -- or NULL.  ss_stack_frames_shape gives the output shape without touching the device. */
+int ss_stack_frames_shape(size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride, int zero_padding,
+                          size_t *num_frames, size_t *frame_len);
+int ss_stack_frames_signal(const float *x, size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride,
+                           const float *window, int zero_padding, float *frames);
 /* speechsauce::processing::power_spectrum(frames: Array2<f32>, fft_points) -> Array2<f32>  (processing.rs:179-181; fft_spectrum
  * :143-171 zero-pads rows shorter than fft_points): frames [rows x cols], cols <= the config's fft_points;
  * P [rows x (fft_points/2+1)] = |rfft(row)| / fft_points.  Only fft_points of the config is used. */
@@ -198,6 +208,10 @@ int ss_stft_device(const ss_config *cfg, const float *d_x, size_t channels, size
 /* stack_frames over a batch of clips: frames [batch x n_frames x frame_len] */
 int ss_stack_frames_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
                            float *d_frames, void *stream);
+
+/* ss_stack_frames_signal on device pointers (d_window: frame_len floats in device memory, or NULL) */
+int ss_stack_frames_signal_device(const float *d_x, size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride,
+                                  const float *d_window, int zero_padding, float *d_frames, void *stream);
 
 /* ---- post-processing on the feature matrix (row-major [rows x cols] f32) ---------- */
 
@@ -269,7 +283,16 @@ int ss_time_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t bat
 int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
                                    size_t ld, float *d_out, void *stream, int iters, float *avg_ms);
 
-/* Test aids and diagnostics (LDS poisoning, per-wave stamps, kernel-selection overrides): include/speechsauce_amd_debug.h */
+/* Shader clock (GHz) the part held during `launches` launches of the MFCC batch kernel on `stream`: every wave of the kernel
+ * writes its lifetime once, in shader cycles and on the constant 100 MHz clock, into a buffer that THIS CALL owns; the result
+ * is the mean ratio over the waves of the last launch.  A per-call diagnostic (bench.py's roofline.clock_ghz_measured): no
+ * process-wide state, other threads' launches are unaffected.  The stamps exist in the fft_points = 512 kernel:
+ * SS_ERR_UNSUPPORTED for configurations served by another kernel. */
+int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_out,
+                         void *stream, int launches, float *ghz);
+
+/* Process-wide test aids (LDS poisoning, kernel-selection overrides, fault injection, a stamp buffer) are NOT part of this
+ * library: include/speechsauce_amd_debug.h, exported by the lab build libspeechsauce_amd_lab.so only. */
 
 const char *ss_status_string(int status);
 const char *ss_last_error_string(void); /* thread-local detail of the last failure */

@@ -11,8 +11,12 @@
 // Arrays are plain row-major std::vector<float> plus shapes (the reference returns ndarray::ArrayN<f32>).
 #pragma once
 
+#include <algorithm>
 #include <complex>
 #include <cstddef>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -170,8 +174,36 @@ inline ComplexArray3 stft2(const float *signal, std::size_t channels, std::size_
 // functions.rs:199-233 (one channel): [rows x freq_size]
 inline ComplexArray3 stft1(const float *signal, std::size_t n, const SpeechConfig &cfg) { return stft2(signal, 1, n, cfg); }
 
-// processing.rs:65-129: frames [num_frames x frame_len].  sample_rate / frame_length / frame_stride, the `filter` argument
-// (mfcc_window switch) and zero_padding (framing = SS_FRAMING_PADDED) are the config's.
+// processing.rs:65-129 with the reference's own argument list:
+//   stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding) -> frames [num_frames x frame_len]
+// `filter` (may be null) is called with the frame length and returns the window as an Array2 of shape (1, frame_len) -- row 0
+// multiplies every frame, what repeat_axis(filt, Axis(0), numframes) does in processing.rs:122-126 (a (frame_len, 1) column is
+// read down its column).  No SpeechConfig and no FFT length are involved: any sampling rate and frame length.
+using FrameFilter = Array2 (*)(std::size_t);
+inline Array2 stack_frames(const float *signal, std::size_t n, std::size_t sample_rate, float frame_length, float frame_stride,
+                           FrameFilter filter, bool zero_padding)
+{
+    std::size_t t = 0, flen = 0;
+    check(ss_stack_frames_shape(n, static_cast<uint32_t>(sample_rate), frame_length, frame_stride, zero_padding ? 1 : 0, &t, &flen));
+    std::vector<float> window;
+    if (filter) {
+        const Array2 w = filter(flen);
+        if (w.rows * w.cols != flen || (w.rows != 1 && w.cols != 1)) throw Error(SS_ERR_ARG, "stack_frames: filter(frame_len) must give frame_len values");
+        window = w.data;
+    }
+    Array2 out{t, flen, std::vector<float>(t * flen)};
+    check(ss_stack_frames_signal(signal, n, static_cast<uint32_t>(sample_rate), frame_length, frame_stride,
+                                 filter ? window.data() : nullptr, zero_padding ? 1 : 0, out.data.data()));
+    return out;
+}
+inline Array2 stack_frames(const std::vector<float> &signal, std::size_t sample_rate, float frame_length, float frame_stride,
+                           FrameFilter filter, bool zero_padding)
+{
+    return stack_frames(signal.data(), signal.size(), sample_rate, frame_length, frame_stride, filter, zero_padding);
+}
+
+// The same stage with the framing taken from a config (its framing / mfcc_window / pad_mode switches apply: literal and centred
+// framing exist only in this form).  An extra beside the reference's signature above.
 inline Array2 stack_frames(const float *signal, std::size_t n, const SpeechConfig &cfg)
 {
     std::size_t t = 0, flen = 0, step = 0;
@@ -182,12 +214,36 @@ inline Array2 stack_frames(const float *signal, std::size_t n, const SpeechConfi
     return out;
 }
 
-// processing.rs:179-181: power_spectrum(frames, fft_points) with fft_points = the config's
+// processing.rs:179-181 on an existing config (fft_points = the config's).  An extra beside the reference's signature below.
 inline Array2 power_spectrum(const Array2 &frames, const SpeechConfig &cfg)
 {
     Array2 out{frames.rows, cfg.freq_size(), std::vector<float>(frames.rows * cfg.freq_size())};
     check(ss_power_spectrum_frames(cfg.handle(), frames.data.data(), frames.rows, frames.cols, out.data.data()));
     return out;
+}
+
+// processing.rs:179-181 with the reference's own argument list: power_spectrum(frames, fft_points).  Only fft_points matters to
+// this stage; the config it runs on is kept per fft_points in a small process-wide cache (the Python front memoises the same
+// way), guarded by a mutex, so repeated calls cost one lookup.
+inline Array2 power_spectrum(const Array2 &frames, std::size_t fft_points)
+{
+    static std::mutex mu;
+    static std::map<std::size_t, std::unique_ptr<SpeechConfig>> cache;
+    const SpeechConfig *cfg = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find(fft_points);
+        if (it == cache.end()) {
+            // a config that validates for this FFT length: a frame of half its length, a bank that fits its spectrum
+            SpeechConfigBuilder b(16000);
+            const std::size_t nf = std::max<std::size_t>(1, std::min<std::size_t>(40, fft_points / 8));
+            b.fft_points(fft_points).frame_length(static_cast<float>(fft_points) / 32000.0f).frame_stride(static_cast<float>(fft_points) / 64000.0f)
+                .num_filters(nf).num_cepstral(std::min<std::size_t>(13, nf));
+            it = cache.emplace(fft_points, std::make_unique<SpeechConfig>(b.build())).first;
+        }
+        cfg = it->second.get();  // configs are immutable and thread-safe; entries are never removed
+    }
+    return power_spectrum(frames, *cfg);
 }
 
 // processing.rs:31-53

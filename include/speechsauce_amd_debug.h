@@ -1,10 +1,14 @@
 /*
- * speechsauce_amd_debug.h -- test aids and diagnostics of libspeechsauce_amd.so.
+ * speechsauce_amd_debug.h -- process-wide test aids of the LAB build, libspeechsauce_amd_lab.so (`make -C mfcc-rust_amd/csrc lab`,
+ * the same sources with -DSS_LAB=1).
  *
- * Not part of the drop-in boundary (include/speechsauce_amd.h): nothing here is needed to use the hot path, and nothing
- * here changes a result.  tests/ and bench.py use these to prove properties of the product build (no uninitialised LDS
- * word reaches a result; every kernel family agrees with the generic one; a lost tile hand-off becomes a status) and to
- * measure the shader clock a launch held.  All settings are process-wide and meant for single-threaded test drivers.
+ * NOT exported by the product library libspeechsauce_amd.so (round 4): its header promises an immutable, thread-safe handle and
+ * a kernel selection that is a pure function of the configuration and the call, and switches that change kernel selection or
+ * inject faults for every config in the process do not belong in what ships.  tests/ load the lab library explicitly where
+ * they need one of these (tests/conftest.py `sslab`): LDS poisoning before product-library launches, forced kernel builds for
+ * the bit-for-bit comparisons, the lost-hand-off fault of the retired tile build.  All settings are process-wide and meant for
+ * single-threaded test drivers.  The shader clock bench.py reports comes from the product's own per-call diagnostic,
+ * ss_mfcc_shader_clock (speechsauce_amd.h).
  */
 #ifndef SPEECHSAUCE_AMD_DEBUG_H
 #define SPEECHSAUCE_AMD_DEBUG_H
@@ -23,8 +27,7 @@ int ss_debug_poison_lds(void *stream);
  * (16 waves x CUs x 6 words, overwritten by each launch): [0] s_memrealtime (100 MHz) at wave start, [2] at wave end,
  * [5] shader-clock cycles the wave lived | 1 << 40 (the two table waves of a workgroup: ticks from their start until the tables
  * were in LDS | 2 << 40), [1] / [3] / [4] prologue end,
- * quads done << 32 | XCC id, first samples arrived.  bench.py uses it to report the shader clock the part held during the
- * timed launches (`roofline.clock_ghz_measured`).  Pass NULL to switch it off. */
+ * quads done << 32 | XCC id, first samples arrived (tools/prof2.py, tools/dbg_times.py).  Pass NULL to switch it off. */
 int ss_debug_stamp_buffer(unsigned long long *d_stamps);
 
 /* on != 0: every configuration runs on the generic kernel (ss_front_generic) instead of its dedicated one -- the
@@ -32,8 +35,9 @@ int ss_debug_stamp_buffer(unsigned long long *d_stamps);
 int ss_debug_force_generic(int on);
 
 /* Which build of the 2048-point mel-spectrogram kernel runs (A/B and the bit-for-bit comparison of the builds):
- * mode 1: automatic (default); 0: eight waves per CU with direct stores (no whole-line tile); 2: the eight-wave builds only
- * (whole-line tile when the batch allows it); 3: the twelve-wave build wherever it exists. */
+ * mode 1: automatic (default); 0: eight waves per CU with direct stores; 2: the eight-wave builds only -- the retired
+ * whole-line tile (tools/experiments/ss_mel2048_tile.hip, lab library only) when the batch allows it; 3: the twelve-wave
+ * build wherever it exists. */
 int ss_debug_mel_tile(int mode);
 
 /* on != 0: the next launches of ss_mel_c1024<tile> do not poll at all -- a wave whose tile hand-off (a clip's last row pair,

@@ -85,6 +85,9 @@ struct ss_config {
     mutable unsigned tile_spin_stage[4] = {0, 0, 0, 0};
 };
 
+#if SS_LAB
+// Process-wide test aids of include/speechsauce_amd_debug.h: LAB BUILDS ONLY.  The product library's kernel selection is a pure
+// function of the configuration and the call (ss_device.h has the constant forms of these accessors).
 namespace {
 extern std::atomic<int> g_force_generic, g_mel_tile_off;
 extern std::atomic<unsigned> g_tile_fault;
@@ -96,14 +99,20 @@ int dbg_mel_build() { return g_mel_tile_off.load(std::memory_order_relaxed); }
 // a forced fault: no polling at all -- the first hand-off that is not there at once counts as lost
 unsigned dbg_tile_spin_limit() { return g_tile_fault.load(std::memory_order_relaxed) ? 0u : (1u << 24); }
 }  // namespace ss
+#endif
 
 namespace {
 
 thread_local const char *g_last_kernel = "";
+// per-wave stamps of the 512-point MFCC kernel: the buffer of the CURRENT call on this thread (ss_mfcc_shader_clock sets it
+// around its own launches; nothing process-wide in the product build)
+thread_local unsigned long long *g_call_stamps = nullptr;
+#if SS_LAB
 std::atomic<unsigned long long *> g_stamp_buffer{nullptr};  // ss_debug_stamp_buffer
 // test aids of include/speechsauce_amd_debug.h (process-wide)
 std::atomic<int> g_force_generic{0}, g_mel_tile_off{0};
 std::atomic<unsigned> g_tile_fault{0};
+#endif
 
 int hip_fail(hipError_t e, const char *what)
 {
@@ -325,7 +334,10 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
             f.dbg = nullptr;
         }
 #endif
-        f.dbg = g_stamp_buffer.load(std::memory_order_relaxed);
+        f.dbg = g_call_stamps;
+#if SS_LAB
+        if (!f.dbg) f.dbg = g_stamp_buffer.load(std::memory_order_relaxed);
+#endif
         const hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
             g_last_kernel = info.kernel_name;
@@ -1074,7 +1086,8 @@ struct Rccl {
 
 std::mutex g_rccl_mu;
 std::string g_rccl_path;       // ss_rccl_library
-std::unique_ptr<Rccl> g_rccl;  // resolved once
+std::unique_ptr<Rccl> g_rccl;  // set once a resolution has succeeded
+std::string g_rccl_error;      // why the last attempt failed
 
 bool rccl_from(void *handle, const char *origin, Rccl &r)
 {
@@ -1090,17 +1103,26 @@ bool rccl_from(void *handle, const char *origin, Rccl &r)
 const Rccl *rccl()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
-    if (g_rccl) return g_rccl->ok() ? g_rccl.get() : nullptr;
-    g_rccl.reset(new Rccl());
+    if (g_rccl) return g_rccl.get();  // only a successful resolution is kept
+    std::unique_ptr<Rccl> r(new Rccl());
+    auto keep = [&]() {
+        g_rccl = std::move(r);
+        return g_rccl.get();
+    };
     if (!g_rccl_path.empty()) {
         void *h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (h && rccl_from(h, g_rccl_path.c_str(), *g_rccl)) return g_rccl.get();
-        return nullptr;  // an explicit path that does not load is an error, not a reason to guess
+        if (h && rccl_from(h, g_rccl_path.c_str(), *r)) return keep();
+        // an explicit path that does not load is an error, not a reason to guess; nothing is cached, so a corrected
+        // ss_rccl_library call is accepted and tried again
+        const char *de = h ? nullptr : dlerror();
+        g_rccl_error = g_rccl_path + (h ? ": ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd not all found" : std::string(": ") + (de ? de : "dlopen failed"));
+        return nullptr;
     }
-    if (rccl_from(RTLD_DEFAULT, "already in the global symbol scope", *g_rccl)) return g_rccl.get();
+    g_rccl_error = "no mapped copy, librccl.so.1 / librccl.so not loadable";
+    if (rccl_from(RTLD_DEFAULT, "already in the global symbol scope", *r)) return keep();
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
         void *h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-        if (h && rccl_from(h, "already mapped (RTLD_NOLOAD)", *g_rccl)) return g_rccl.get();
+        if (h && rccl_from(h, "already mapped (RTLD_NOLOAD)", *r)) return keep();
     }
     {
         // a copy mapped under another name (torch/lib/librccl.so is loaded by path): look through the process's objects
@@ -1118,12 +1140,12 @@ const Rccl *rccl()
         }
         if (!ctx.path.empty()) {
             void *h = dlopen(ctx.path.c_str(), RTLD_NOW | RTLD_NOLOAD);
-            if (h && rccl_from(h, ctx.path.c_str(), *g_rccl)) return g_rccl.get();
+            if (h && rccl_from(h, ctx.path.c_str(), *r)) return keep();
         }
     }
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
         void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (h && rccl_from(h, name, *g_rccl)) return g_rccl.get();
+        if (h && rccl_from(h, name, *r)) return keep();
     }
     return nullptr;
 }
@@ -1152,7 +1174,7 @@ int ss_all_gather_features(void *nccl_comm, const float *d_block, size_t elems_p
     if (!nccl_comm || !d_block || !d_out) return ss::fail(SS_ERR_ARG, "null argument");
     if (elems_per_rank == 0) return SS_OK;
     const Rccl *r = rccl();
-    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (no mapped copy, librccl.so.1 / librccl.so not loadable)");
+    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (" + g_rccl_error + ")");
     // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream)
     const int rc = r->all_gather(d_block, d_out, elems_per_rank, kNcclFloat32, nccl_comm, static_cast<hipStream_t>(stream));
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
@@ -1167,7 +1189,7 @@ int ss_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_r
     if (rank == root && !d_out) return ss::fail(SS_ERR_ARG, "the root needs an output buffer");
     if (elems_per_rank == 0) return SS_OK;
     const Rccl *r = rccl();
-    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (no mapped copy, librccl.so.1 / librccl.so not loadable)");
+    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (" + g_rccl_error + ")");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (rank != root) {
         const int rc = r->send(d_block, elems_per_rank, kNcclFloat32, root, nccl_comm, st);
@@ -1238,6 +1260,66 @@ int ss_power_spectrum_frames(const ss_config *cfg, const float *frames, size_t r
                          });
 }
 
+}  // extern "C"
+
+namespace {
+
+// The framing kernels for `batch` clips of n_samples (row stride ld): frames [batch x T x flen]; d_window: flen floats or null.
+int launch_stack_frames(const float *d_x, size_t batch, size_t n_samples, size_t ld, uint32_t flen, uint32_t step, size_t T, int mode,
+                        int pad_reflect, const float *d_window, float *d_frames, hipStream_t stream)
+{
+    if (n_samples > 0x7fffffffull || static_cast<unsigned long long>(T) * step + flen > 0xffffffffull) return ss::fail(SS_ERR_ARG, "clip too long");
+    const unsigned long long total = static_cast<unsigned long long>(batch) * T * flen;
+    const bool aligned4 = mode == ss::FRAME_NORMAL && flen % 4 == 0 && step % 4 == 0 && ld % 4 == 0 &&
+                          reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_frames) % 16 == 0 &&
+                          (!d_window || reinterpret_cast<uintptr_t>(d_window) % 16 == 0);
+    if (aligned4) {
+        const unsigned long long rows = static_cast<unsigned long long>(batch) * T;
+        const unsigned rpb = 4;
+        const unsigned long long nb = (rows + rpb - 1) / rpb;
+        if (nb > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "batch too large");
+        hipLaunchKernelGGL(ss_stack_frames_rows4, dim3(static_cast<unsigned>(nb)), dim3(64), 0, stream, d_x, static_cast<unsigned long long>(ld),
+                           flen / 4, step, static_cast<unsigned>(T), d_window, d_frames, rows, rpb);
+        const hipError_t e4 = hipGetLastError();
+        if (e4 != hipSuccess) return hip_fail(e4, "ss_stack_frames_rows4");
+        g_last_kernel = "ss_stack_frames_rows4";
+        return SS_OK;
+    }
+    const unsigned long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "batch too large");
+    hipLaunchKernelGGL(ss_stack_frames_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, d_x, static_cast<unsigned long long>(ld),
+                       static_cast<unsigned>(n_samples), flen, step, static_cast<unsigned>(T), mode, pad_reflect, d_window, d_frames, total);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "ss_stack_frames_kernel");
+    g_last_kernel = "ss_stack_frames_kernel";
+    return SS_OK;
+}
+
+// processing.rs:77-78, :91-92, :101: frame sizes and count from the reference's own loose arguments (no SpeechConfig, no FFT length)
+int frames_shape(size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride, int zero_padding, size_t &T, uint32_t &flen,
+                 uint32_t &step)
+{
+    ss_params p{};
+    int rc = ss_params_default(&p, sample_rate ? sample_rate : 1u);
+    if (rc) return rc;
+    if (sample_rate == 0) return ss::fail(SS_ERR_BAD_CONFIG, "sample_rate must be > 0");
+    p.frame_length = frame_length;
+    p.frame_stride = frame_stride;
+    p.framing = zero_padding ? SS_FRAMING_PADDED : SS_FRAMING_CONTRACT;
+    ss::Derived d;
+    rc = ss::derive(p, d);
+    if (rc) return rc;
+    rc = ss::num_frames(p, n_samples, T);
+    if (rc) return rc;
+    flen = d.flen;
+    step = d.step;
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int ss_stack_frames_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_frames,
                            void *stream)
 {
@@ -1249,38 +1331,65 @@ int ss_stack_frames_device(const ss_config *cfg, const float *d_x, size_t batch,
     if (rc) return rc;
     if (batch == 0) return SS_OK;
     if (!d_x || !d_frames) return ss::fail(SS_ERR_ARG, "null buffer");
-    if (n_samples > 0x7fffffffull || static_cast<unsigned long long>(T) * h.d.step + h.d.flen > 0xffffffffull)
-        return ss::fail(SS_ERR_ARG, "clip too long");
     rc = check_device(cfg);
     if (rc) return rc;
     int mode = ss::FRAME_NORMAL;
     if (h.params.framing == SS_FRAMING_LITERAL) mode = T > 2 ? ss::FRAME_ZERO : ss::FRAME_FIRST;
     else if (h.params.framing == SS_FRAMING_CENTER) mode = ss::FRAME_CENTER;
     else if (h.params.framing == SS_FRAMING_PADDED) mode = ss::FRAME_PADDED;
-    const unsigned long long total = static_cast<unsigned long long>(batch) * T * h.d.flen;
-    const bool aligned4 = mode == ss::FRAME_NORMAL && h.d.flen % 4 == 0 && h.d.step % 4 == 0 && ld % 4 == 0 &&
-                          reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_frames) % 16 == 0 &&
-                          (!cfg->d_window_mfcc || reinterpret_cast<uintptr_t>(cfg->d_window_mfcc) % 16 == 0);
-    if (aligned4) {
-        const unsigned long long rows = static_cast<unsigned long long>(batch) * T;
-        const unsigned rpb = 4;
-        const unsigned long long nb = (rows + rpb - 1) / rpb;
-        if (nb > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "batch too large");
-        hipLaunchKernelGGL(ss_stack_frames_rows4, dim3(static_cast<unsigned>(nb)), dim3(64), 0, static_cast<hipStream_t>(stream), d_x,
-                           static_cast<unsigned long long>(ld), h.d.flen / 4, h.d.step, static_cast<unsigned>(T), cfg->d_window_mfcc, d_frames, rows, rpb);
-        const hipError_t e4 = hipGetLastError();
-        if (e4 != hipSuccess) return hip_fail(e4, "ss_stack_frames_rows4");
-        g_last_kernel = "ss_stack_frames_rows4";
-        return SS_OK;
-    }
-    const unsigned long long blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "batch too large");
-    hipLaunchKernelGGL(ss_stack_frames_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), d_x,
-                       static_cast<unsigned long long>(ld), static_cast<unsigned>(n_samples), h.d.flen, h.d.step, static_cast<unsigned>(T), mode,
-                       h.params.pad_mode == SS_PAD_REFLECT ? 1 : 0, cfg->d_window_mfcc, d_frames, total);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "ss_stack_frames_kernel");
-    g_last_kernel = "ss_stack_frames_kernel";
+    return launch_stack_frames(d_x, batch, n_samples, ld, h.d.flen, h.d.step, T, mode, h.params.pad_mode == SS_PAD_REFLECT ? 1 : 0,
+                               cfg->d_window_mfcc, d_frames, static_cast<hipStream_t>(stream));
+}
+
+// ---- stack_frames with the reference's own argument list (processing.rs:65-76): no SpeechConfig, no FFT length ----
+
+int ss_stack_frames_shape(size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride, int zero_padding,
+                          size_t *num_frames, size_t *frame_len)
+{
+    if (!num_frames || !frame_len) return ss::fail(SS_ERR_ARG, "null argument");
+    size_t T = 0;
+    uint32_t flen = 0, step = 0;
+    const int rc = frames_shape(n_samples, sample_rate, frame_length, frame_stride, zero_padding, T, flen, step);
+    if (rc) return rc;
+    *num_frames = T;
+    *frame_len = flen;
+    return SS_OK;
+}
+
+int ss_stack_frames_signal_device(const float *d_x, size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride,
+                                  const float *d_window, int zero_padding, float *d_frames, void *stream)
+{
+    size_t T = 0;
+    uint32_t flen = 0, step = 0;
+    const int rc = frames_shape(n_samples, sample_rate, frame_length, frame_stride, zero_padding, T, flen, step);
+    if (rc) return rc;
+    if (!d_x || !d_frames) return ss::fail(SS_ERR_ARG, "null buffer");
+    return launch_stack_frames(d_x, 1, n_samples, n_samples, flen, step, T, zero_padding ? ss::FRAME_PADDED : ss::FRAME_NORMAL, 0, d_window,
+                               d_frames, static_cast<hipStream_t>(stream));
+}
+
+int ss_stack_frames_signal(const float *x, size_t n_samples, uint32_t sample_rate, float frame_length, float frame_stride,
+                           const float *window, int zero_padding, float *frames)
+{
+    size_t T = 0;
+    uint32_t flen = 0, step = 0;
+    int rc = frames_shape(n_samples, sample_rate, frame_length, frame_stride, zero_padding, T, flen, step);
+    if (rc) return rc;
+    if (!x || !frames) return ss::fail(SS_ERR_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return ss::fail(SS_ERR_HIP, "no usable HIP device: the speechsauce_amd hot path has no CPU fallback");
+    // a cold path (no config, so no staging pipeline to reuse): plain allocations and synchronous copies
+    DeviceBuf dx, dw, df;
+    const size_t out_bytes = T * static_cast<size_t>(flen) * sizeof(float);
+    if ((rc = dx.alloc(n_samples * sizeof(float))) || (rc = df.alloc(out_bytes))) return rc;
+    if (window && (rc = dw.alloc(flen * sizeof(float)))) return rc;
+    SS_HIP(hipMemcpy(dx.p, x, n_samples * sizeof(float), hipMemcpyHostToDevice));
+    if (window) SS_HIP(hipMemcpy(dw.p, window, flen * sizeof(float), hipMemcpyHostToDevice));
+    rc = ss_stack_frames_signal_device(dx.as<float>(), n_samples, sample_rate, frame_length, frame_stride, window ? dw.as<float>() : nullptr,
+                                       zero_padding, df.as<float>(), nullptr);
+    if (rc) return rc;
+    SS_HIP(hipMemcpy(frames, df.p, out_bytes, hipMemcpyDeviceToHost));
     return SS_OK;
 }
 
@@ -1419,7 +1528,8 @@ int ss_preemphasis(const float *x, size_t n_samples, long shift, float cof, floa
 
 const char *ss_last_kernel_name(void) { return g_last_kernel; }
 
-// ---- test aids (include/speechsauce_amd_debug.h) ----
+// ---- test aids (include/speechsauce_amd_debug.h): exported by the LAB library only ----
+#if SS_LAB
 int ss_debug_force_generic(int on)
 {
     g_force_generic.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -1453,6 +1563,46 @@ int ss_debug_poison_lds(void *stream)
     SS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     hipError_t e = ss::launch_poison_lds(static_cast<hipStream_t>(stream), cus);
     if (e != hipSuccess) return hip_fail(e, "launch_poison_lds");
+    return SS_OK;
+}
+#endif  // SS_LAB
+
+// Shader clock the part held during launches of the MFCC batch kernel: `launches` launches on `stream`, each with the kernel's
+// per-wave stamps switched on (a wave writes its lifetime in shader cycles, s_memtime, and on the constant 100 MHz clock,
+// s_memrealtime, once, as it ends), into a buffer this call owns; the mean of cycles / lifetime over the waves of the last
+// launch.  A per-call diagnostic: nothing process-wide is touched, launches of other threads are not affected.  The stamps
+// exist in the 512-point kernel only: SS_ERR_UNSUPPORTED for configurations that run on another kernel.
+int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_out,
+                         void *stream, int launches, float *ghz)
+{
+    if (!cfg || !ghz || launches <= 0) return ss::fail(SS_ERR_ARG, "bad clock request");
+    *ghz = 0.f;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16, words = nwaves * 6;
+    DeviceBuf db;
+    int rc = db.alloc(words * sizeof(unsigned long long));
+    if (rc) return rc;
+    SS_HIP(hipMemsetAsync(db.p, 0, words * sizeof(unsigned long long), s));
+    g_call_stamps = db.as<unsigned long long>();
+    for (int i = 0; i < launches && rc == SS_OK; ++i) rc = ss_mfcc_batch_device(cfg, d_x, batch, n_samples, ld, d_out, stream);
+    g_call_stamps = nullptr;
+    const bool stamped = std::strncmp(g_last_kernel, "ss_mfcc_c256<", 13) == 0;
+    const hipError_t es = hipStreamSynchronize(s);
+    if (rc) return rc;
+    if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize");
+    if (!stamped) return ss::fail(SS_ERR_UNSUPPORTED, "the shader-clock stamps exist in the 512-point MFCC kernel only");
+    std::vector<unsigned long long> w(words);
+    SS_HIP(hipMemcpy(w.data(), db.p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum = 0.0;
+    size_t n = 0;
+    for (size_t k = 0; k < nwaves; ++k) {
+        const unsigned long long t0 = w[6 * k], t1 = w[6 * k + 2], cyc = w[6 * k + 5];
+        if (t1 <= t0 || (cyc >> 40) != 1) continue;  // waves that did not run / the two table waves of a workgroup (they report something else)
+        sum += static_cast<double>(cyc & ((1ull << 40) - 1)) / (static_cast<double>(t1 - t0) * 10.0);  // cycles per ns
+        ++n;
+    }
+    if (n == 0) return ss::fail(SS_ERR_DEVICE, "no wave reported its lifetime");
+    *ghz = static_cast<float>(sum / static_cast<double>(n));
     return SS_OK;
 }
 

@@ -9,7 +9,8 @@
 // and the call -- no environment knob is read anywhere, and the timing-attribution switches of the headline kernel
 // (SS_ABLATE) are compiled out.  `make lab` (-DSS_LAB=1) builds libspeechsauce_amd_lab.so with the A/B knobs (SS_RES,
 // SS_WAVES, SS_MEL_WAVES, SS_HOST_CHUNK_MB, SS_HOST_SMALL_KB, SS_DEBUG_TIMES, SS_DEBUG_ROWS) and the stage-removal builds
-// tools/ablate.sh drives.  The test aids of include/speechsauce_amd_debug.h exist in both.
+// tools/ablate.sh drives, and the process-wide test aids of include/speechsauce_amd_debug.h (LDS poisoning, kernel-selection
+// overrides, fault injection, the stamp buffer): those exist in the lab library ONLY.
 #ifndef SS_LAB
 #define SS_LAB 0
 #endif
@@ -19,11 +20,18 @@
 
 namespace ss {
 
-// Process-wide test aids set through include/speechsauce_amd_debug.h (ss_api.hip)
+// Process-wide test aids set through include/speechsauce_amd_debug.h (ss_api.hip, lab builds); constants in the product build
+#if SS_LAB
 bool dbg_force_generic();        // ss_debug_force_generic: every configuration on the generic kernel
 bool dbg_mel_tile_off();         // ss_debug_mel_tile(0): eight waves, direct stores instead of the whole-line tile
 int dbg_mel_build();             // 0 automatic, 1 = the above, 2 eight-wave builds only, 3 the twelve-wave build where it exists
 unsigned dbg_tile_spin_limit();  // polls before a tile hand-off counts as a protocol error (ss_debug_tile_fault: 0)
+#else
+constexpr bool dbg_force_generic() { return false; }
+constexpr bool dbg_mel_tile_off() { return false; }
+constexpr int dbg_mel_build() { return 0; }
+constexpr unsigned dbg_tile_spin_limit() { return 1u << 24; }
+#endif
 
 enum OutKind : int32_t {
     OUT_MFCC = 0,   // [frames x num_cepstral]                    feature.rs:99-148
@@ -85,8 +93,10 @@ struct LaunchInfo {
 // Generic front-end (any power-of-two fft_points in [32, 4096]; with a.blu_n != 0 the chirp-z build for other lengths, log2c then
 // being the length of its complex FFT).
 hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info);
-// Test aid: every word of every CU's LDS := 0xFFFFFFFF (ss_debug_poison_lds).
+#if SS_LAB
+// Test aid (lab library): every word of every CU's LDS := 0xFFFFFFFF (ss_debug_poison_lds).
 hipError_t launch_poison_lds(hipStream_t stream, int num_cus);
+#endif
 // Element-wise pre-emphasis (processing.rs:31-53).
 hipError_t launch_preemphasis(const float *x, float *y, size_t n, size_t shift, float cof, hipStream_t stream);
 
@@ -156,6 +166,11 @@ struct Mel2048Args {
 };
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+#if SS_LAB
+// the retired whole-line-tile build (tools/experiments/ss_mel2048_tile.hip, linked into the lab library only);
+// hipErrorInvalidValue where the shape has no tile build
+hipError_t launch_mel_c1024_tile(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+#endif
 // fft_points = 1024 mel-spectrogram kernel (ss_mfcc1024.hip): same argument block, table layout ss::mfcc1024_layout
 hipError_t launch_mel_c512(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 // fft_points = 4096 mel-spectrogram kernel (ss_mfcc4096.hip): same argument block, table layout ss::mfcc4096_layout

@@ -494,6 +494,8 @@ __global__ void ss_preemphasis_kernel(const float *__restrict__ x, float *__rest
     }
 }
 
+#if SS_LAB
+// (lab library only: ss_debug_poison_lds)
 // One workgroup takes a CU's whole LDS (160 KB), so a grid of several workgroups per CU sweeps every CU several times.
 __global__ __launch_bounds__(256) void ss_poison_lds_kernel(unsigned words)
 {
@@ -504,9 +506,11 @@ __global__ __launch_bounds__(256) void ss_poison_lds_kernel(unsigned words)
     // keep the stores observable
     if (w[(threadIdx.x * 97u) % words] != 0xFFFFFFFFu) __builtin_trap();
 }
+#endif
 
 }  // namespace
 
+#if SS_LAB
 hipError_t launch_poison_lds(hipStream_t stream, int num_cus)
 {
     const size_t lds = 160 * 1024;
@@ -516,6 +520,7 @@ hipError_t launch_poison_lds(hipStream_t stream, int num_cus)
     hipLaunchKernelGGL(ss_poison_lds_kernel, dim3(grid), dim3(256), lds, stream, static_cast<unsigned>(lds / 4));
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_front_generic(const FrontArgs &a, uint32_t log2c, hipStream_t stream, int num_cus, LaunchInfo *info)
 {

@@ -13,11 +13,14 @@
 //   * untangle with ds_bpermute_b32 (partner = lane 32-j, register 31-r); only bins 0..512 are produced: the mel
 //     bank ends at bin (F+1)/2 (feature.rs:69-70) and this path has no frame energy.
 //   * (|X| wnorm)^2 (functions.rs:166-169, feature.rs:164) -> P row in LDS -> banded mel reduction, 4 filters per lane.
-//   * output [clip][m][r]: with at least one clip per CU the clip's block is collected in a CU-wide LDS tile and leaves as
-//     whole 128-byte lines (TILE below; HBM writes = the output, 1.00x).  Otherwise each lane stores its four mel values
-//     straight to out[clip][m][r]: the wave's two rows are adjacent words, so the stores are 8-byte pieces of lines
-//     whose other rows come from other waves and merge in L2 only partly (writes 1.39x the output).  No workgroup barrier
-//     anywhere in the main loop in either build (a barrier-synchronised transposing tile measured 20 % slower in round 1).
+//   * output [clip][m][r]: each lane stores its four mel values straight to out[clip][m][r]; the wave's two rows are adjacent
+//     words, so the stores are 8-byte pieces of lines whose other rows come from other waves of the same CU within a few
+//     microseconds and merge in L2 only partly (HBM writes ~1.4x the output = traffic 1.09x the algorithmic bytes).  The CU-wide
+//     whole-line tile that removed this (writes 1.00x, same duration) lives in tools/experiments/ss_mel2048_tile.hip since round 4:
+//     it does not fit beside twelve waves, and no BASELINE shape selected it any more.  No workgroup barrier anywhere in the main
+//     loop (a barrier-synchronised transposing tile measured 20 % slower in round 1).
+//   * stft output [clip][row][1025] complex64: see the note on write-dominated streams in DESIGN.md (the 1024-clip shape's
+//     269 MB output sits on the edge of the 256 MiB Infinity Cache).
 // Rows >= real_rows (the trailing n_pad rows the reference never writes, functions.rs:121) come out as exact zeros.
 #include "ss_device.h"
 #include "ss_fft_reg.h"
@@ -59,21 +62,7 @@ constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange re
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
 
-// TILE (mel output; rows <= 32 and a multiple of 4, filters <= 128 and a multiple of 8; batch >= CUs): a clip's [mel][row]
-// block is collected in a CU-wide LDS tile and leaves as whole 128-byte lines.  No workgroup barrier: two LDS counters per
-// tile buffer that only grow -- row pairs written into it, wave shares written out of it -- tell a wave when a clip is
-// complete and when its buffer may be reused; each wave writes a fixed share (filters 8w .. 8w + 7 and 8(w + 8) ..) of every
-// clip at its next unit after the clip completed, and the rest when it runs out of units.  kTileBufs buffers: the CU's waves
-// run ahead of its slowest wave by at most kTileBufs - 1 clips before they wait.  Measured on cfg3 (profiles/r02): same
-// duration as the direct stores (52.9 vs 52.8 us), HBM traffic 1.007x instead of 1.09x the algorithmic bytes.  What it took
-// to get there: polls as relaxed atomics (a volatile LDS poll is a flat_load whose vmcnt(0) drains the prefetch), counter
-// reads issued at the top of the unit, no returning atomics, 16-byte stores only (one wave flushing a whole tile: +5 us;
-// slices handed out through a CAS counter: +9 us).
-constexpr int kTileRows = 32, kTileMels = 128, kTilePitch = 36;  // [mel][row], rows of 144 bytes: 16-byte aligned for the flush
-constexpr int kTileBufs = 3;  // clips a CU may have open at once (its waves run ahead of the slowest by up to kTileBufs - 1 clips)
-constexpr int kTileFloats = kTileBufs * kTileMels * kTilePitch;
-
-template <int kWavesM, bool STFT, bool FULLP = false, bool TILE = false, bool FIXMEL = false>
+template <int kWavesM, bool STFT, bool FULLP = false>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
 {
     constexpr bool PREFETCH_M = kWavesM <= 8;  // the next unit's samples are requested while the current one is in its second pass
@@ -97,34 +86,15 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     const int *s_start = reinterpret_cast<const int *>(s_tab + L::kStart);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     const float *s_melw = s_tab + L::kMelW;
-    // behind the table block: 4 words copied with it ([0] = the poll bound of the tile hand-offs), then the unit counter
-    const unsigned *s_ctl = reinterpret_cast<const unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch);
+    // behind the table block: 4 words copied with it, then the unit counter
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
-    float *s_tile = reinterpret_cast<float *>(s_next + 4);                        // TILE: [kTileBufs][32][129]
-    // both counters only ever grow, so nobody needs the value its own increment returned: clip c (the g-th user of its
-    // buffer, g = (c - c_lo) / kTileBufs) may write the tile once s_fd == kWavesM g, and is complete at s_cnt == pairs (g + 1)
-    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tile + kTileFloats);           // row pairs written into buffer b so far
-    // polling reads of those words: relaxed atomics, not volatile -- a volatile access keeps the generic address space and
-    // becomes a flat_load, whose s_waitcnt vmcnt(0) drains the wave's outstanding global loads and stores on every poll
-    auto peek = [](const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    unsigned *s_fd = s_cnt + kTileBufs;  // shares of buffer b written out so far (kWavesM per clip)
-    const unsigned pairs0 = (a.rows + 1) / 2;
-    // TILE: the workgroup's range is made of whole clips
-    const unsigned c_lo = static_cast<unsigned>(static_cast<unsigned long long>(a.batch) * blockIdx.x / gridDim.x);
-    const unsigned c_hi = static_cast<unsigned>(static_cast<unsigned long long>(a.batch) * (blockIdx.x + 1) / gridDim.x);
 
     {
         const int n4 = (L::kMelW + 32 * a.mel_wpitch + 4) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) {
             const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
-            *s_next = (TILE ? c_lo * pairs0 : static_cast<unsigned>(units0 * blockIdx.x / gridDim.x)) + kWavesM;
-            if (TILE) {
-                for (int b = 0; b < kTileBufs; ++b) {
-                    s_cnt[b] = 0u;
-                    s_fd[b] = 0u;
-                }
-            }
+            *s_next = static_cast<unsigned>(units0 * blockIdx.x / gridDim.x) + kWavesM;
         }
     }
     __syncthreads();
@@ -144,61 +114,8 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     // pull them from an LDS counter
     const unsigned pairs = (a.rows + 1) / 2;
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
-    const unsigned u_lo = TILE ? c_lo * pairs : static_cast<unsigned>(units * blockIdx.x / gridDim.x);
-    const unsigned u_hi = TILE ? c_hi * pairs : static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
-    // TILE: a finished clip's tile leaves in slices of eight filters (eight whole lines, one 16-byte store per lane); wave w
-    // writes slices w, w + kWavesM, ... of every clip, at its next stop after the clip's last row pair has arrived; once
-    // all kWavesM shares are out the buffer is clip + kTileBufs's.  (One wave writing all 128 lines held that wave up for
-    // microseconds; handing slices out through an LDS counter cost four LDS round trips per slice.)
-    const int nsl = (M + 7) >> 3;
-    unsigned fl_next = c_lo;  // the oldest clip whose share this wave has not written yet
-    auto tile_full = [&](unsigned c) { return pairs * ((c - c_lo) / kTileBufs + 1u); };  // s_cnt of c's buffer once c is complete
-    auto flush_one = [&]() {  // this wave's share of clip fl_next, which is complete
-        const unsigned fb = (fl_next - c_lo) % kTileBufs;
-        // rows % 4 == 0 and filters % 8 == 0 here (launcher): lane l holds rows 4 (l & 7) .. + 3 of filter 8 sl + (l >> 3)
-        const float *tb = s_tile + fb * (kTileMels * kTilePitch) + (lane >> 3) * kTilePitch + (lane & 7) * 4;
-        float *dstc = a.out + static_cast<unsigned long long>(fl_next) * M * R + (lane >> 3) * R + (lane & 7) * 4;
-        if ((lane & 7) * 4 < R) {
-            for (int sl = wave; sl < nsl; sl += kWavesM) *reinterpret_cast<float4 *>(dstc + sl * 8 * R) = *reinterpret_cast<const float4 *>(tb + sl * 8 * kTilePitch);
-        }
-        wave_order();
-        if (lane == 0) atomicAdd(s_fd + fb, 1u);
-        ++fl_next;
-    };
-    // A hand-off that never comes (a protocol error: it cannot happen unless a wave of this workgroup died or the counters
-    // were corrupted) must neither hang nor pass for a result.  The waits are bounded; a wave that runs into the bound sets
-    // the config's device error word (pinned host memory, so the host sees it without a copy: ss_api.hip turns it into
-    // SS_ERR_DEVICE at the next launch / synchronisation point on the config) and ends (s_endpgm): it writes nothing more
-    // into the tile, flushes nothing, takes no further unit.  Its peers then run into their own bounds and end as well.
-    // (A trap measured 2 us on the whole launch; NaNs in the output could be overwritten by a later flush.)
-    // (Everything about this lives on the cold side of a branch, behind ONE kernel argument: the kernel sits at the SGPR limit
-    // and every extra argument or flag on the hot path measured +1 us of 49.)
-    auto protocol_error = [&]() {
-        if (lane == 0 && a.ctl) __hip_atomic_store(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_s_waitcnt(0);  // the store has left the wave
-        __builtin_amdgcn_endpgm();       // the wave ends here: no flag to test anywhere on the hot path
-    };
-    // polls before a hand-off counts as lost: the word behind the table block, copied into LDS with it (2^24 in normal operation:
-    // ~0.5 s; ss_debug_tile_fault sets 0, so that the first wait that is not satisfied at once takes the error path).  An LDS
-    // read on purpose: a global load here would wait on vmcnt, i.e. for this wave's outstanding output stores (+2 us of 49).
-    auto spin_limit = [&]() { return peek(s_ctl); };
-    auto flush_share = [&](unsigned upto, bool wait) {
-        while (fl_next < upto) {
-            const unsigned fb = (fl_next - c_lo) % kTileBufs;
-            const unsigned full = tile_full(fl_next);
-            if (peek(s_cnt + fb) != full) {
-                if (!wait) return;
-                const unsigned lim = spin_limit();
-                unsigned tries = 0;
-                while (peek(s_cnt + fb) != full && tries < lim) {
-                    __builtin_amdgcn_s_sleep(1);
-                    ++tries;
-                }
-                if (peek(s_cnt + fb) != full) protocol_error();
-            }
-            flush_one();
-        }
-    };
+    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
     // (clip, row) of this half-wave within a unit, and the loads of its window: functions.rs:137-151, the window covers the
     // last W samples ending at chunk r + n_pad
     auto load_unit = [&](unsigned un, float2 (&vv)[32]) {
@@ -243,6 +160,13 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
     unsigned unit = u_lo + wave;
     float2 v[32];
     if (unit < u_hi) load_unit(unit, v);
+    if (STFT) {
+        // the first unit's samples have no stores behind them: as many dropped stores as a unit issues, so that both ways into
+        // the loop look alike to the compiler's wait counting (see ss_mfcc512.hip)
+        const __amdgpu_buffer_rsrc_t none = out_rsrc(a.out, 0u);
+#pragma unroll
+        for (int k = 0; k < 33; ++k) buf_store(make_float2(0.f, 0.f), none, 64 * k);
+    }
     while (unit < u_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);
@@ -257,16 +181,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     const float4 w = s_win4[e >> 1];
                     v[e] = make_float2(v[e].x * w.x, v[e].y * w.y);
                     v[e + 1] = make_float2(v[e + 1].x * w.z, v[e + 1].y * w.w);
-                }
-                // TILE: this wave's share of the finished clips behind this one leaves here, right after the unit's samples
-                // have arrived: vmcnt retires in order and a write is acknowledged microseconds after it was issued, so
-                // stores issued later in the unit (ahead of or behind the next unit's loads) made that unit wait for them
-                // TILE: the two counters this unit will look at are read here, long before their values are needed, so that the
-                // round trips hide behind the transform (a stale value only postpones the flush to the wave's next unit)
-                unsigned seen_cnt = 0, seen_fd = 0;
-                if (TILE) {
-                    seen_cnt = peek(s_cnt + (fl_next - c_lo) % kTileBufs);
-                    seen_fd = peek(s_fd + (clip - c_lo) % kTileBufs);
                 }
                 // ---- 1024-point complex FFT: radix-32, transpose through LDS (one frame at a time), twiddle, radix-32 ----
                 fft_reg<32>(v);
@@ -304,7 +218,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 // read where they are used they came a pair at a time, each one exposed LDS round trip (with two waves per SIMD
                 // nobody hides it).
                 // the window registers are dead now: the next unit's samples load into them while this one is finished
-                if (TILE && fl_next < clip && seen_cnt == tile_full(fl_next)) flush_one();
                 if (PREFETCH_M && next < u_hi) load_unit(next, v);
                 // (Requesting the sixteen twiddle pairs in one or two batches in front of the products, or reading the unit claim
                 // late, measured within +-0.3 us here -- unlike in the 4096-point kernel -- and perturbs this kernel's register
@@ -320,8 +233,28 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 // ---- untangle: k = j + 32 r, r < 16 (and its mirror 1024 - k for the stft output), and k = 512 ----
                 // stft output (functions.rs:86-123, :166-169): X[k] * wnorm for all 1025 bins of the row, interleaved re, im;
                 // lanes of a half-wave write 256 contiguous bytes per register on both sides of the spectrum
-                float2 *srow = nullptr;
-                if (STFT && in_rows) srow = reinterpret_cast<float2 *>(a.out) + (static_cast<unsigned long long>(clip) * R + r) * 1025ull;
+                // (counted stores, ss_wave.h: one descriptor over the pair's rows that exist -- a clip's last pair may have one --
+                // so that the next unit's prefetched samples are waited for with these 33 stores still in flight)
+                __amdgpu_buffer_rsrc_t srs = out_rsrc(nullptr, 0u);
+                if (STFT) {
+                    const unsigned unit_s = __builtin_amdgcn_readfirstlane(unit);
+                    const unsigned clip_s = unit_s / pairs;
+                    const unsigned r0 = (unit_s - clip_s * pairs) * 2;
+                    srs = out_rsrc(a.out + (static_cast<unsigned long long>(clip_s) * R + r0) * 2050ull, min(2u, static_cast<unsigned>(R) - r0) * 8200u);
+#if SS_LAB && defined(SS_XSTFT)
+                    // store-path probes (lab builds, results wrong by design): 1 = rows at a pitch of 65 whole lines (wrapped into the
+                    // buffer), 2 = every store dropped by the range check (what the launch costs without its output)
+                    if (SS_XSTFT == 1) srs = out_rsrc(a.out + ((static_cast<unsigned long long>(clip_s) * R + r0) % 32000ull) * 2080ull, 2u * 8320u);
+                    if (SS_XSTFT == 2) srs = out_rsrc(a.out, 0u);
+                    // 4 = every unit writes into the first 4 MB of the buffer (stays in L2: the path to L2 without the path to HBM)
+                    if (SS_XSTFT == 4) srs = out_rsrc(a.out + (static_cast<unsigned long long>(unit_s) % 256ull) * 4100ull, 2u * 8200u);
+#endif
+                }
+#if SS_LAB && defined(SS_XSTFT)
+                const int srow_off = half * (SS_XSTFT == 1 ? 8320 : 8200);
+#else
+                const int srow_off = half * 8200;
+#endif
                 const float cs = 0.5f * a.scale;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
@@ -331,6 +264,9 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     float4 tw4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) tw4[i] = s_twn4[4 * hb + i];
+#if SS_LAB && defined(SS_XSTFT4)
+                    float4 xkeep = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         const int q = 8 * hb + qq;
@@ -344,11 +280,27 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         const float xr = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
                         const float xi = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
                         if (STFT) {
-                            if (srow) {
-                                srow[j + 32 * q] = make_float2(cs * xr, cs * xi);
-                                // 2 conj X[1024 - k] = 2 s - 2 X[k]
-                                srow[1024 - j - 32 * q] = make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
+#if SS_LAB && defined(SS_XSTFT4)
+                            // store-width probe (lab builds, results wrong by design): the same bytes as 16-byte stores
+                            static_assert(true, "");
+                            if (qq & 1) {
+                                buf_store(make_float4(cs * xr, cs * xi, xkeep.x, xkeep.y), srs, srow_off + (2 * j + 64 * (q >> 1)) * 8);
+                                buf_store(make_float4(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi), xkeep.z, xkeep.w), srs, srow_off + (1024 - 62 - 64 * (q >> 1) + 2 * j - 1) * 8);
+                            } else {
+                                xkeep = make_float4(cs * xr, cs * xi, cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
                             }
+#elif SS_LAB && defined(SS_XAUX)
+                            // cache-policy probe (lab builds): the row stores with other policy bits
+                            buf_store<SS_XAUX>(make_float2(cs * xr, cs * xi), srs, srow_off + (j + 32 * q) * 8);
+                            buf_store<SS_XAUX>(make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi)), srs, srow_off + (1024 - j - 32 * q) * 8);
+#else
+                            buf_store(make_float2(cs * xr, cs * xi), srs, srow_off + (j + 32 * q) * 8);
+                            // 2 conj X[1024 - k] = 2 s - 2 X[k]
+#if SS_LAB && defined(SS_XSTFT)
+                            if (SS_XSTFT != 3)  // 3 = the mirrored half of every row is not stored (half the bytes)
+#endif
+                            buf_store(make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi)), srs, srow_off + (1024 - j - 32 * q) * 8);
+#endif
                         } else {
                             prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
                             if (FULLP) {  // bins 513..1024 as well
@@ -358,15 +310,12 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         }
                     }
                 }
-                if (j == 0) {
+                if (!STFT && j == 0) {
                     const float2 z = u[16];  // X[512] = conj Z[512]
-                    if (STFT) {
-                        if (srow) srow[512] = make_float2(a.scale * z.x, -a.scale * z.y);
-                    } else {
-                        prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
-                    }
+                    prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
                 }
                 if (STFT) {
+                    buf_store(make_float2(a.scale * u[16].x, -a.scale * u[16].y), srs, j == 0 ? srow_off + 512 * 8 : kOobOffset);  // X[512] = conj Z[512]
                     wave_order();
                     if (!PREFETCH_M && next < u_hi) load_unit(next, v);
                     unit = next;
@@ -376,47 +325,12 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                 wave_order();
                 // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are
                 //      adjacent words of out[clip][m][.] ----
-                if (TILE) {
-                    const unsigned b = (clip - c_lo) % kTileBufs;
-                    float mv[4];
-                    if constexpr (FIXMEL) {
-                        // cfg3's bank shape (128 filters up to 8 kHz: 6 / 3 / 2 / 1 float4s per slot): every weight and tap is
-                        // requested before the first FMA -- one LDS wait for the stage
-                        mel4_fixed2<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
-                                               reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mv);
-                    } else {
-                        int off = 0;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            mv[s] = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
-                            off += a.mel_q4[s];
-                        }
-                    }
-                    // the buffer is ours once clip - kTileBufs has left it
-                    const unsigned freed = kWavesM * ((clip - c_lo) / kTileBufs);
-                    for (unsigned tries = 0; seen_fd != freed && peek(s_fd + b) != freed; ++tries) {
-                        flush_share(clip, false);  // the buffer may be waiting for this very wave's share of an older clip
-                        __builtin_amdgcn_s_sleep(1);
-                        if (tries > (1u << 24)) protocol_error();  // the buffer still belongs to an older clip: do not touch it
-                    }
-                    float *tcol = s_tile + b * (kTileMels * kTilePitch) + r;
-                    if (in_rows) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (fi[s] >= 0) tcol[fi[s] * kTilePitch] = mv[s];
-                    }
-                    wave_order();
-                    if (lane == 0) atomicAdd(s_cnt + b, 1u);
-                } else if (in_rows) {
+                if (in_rows) {
                     float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
-                    float mfix[4] = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (FIXMEL)
-                        mel4_fixed2<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
-                                               reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mfix);
                     int off = 0;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float m = FIXMEL ? mfix[s] : mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                        const float m = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = m;
                         off += a.mel_q4[s];
                     }
@@ -426,10 +340,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         }
         if (!PREFETCH_M && next < u_hi) load_unit(next, v);
         unit = next;
-    }
-    if (TILE) {
-        // out of units: what is left of the range's last clips (bounded wait for rows other waves are still computing)
-        flush_share(c_hi, true);
     }
 }
 
@@ -441,7 +351,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 // phases of the exchange fill it (left half-defined, the "undefined" halves are carried around the loop and spilled).
 // Twelve exchange regions + the tables are 134 KB of LDS, so the CU-wide whole-line tile of the 8-wave build (55 KB) does not
 // fit beside them: the rows leave as 8-byte pieces of lines (HBM writes 1.4x the output, traffic 1.09x the algorithmic bytes).
-template <bool FIXMEL>
+template <bool FIXMEL, bool STFT = false>
 __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a)
 {
     constexpr int kWavesM = 12;
@@ -602,9 +512,21 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         int st[4], fi[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            st[s] = reinterpret_cast<const int *>(s_tab + L::kStart)[s * 32 + j];
-            fi[s] = reinterpret_cast<const int *>(s_tab + L::kFilt)[s * 32 + j];
+            st[s] = STFT ? 0 : reinterpret_cast<const int *>(s_tab + L::kStart)[s * 32 + j];
+            fi[s] = STFT ? 0 : reinterpret_cast<const int *>(s_tab + L::kFilt)[s * 32 + j];
         }
+        // stft output (functions.rs:86-123, :166-169): X[k] * wnorm for all 1025 bins of the row, interleaved re, im, through a
+        // descriptor over the pair's rows that exist (counted stores, ss_wave.h); lanes of a half-wave write 256 contiguous bytes
+        // per register on both sides of the spectrum
+        __amdgpu_buffer_rsrc_t srs = out_rsrc(nullptr, 0u);
+        if (STFT) {
+            const unsigned unit_s = __builtin_amdgcn_readfirstlane(unit);
+            const unsigned clip_s = unit_s / pairs;
+            const unsigned r0 = (unit_s - clip_s * pairs) * 2;
+            srs = out_rsrc(a.out + (static_cast<unsigned long long>(clip_s) * R + r0) * 2050ull, min(2u, static_cast<unsigned>(R) - r0) * 8200u);
+        }
+        const int srow_off = half * 8200;
+        const float cs = 0.5f * a.scale;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
             float2 zcs[8];
@@ -626,8 +548,21 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 // 2 X[k] = s - i w d: two chained FMAs per component
                 const float xr = fmaf(w.y, df.x, fmaf(w.x, df.y, sm.x));
                 const float xi = fmaf(w.y, df.y, fmaf(-w.x, df.x, sm.y));
-                prow[j + 32 * q] = hs * (xr * xr + xi * xi);
+                if (STFT) {
+                    buf_store(make_float2(cs * xr, cs * xi), srs, srow_off + (j + 32 * q) * 8);
+                    // 2 conj X[1024 - k] = 2 s - 2 X[k]
+                    buf_store(make_float2(cs * fmaf(2.f, sm.x, -xr), -cs * fmaf(2.f, sm.y, -xi)), srs, srow_off + (1024 - j - 32 * q) * 8);
+                } else {
+                    prow[j + 32 * q] = hs * (xr * xr + xi * xi);
+                }
             }
+        }
+        if (STFT) {
+            buf_store(make_float2(a.scale * u[16].x, -a.scale * u[16].y), srs, j == 0 ? srow_off + 512 * 8 : kOobOffset);  // X[512] = conj Z[512]
+            wave_order();
+            SS_PRIOL(SS_P_TOP);
+            unit = __builtin_amdgcn_readfirstlane(next_v);
+            continue;
         }
         if (j == 0) {
             const float2 z = u[16];  // X[512] = conj Z[512]
@@ -668,13 +603,8 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 template <int kWavesM>
 hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    // whole-line stores through the CU-wide tile: mel output, every CU at least one clip, the tile fits next to everything else
-    const size_t lds_tile = lds + (kTileFloats + 2 * kTileBufs + 2) * sizeof(float);
-    const bool tile = !dbg_mel_tile_off() && !a.out_stft && !a.fullp && a.rows <= kTileRows && a.rows % 4 == 0 && a.n_filters <= 128 && a.n_filters % 8 == 0 &&
-                      lds_tile <= 160 * 1024 && a.batch >= static_cast<uint32_t>(num_cus > 0 ? num_cus : 256);
-    if (tile) lds = lds_tile;
     if (a.batch == 0) return hipSuccess;
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
@@ -688,13 +618,10 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
         return hipGetLastError();
     };
-    const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
-    // (the fixed-shape mel stage costs this kernel 84 bytes of scratch per lane beside the prefetched unit: measured 77 us against
+    // (a fixed-shape mel stage costs this kernel 84 bytes of scratch per lane beside the prefetched unit: measured 77 us against
     // 50; the run-time loops stay, with their remainders fetched in one batch)
-    if (tile) return go(ss_mel_c1024<kWavesM, false, false, true>, "ss_mel_c1024<tile>");
     if (a.out_stft) return go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>");
     if (a.fullp) return go(ss_mel_c1024<kWavesM, false, true>, "ss_mel_c1024<fullp>");
-    (void)m6321;
     return go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
 }
 
@@ -702,7 +629,7 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
 hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
     constexpr int kWavesM = 12;
-    if (a.out_stft || a.fullp || a.batch == 0) return hipErrorInvalidValue;
+    if (a.fullp || a.batch == 0) return hipErrorInvalidValue;
     const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
@@ -717,6 +644,7 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
         return hipGetLastError();
     };
+    if (a.out_stft) return go(ss_mel_c1024_w12<false, true>, "ss_mel_c1024<w12,stft>");
     const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
     return m6321 ? go(ss_mel_c1024_w12<true>, "ss_mel_c1024<w12,mel6321>") : go(ss_mel_c1024_w12<false>, "ss_mel_c1024<w12>");
 }
@@ -725,14 +653,37 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    // Eight waves per CU (whole-line tile when the batch allows it) or twelve (direct stores)?  A unit (two rows) takes a wave
-    // 1.29 x as long with three waves on its SIMD as with two (cfg3, one box: 8.0 us against 6.2), and a CU's units go round in
-    // ceil(units / waves) rounds: twelve waves win unless the CU's share of units fits eight waves much better (cfg3: 64 units
-    // per CU, 8 rounds of 8 against 5.3 -> 6 of 12: 46.5 us against 49.7).  ss_debug_mel_tile(0) keeps its meaning (8 waves,
-    // direct stores).
-    if (!a.out_stft && !a.fullp && (dbg_mel_build() == 0 || dbg_mel_build() == 3)) {
-        const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
-        const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+#if SS_LAB
+    // lab library: ss_debug_mel_tile(2) asks for the eight-wave builds only -- the retired whole-line tile
+    // (tools/experiments/ss_mel2048_tile.hip) where the shape has one, else eight waves with direct stores
+    if (dbg_mel_build() == 2) {
+        const hipError_t e = launch_mel_c1024_tile(a, stream, num_cus, info);
+        if (e != hipErrorInvalidValue) return e;
+    }
+    static const char *w = std::getenv("SS_MEL_WAVES");  // A/B knobs (lab build)
+    if (w && std::atoi(w) == 12) return launch_mel_w<12>(a, stream, num_cus, info);
+    static const char *sw = std::getenv("SS_STFT_WAVES");
+    if (a.out_stft && sw) return std::atoi(sw) == 12 ? launch_mel_w12(a, stream, num_cus, info) : launch_mel_w<8>(a, stream, num_cus, info);
+#endif
+    if (a.out_stft && !a.fullp) {
+        // stft writes 8200 bytes per row: the launch is a write-dominated stream.  While input + output fit the 256 MiB Infinity
+        // Cache the twelve-wave build is the faster one (cfg3 shape, 768 clips: 51.7 against 60.5 us); beyond it both run at the
+        // part's mixed read / write rate and the eight-wave build, which asks for the next unit's samples ahead of its stores,
+        // is level or slightly ahead (1024 clips: 95.5 against 99.5 us; 4096 clips: 318 against 323).
+        const unsigned long long bytes = static_cast<unsigned long long>(a.batch) * (4ull * a.n_samples + 8200ull * a.rows);
+        if (bytes <= (240ull << 20)) {
+            const hipError_t e = launch_mel_w12(a, stream, num_cus, info);
+            if (e != hipErrorInvalidValue) return e;
+        }
+        return launch_mel_w<8>(a, stream, num_cus, info);
+    }
+    // Eight waves per CU or twelve?  A unit (two rows) takes a wave 1.29 x as long with three waves on its SIMD as with two (cfg3,
+    // one box: 8.0 us against 6.2), and a CU's units go round in ceil(units / waves) rounds: twelve waves win unless the CU's
+    // share of units fits eight waves much better (cfg3: 64 units per CU, 8 rounds of 8 against 5.3 -> 6 of 12: 46.5 us
+    // against 49.7).
+    if (!a.out_stft && !a.fullp && dbg_mel_build() != 1 && dbg_mel_build() != 2) {
         const unsigned long long per_cu = (units + cus - 1) / cus;
         const double r8 = static_cast<double>((per_cu + 7) / 8), r12 = 1.29 * static_cast<double>((per_cu + 11) / 12);
         if (r12 < r8 || dbg_mel_build() == 3) {
@@ -740,10 +691,6 @@ hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cu
             if (e != hipErrorInvalidValue) return e;
         }
     }
-#if SS_LAB
-    static const char *w = std::getenv("SS_MEL_WAVES");  // A/B knob (lab build)
-    if (w && std::atoi(w) == 12) return launch_mel_w<12>(a, stream, num_cus, info);
-#endif
     return launch_mel_w<8>(a, stream, num_cus, info);
 }
 

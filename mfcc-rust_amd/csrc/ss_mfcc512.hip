@@ -430,6 +430,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     const unsigned long long tstart = tprev;
 #endif
     unsigned n_done = 0;
+    // The loop waits for a quad's prefetched samples with its predecessor's output store still in flight (vmcnt(1): the store is
+    // the one younger operation).  The first quad's samples come from the prologue, with no store behind them -- and where the
+    // two paths meet the compiler would have to assume the worse one, vmcnt(0), for every iteration.  One store that the range
+    // check drops gives the prologue path the same shape (as many as the build stores per quad: 1 MFCC, 4 mfe, 17 power rows).
+    {
+        constexpr int kLoopStores = OUTK == 0 ? 1 : (OUTK == 1 ? 4 : 17);
+        const __amdgpu_buffer_rsrc_t none = out_rsrc(a.out, 0u);
+#pragma unroll
+        for (int k = 0; k < kLoopStores; ++k) buf_store(0.f, none, 64 * k);  // (distinct, non-adjacent addresses: identical or adjacent stores would be merged)
+    }
 
     SS_PRIOL(SS_P2_TOP);
     while (quad < q_hi) {
@@ -449,11 +459,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         SS_PH(2);  // the prefetched samples are here
         SS_PRIOL(SS_P2_F1);
         float2 v[16];
+#if SS_LAB
         if (!SS_PROF2 && a.dbg && n_done == 1) {
-            // diagnostic runs: when this wave's first samples have arrived
+            // diagnostic runs (lab builds: a conditional store inside the loop costs the product path its counted waits): when
+            // this wave's first samples have arrived
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(4, __builtin_amdgcn_s_memrealtime());
         }
+#endif
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float2 s = e < NE ? vin[e] : make_float2(0.f, 0.f);  // zero pad, processing.rs:147-156
@@ -540,12 +553,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         float esum = 0.f;
         // power_spectrum output (processing.rs:179-181): the scaled |X| of all 257 bins of the frame, 64 contiguous bytes
         // per register and frame on either side of the spectrum
-        float *pw_row = nullptr;
+        // (counted stores, ss_wave.h: the descriptor covers the quad's valid frames)
         const float hs_pw = hscale32 * (1.0f / kTwo32);
+        __amdgpu_buffer_rsrc_t pw_rsrc = out_rsrc(nullptr, 0u);
         if (PWR) {
-            const unsigned gfp = quad * 4 + f;
-            if (gfp < total) pw_row = a.out + static_cast<unsigned long long>(gfp) * 257ull;
+            const unsigned quad_s = __builtin_amdgcn_readfirstlane(quad);
+            pw_rsrc = out_rsrc(a.out + static_cast<unsigned long long>(quad_s) * 4ull * 257ull, min(4u, total - quad_s * 4) * 257u * 4u);
         }
+        const int pw_off = f * 257 * 4;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float2 zk = u[r];
@@ -562,10 +577,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             const float pa = (POW2 || (SS_ABLATE & 8)) ? na : __builtin_amdgcn_sqrtf(na);  // unscaled; hscale is applied to the sums below
             const float pb = (POW2 || (SS_ABLATE & 8)) ? nb : __builtin_amdgcn_sqrtf(nb);
             if (PWR) {
-                if (pw_row) {
-                    pw_row[j + 16 * r] = hs_pw * pa;
-                    pw_row[256 - j - 16 * r] = hs_pw * pb;
-                }
+                buf_store(hs_pw * pa, pw_rsrc, pw_off + (j + 16 * r) * 4);
+                buf_store(hs_pw * pb, pw_rsrc, pw_off + (256 - j - 16 * r) * 4);
                 continue;
             }
             prow[j + 16 * r] = pa;  // only bins <= 128 can carry mel weight (the bank ends at (F+1)/2, feature.rs:69-70) ...
@@ -577,12 +590,15 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             const float2 z = u[8];
             const float n = 4.f * (z.x * z.x + z.y * z.y);
             const float p128 = POW2 ? n : __builtin_amdgcn_sqrtf(n);
-            if (PWR) {
-                if (pw_row) pw_row[128] = hs_pw * p128;
-            } else {
+            if (!PWR) {
                 prow[128] = p128;
                 esum += p128;
             }
+        }
+        if (PWR) {
+            const float2 z = u[8];  // (every lane computes it; lane 0's is X[128])
+            buf_store(hs_pw * (POW2 ? 4.f * (z.x * z.x + z.y * z.y) : __builtin_amdgcn_sqrtf(4.f * (z.x * z.x + z.y * z.y))), pw_rsrc,
+                      j == 0 ? pw_off + 128 * 4 : kOobOffset);
         }
         if ((FULLP || ALIAS) && j < 3) prow[(FULLP ? 257 : 129) + j] = 0.f;  // pad bins (the slot was overwritten by the exchange)
         if (PWR) {
@@ -617,17 +633,20 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         if (MFE) {
             // mfe (feature.rs:200-233): the mel energies and the frame energy themselves, in filter order
             const float hs = hscale32 * (1.0f / kTwo32);
-            const unsigned gf = quad * 4 + f;
-            if (gf < total) {
-                float *row = a.out + static_cast<unsigned long long>(gf) * a.n_filters;
+            {
+                // counted stores (ss_wave.h): descriptors over the quad's valid frames; slots without a filter are dropped
+                const unsigned quad_s = __builtin_amdgcn_readfirstlane(quad);
+                const unsigned nvalid = min(4u, total - quad_s * 4);
+                const unsigned nfl = a.n_filters;
+                const __amdgpu_buffer_rsrc_t frs = out_rsrc(a.out + static_cast<unsigned long long>(quad_s) * 4ull * nfl, nvalid * nfl * 4u);
+                const __amdgpu_buffer_rsrc_t ers = out_rsrc(a.out_energy + static_cast<unsigned long long>(quad_s) * 4ull, nvalid * 4u);
+                const int rowb = f * static_cast<int>(nfl);
                 const float e0 = m0 * hs, e1 = m1 * hs, e2 = m2 * hs;
-                if (fidx0 >= 0) row[fidx0] = e0 == 0.f ? kEps : e0;
-                if (fidx1 >= 0) row[fidx1] = e1 == 0.f ? kEps : e1;
-                if (fidx2 >= 0) row[fidx2] = e2 == 0.f ? kEps : e2;
-                if (j == 0) {
-                    const float en = energy * (1.0f / kTwo32);  // exact: power-of-two scaling
-                    a.out_energy[gf] = en;
-                }
+                buf_store(e0 == 0.f ? kEps : e0, frs, fidx0 >= 0 ? (rowb + fidx0) * 4 : kOobOffset);
+                buf_store(e1 == 0.f ? kEps : e1, frs, fidx1 >= 0 ? (rowb + fidx1) * 4 : kOobOffset);
+                buf_store(e2 == 0.f ? kEps : e2, frs, fidx2 >= 0 ? (rowb + fidx2) * 4 : kOobOffset);
+                const float en = energy * (1.0f / kTwo32);  // exact: power-of-two scaling
+                buf_store(en, ers, j == 0 ? f * 4 : kOobOffset);
             }
             wave_order();
             quad = next;
@@ -711,7 +730,13 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
                     o = acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
                 }
             }
-            if (j < Cc && gf < total) a.out[static_cast<unsigned long long>(gf) * Cc + j] = o;
+            // unconditional, counted store (ss_wave.h): the descriptor covers the quad's valid frames, lanes j >= n_ceps are
+            // dropped by its range check -- the next quad's samples are waited for with this store still in flight
+            (void)gf;
+            const unsigned quad_s = __builtin_amdgcn_readfirstlane(quad);  // uniform, but born from the wave number: a VGPR to the compiler
+            const unsigned nvalid = min(4u, total - quad_s * 4);
+            const __amdgpu_buffer_rsrc_t orow = out_rsrc(a.out + static_cast<unsigned long long>(quad_s) * 4ull * Cc, nvalid * Cc * 4u);
+            buf_store(o, orow, j < Cc ? (f * Cc + j) * 4 : kOobOffset);
         }
         wave_order();
         SS_PH(9);  // store

@@ -23,6 +23,44 @@ __device__ __forceinline__ void wg_barrier_lds()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Output stores that the compiler can COUNT.  vmcnt retires loads and stores together, in issue order (gfx9 family), and a store
+// is acknowledged only when it has reached L2 -- hundreds of nanoseconds under load.  A store inside `if (lane is valid)` sits
+// behind a branch, so the compiler cannot know whether it was issued and every later wait for the next unit's prefetched samples
+// becomes s_waitcnt vmcnt(0): the wave waits for its own store's acknowledgement in every iteration.  A buffer store through a
+// resource descriptor is issued unconditionally by every lane (straight-line code: the wait for the samples becomes
+// vmcnt(<stores behind them>) and the stores stay in flight); lanes that must not write pass kOobOffset and the range check
+// of the descriptor drops them (offset >= num_records), as it drops rows beyond `bytes`.
+constexpr int kOobOffset = 0x7fffffff;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(const void *base, unsigned bytes)
+{
+    // word 3: DATA_FORMAT = 32 (gfx9 / CDNA raw buffer), stride 0: byte offsets, range-checked against num_records
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+}
+// AUX: cache-policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); 0 = the default write-back policy
+template <int AUX = 0>
+__device__ __forceinline__ void buf_store(float2 v, __amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 d;
+    d.x = __builtin_bit_cast(unsigned, v.x);
+    d.y = __builtin_bit_cast(unsigned, v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, byte_off, 0, AUX);
+}
+__device__ __forceinline__ void buf_store(float4 v, __amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 d;
+    d.x = __builtin_bit_cast(unsigned, v.x);
+    d.y = __builtin_bit_cast(unsigned, v.y);
+    d.z = __builtin_bit_cast(unsigned, v.z);
+    d.w = __builtin_bit_cast(unsigned, v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, 0);
+}
+
 // ds_bpermute_b32: every lane reads `v` of the lane whose number is addr / 4 (LDS crossbar, no memory round trip)
 __device__ __forceinline__ float bperm(int addr, float v)
 {

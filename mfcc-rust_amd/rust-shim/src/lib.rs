@@ -5,7 +5,8 @@
 //!   speechsauce::feature::mfe(ArrayView1<f32>, &SpeechConfig) -> (Array2, Array1)       (feature.rs:200)
 //!   speechsauce::feature::mel_spectrogram1 / mel_spectrogram2                           (feature.rs:151,163)
 //!   speechsauce::processing::preemphasis(Array1<f32>, isize, f32) -> Array1<f32>        (processing.rs:31)
-//!   speechsauce::processing::stack_frames / power_spectrum(frames, fft_points)          (processing.rs:65,179)
+//!   speechsauce::processing::stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding)
+//!   speechsauce::processing::power_spectrum(frames, fft_points)                         (processing.rs:65,179)
 //!   speechsauce::functions::stft1 / stft2 -> Array2 / Array3<Complex32>                 (functions.rs:199,86)
 //!   speechsauce::config::{SpeechConfig, SpeechConfigBuilder}                            (config.rs:10-190)
 //! The host side here owns what the north-star assigns to Rust: ndarray I/O (contiguity, shapes,
@@ -69,6 +70,10 @@ extern "C" {
     fn ss_frame_sizes(p: *const SsParams, frame_len: *mut usize, frame_step: *mut usize) -> c_int;
     fn ss_stft(cfg: *const SsConfig, x: *const f32, channels: usize, n: usize, out: *mut f32) -> c_int;
     fn ss_stack_frames(cfg: *const SsConfig, x: *const f32, n: usize, frames: *mut f32) -> c_int;
+    fn ss_stack_frames_shape(n_samples: usize, sample_rate: u32, frame_length: f32, frame_stride: f32, zero_padding: c_int,
+                             num_frames: *mut usize, frame_len: *mut usize) -> c_int;
+    fn ss_stack_frames_signal(x: *const f32, n_samples: usize, sample_rate: u32, frame_length: f32, frame_stride: f32,
+                              window: *const f32, zero_padding: c_int, frames: *mut f32) -> c_int;
     fn ss_power_spectrum_frames(cfg: *const SsConfig, frames: *const f32, rows: usize, cols: usize, p_out: *mut f32) -> c_int;
     fn ss_power_spectrum(cfg: *const SsConfig, x: *const f32, n: usize, p_out: *mut f32) -> c_int;
     fn ss_config_device_status(cfg: *const SsConfig) -> c_int;
@@ -315,10 +320,37 @@ pub fn stft1(input: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<Complex32> {
     out.into_shape((r, f)).expect("shape")
 }
 
-/// processing.rs:65-129.  `sample_rate`, `frame_length`, `frame_stride`, the `filter` argument (the `mfcc_window` switch) and
-/// `zero_padding` (`framing = 3`) are the config's: `stack_frames(signal, &cfg)` replaces
-/// `stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding)`.
-pub fn try_stack_frames(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+/// processing.rs:65-129 with the reference's own signature:
+/// `stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding) -> Array2<f32>` -- a caller of
+/// `speechsauce::processing::stack_frames` switches the `use` line and nothing else.  `filter` is called with the frame
+/// length and its row 0 multiplies every frame (what `repeat_axis(filt, Axis(0), numframes)` does with the reference's
+/// `(1, frame_len)` array, processing.rs:122-126); the framing is the documented contract (frame t = samples
+/// `t * step .. t * step + frame_len`), see SURVEY.md Q1 for what the reference's copy loop does instead.
+pub fn try_stack_frames(signal: ArrayView1<f32>, sample_rate: usize, frame_length: f32, frame_stride: f32,
+                        filter: Option<fn(usize) -> Array2<f32>>, zero_padding: bool) -> Result<Array2<f32>, Error> {
+    let x = contiguous(signal);
+    let (mut t, mut flen) = (0usize, 0usize);
+    check(unsafe { ss_stack_frames_shape(x.len(), sample_rate as u32, frame_length, frame_stride, zero_padding as c_int, &mut t, &mut flen) })?;
+    let window: Option<Vec<f32>> = filter.map(|f| {
+        let w = f(flen);
+        // row 0 of the (1, frame_len) array; a (frame_len, 1) column (feature.rs:176-178 `_f_it`) is read down its column
+        let v: Vec<f32> = if w.nrows() == 1 { w.row(0).to_vec() } else { w.column(0).to_vec() };
+        assert_eq!(v.len(), flen, "filter(frame_len) must give frame_len values");
+        v
+    });
+    let mut out = Array2::<f32>::zeros((t, flen));
+    let wptr = window.as_ref().map_or(std::ptr::null(), |w| w.as_ptr());
+    check(unsafe { ss_stack_frames_signal(x.as_ptr(), x.len(), sample_rate as u32, frame_length, frame_stride, wptr, zero_padding as c_int, out.as_mut_ptr()) })?;
+    Ok(out)
+}
+pub fn stack_frames(signal: ArrayView1<f32>, sample_rate: usize, frame_length: f32, frame_stride: f32,
+                    filter: Option<fn(usize) -> Array2<f32>>, zero_padding: bool) -> Array2<f32> {
+    try_stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding).expect("stack_frames")
+}
+
+/// The same stage with the framing taken from a config (its `framing` / `mfcc_window` / `pad_mode` switches apply: literal and
+/// centred framing exist only in this form).  An extra beside the reference's signature above.
+pub fn try_stack_frames_with(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
     let x = contiguous(signal);
     let (mut t, mut flen, mut step) = (0usize, 0usize, 0usize);
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
@@ -327,18 +359,53 @@ pub fn try_stack_frames(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<A
     check(unsafe { ss_stack_frames(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
     Ok(out)
 }
-pub fn stack_frames(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_stack_frames(signal, cfg).expect("stack_frames") }
+pub fn stack_frames_with(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_stack_frames_with(signal, cfg).expect("stack_frames") }
 
-/// processing.rs:179-181: `power_spectrum(frames, fft_points)`; `fft_points` must be the config's (the reference takes it
-/// as a loose argument, its callers pass `speech_config.fft_points`, feature.rs:211)
-pub fn try_power_spectrum(frames: Array2<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
+/// processing.rs:179-181 with the reference's own signature: `power_spectrum(frames: Array2<f32>, fft_points: usize)`.
+/// Only `fft_points` matters to this stage; the config it runs on is kept per `fft_points` in a small process-wide cache
+/// (the Python front memoises the same way), so repeated calls cost one lookup.
+pub fn try_power_spectrum(frames: Array2<f32>, fft_points: usize) -> Result<Array2<f32>, Error> {
+    use std::collections::HashMap;
+    use std::sync::{Mutex, OnceLock};
+    struct Handle(*mut SsConfig);
+    unsafe impl Send for Handle {}  // the handle is immutable after creation and thread-safe (speechsauce_amd.h)
+    static CACHE: OnceLock<Mutex<HashMap<usize, Handle>>> = OnceLock::new();
+    let cache = CACHE.get_or_init(|| Mutex::new(HashMap::new()));
+    let handle = {
+        let mut map = cache.lock().expect("power_spectrum config cache");
+        if let Some(h) = map.get(&fft_points) {
+            h.0
+        } else {
+            // a config that validates for this FFT length: a frame of half its length, a bank that fits its spectrum
+            let mut p = SpeechConfigBuilder::new(16000).p;
+            p.fft_points = fft_points as u32;
+            p.frame_length = fft_points as f32 / 32000.0;
+            p.frame_stride = fft_points as f32 / 64000.0;
+            p.num_filters = std::cmp::max(1, std::cmp::min(40, fft_points / 8)) as u32;
+            p.num_cepstral = std::cmp::min(13, p.num_filters);
+            let mut h: *mut SsConfig = std::ptr::null_mut();
+            check(unsafe { ss_config_create(&p, &mut h) })?;
+            map.insert(fft_points, Handle(h));  // kept for the life of the process
+            h
+        }
+    };
+    let x = frames.as_standard_layout();
+    let (rows, cols) = x.dim();
+    let mut out = Array2::<f32>::zeros((rows, fft_points / 2 + 1));
+    check(unsafe { ss_power_spectrum_frames(handle, x.as_ptr(), rows, cols, out.as_mut_ptr()) })?;
+    Ok(out)
+}
+pub fn power_spectrum(frames: Array2<f32>, fft_points: usize) -> Array2<f32> { try_power_spectrum(frames, fft_points).expect("power_spectrum") }
+
+/// The same stage on an existing config (`fft_points` is the config's).  An extra beside the reference's signature above.
+pub fn try_power_spectrum_with(frames: Array2<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
     let x = frames.as_standard_layout();
     let (rows, cols) = x.dim();
     let mut out = Array2::<f32>::zeros((rows, cfg.freq_size));
     check(unsafe { ss_power_spectrum_frames(cfg.handle, x.as_ptr(), rows, cols, out.as_mut_ptr()) })?;
     Ok(out)
 }
-pub fn power_spectrum(frames: Array2<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_power_spectrum(frames, cfg).expect("power_spectrum") }
+pub fn power_spectrum_with(frames: Array2<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_power_spectrum_with(frames, cfg).expect("power_spectrum") }
 
 /// stack_frames + power_spectrum fused, as mfe uses them (feature.rs:203-214): `[frames, freq_size]`
 pub fn try_power_spectrum_of_signal(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {

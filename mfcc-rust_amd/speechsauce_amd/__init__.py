@@ -36,13 +36,14 @@ class SpeechConfig:
     def __init__(self, params: SsParams):
         self.params = params
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().ss_config_create(C.byref(params), C.byref(self._h)))
+        self._owner = _lib.lib()  # the build that created the handle destroys it (tests run the front on the lab build too)
+        _lib.check(self._owner.ss_config_create(C.byref(params), C.byref(self._h)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
-                _lib.lib().ss_config_destroy(h)
+                self._owner.ss_config_destroy(h)
             except Exception:
                 pass
 
@@ -93,6 +94,9 @@ def _get_speech_config(sampling_frequency, frame_length=0.020, frame_stride=0.01
                                   low_frequency, dc_elimination, high_frequency, **dict(switches))
     return _speech_config(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
                           low_frequency, dc_elimination, high_frequency, **dict(switches))
+
+
+_lib._on_switch.append(_get_speech_config.cache_clear)  # a config belongs to the library that created it
 
 
 def _device_key(signal) -> int:
@@ -365,30 +369,70 @@ def stft(signal, sampling_frequency, frame_length=0.020, fft_length=512, **switc
     return z[0] if one_d else z
 
 
-def stack_frames(signal, sampling_frequency, frame_length=0.020, frame_stride=0.020, zero_padding=False, **switches):
-    """``speechsauce::processing::stack_frames`` (processing.rs:65-129): (num_frames, frame_len) frames of a 1-D signal.
-    ``zero_padding=True`` is the reference's flag (ceil instead of floor frames, the tail reading appended zeros);
-    ``mfcc_window=`` plays the role of its ``filter`` argument; ``framing="literal"`` gives the copy exactly as written."""
+def stack_frames(signal, sampling_frequency, frame_length=0.020, frame_stride=0.020, filter=None, zero_padding=False, **switches):
+    """``speechsauce::processing::stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding)``
+    (processing.rs:65-129): (num_frames, frame_len) frames of a 1-D signal, any sampling rate and frame length (the function
+    has no FFT dependency: 44.1 kHz x 25 ms = 1102-sample frames are fine).  ``filter``: as in the reference, a callable that
+    gets frame_len and returns the window as a (1, frame_len) array (row 0 is used; a 1-D array of frame_len works too), or an
+    array; ``zero_padding=True`` is the reference's flag (ceil instead of floor frames, the tail reading appended zeros).
+    ``switches`` (``framing="literal" | "center"``, ``mfcc_window=``, ``pad_mode=``) go through a SpeechConfig instead and then
+    need frame_len <= 8192."""
     sig = _require_f32(signal, (1,), "stack_frames")
-    if zero_padding:
-        switches = dict(switches, framing="padded")
-    config = _cfg(sampling_frequency, frame_length, frame_stride, 13, 40, 512, 0, None, True, switches, sig)
     lib = _lib.lib()
     L = sig.shape[0]
-    T = config.num_frames(L)
-    fl, st = C.c_size_t(), C.c_size_t()
-    _lib.check(lib.ss_frame_sizes(C.byref(config.params), C.byref(fl), C.byref(st)))
+    if switches:
+        if filter is not None:
+            raise ValueError("stack_frames: pass either filter= or the mfcc_window switch")
+        if zero_padding:
+            switches = dict(switches, framing="padded")
+        flen = int(np.floor(np.float32(np.float32(sampling_frequency) * np.float32(frame_length)) + np.float32(0.5)))  # f32::round
+        n_fft = 512
+        while n_fft < flen and n_fft < 8192:  # the config needs an FFT length that holds the frame; nothing else uses it here
+            n_fft *= 2
+        config = _cfg(sampling_frequency, frame_length, frame_stride, 13, 40, n_fft, 0, None, True, switches, sig)
+        T = config.num_frames(L)
+        fl, st = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.ss_frame_sizes(C.byref(config.params), C.byref(fl), C.byref(st)))
+        if _is_torch(sig):
+            import torch
+
+            x = sig.contiguous()
+            out = torch.empty((T, fl.value), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(lib.ss_stack_frames_device(config.handle, x.data_ptr(), 1, L, L, out.data_ptr(), _stream_ptr()))
+            return out
+        x = np.ascontiguousarray(sig)
+        out = np.empty((T, fl.value), dtype=np.float32)
+        _lib.check(lib.ss_stack_frames(config.handle, x.ctypes.data, L, out.ctypes.data))
+        return out
+    T, fl = C.c_size_t(), C.c_size_t()
+    _lib.check(lib.ss_stack_frames_shape(L, int(sampling_frequency), float(frame_length), float(frame_stride), int(bool(zero_padding)),
+                                         C.byref(T), C.byref(fl)))
+    win = None
+    if filter is not None:
+        w = filter(fl.value) if callable(filter) else filter
+        w = w.detach().cpu().numpy() if _is_torch(w) else np.asarray(w)
+        w = np.ascontiguousarray(w.reshape(-1)[: fl.value] if w.ndim == 1 or w.shape[0] != 1 else w[0], dtype=np.float32)
+        if w.shape[0] != fl.value:
+            raise ValueError(f"stack_frames: filter gave {w.shape[0]} values for frames of {fl.value} samples")
+        win = w
     if _is_torch(sig):
         import torch
 
         x = sig.contiguous()
-        out = torch.empty((T, fl.value), dtype=torch.float32, device=x.device)
+        out = torch.empty((T.value, fl.value), dtype=torch.float32, device=x.device)
+        wd = torch.from_numpy(win).to(x.device) if win is not None else None
         with torch.cuda.device(x.device):
-            _lib.check(lib.ss_stack_frames_device(config.handle, x.data_ptr(), 1, L, L, out.data_ptr(), _stream_ptr()))
+            _lib.check(lib.ss_stack_frames_signal_device(x.data_ptr(), L, int(sampling_frequency), float(frame_length), float(frame_stride),
+                                                         wd.data_ptr() if wd is not None else None, int(bool(zero_padding)), out.data_ptr(),
+                                                         _stream_ptr()))
+        if wd is not None:
+            wd.record_stream(torch.cuda.current_stream(x.device))
         return out
     x = np.ascontiguousarray(sig)
-    out = np.empty((T, fl.value), dtype=np.float32)
-    _lib.check(lib.ss_stack_frames(config.handle, x.ctypes.data, L, out.ctypes.data))
+    out = np.empty((T.value, fl.value), dtype=np.float32)
+    _lib.check(lib.ss_stack_frames_signal(x.ctypes.data, L, int(sampling_frequency), float(frame_length), float(frame_stride),
+                                          win.ctypes.data if win is not None else None, int(bool(zero_padding)), out.ctypes.data))
     return out
 
 

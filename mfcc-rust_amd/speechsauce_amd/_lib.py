@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(_HERE)
 # SS_LIB_PATH overrides the in-tree build (A/B runs of two builds in one process tree)
 LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
+# the lab build (same sources, -DSS_LAB=1): the only library that exports the ss_debug_* test aids
+LAB_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd_lab.so")
+ABI_VERSION = 5
 
 SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED, SS_ERR_DEVICE = range(7)
 FRAMING = {"contract": 0, "literal": 1, "center": 2, "padded": 3}
@@ -62,7 +65,7 @@ class SpeechSauceError(RuntimeError):
 
 _lib = None
 
-# name -> (restype, argtypes); every symbol include/speechsauce_amd.h and include/speechsauce_amd_debug.h declare
+# name -> (restype, argtypes); every symbol include/speechsauce_amd.h declares (LAB_PROTOTYPES: include/speechsauce_amd_debug.h)
 _P = C.POINTER
 _cfg = C.c_void_p
 _fp = C.c_void_p  # float* passed as an address (numpy .ctypes.data or a device pointer)
@@ -121,48 +124,109 @@ PROTOTYPES = {
     "ss_last_kernel_name": (C.c_char_p, []),
     "ss_time_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_time_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
+    "ss_mfcc_shader_clock": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
+    "ss_stack_frames_shape": (C.c_int, [C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
+    "ss_stack_frames_signal": (C.c_int, [_fp, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp]),
+    "ss_stack_frames_signal_device": (C.c_int, [_fp, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp, C.c_void_p]),
+    "ss_status_string": (C.c_char_p, [C.c_int]),
+    "ss_last_error_string": (C.c_char_p, []),
+    "ss_abi_version": (C.c_int, []),
+}
+# the process-wide test aids: exported by the lab library only (include/speechsauce_amd_debug.h)
+LAB_PROTOTYPES = {
     "ss_debug_poison_lds": (C.c_int, [C.c_void_p]),
     "ss_debug_stamp_buffer": (C.c_int, [C.c_void_p]),
     "ss_debug_force_generic": (C.c_int, [C.c_int]),
     "ss_debug_mel_tile": (C.c_int, [C.c_int]),
     "ss_debug_tile_fault": (C.c_int, [C.c_int]),
-    "ss_status_string": (C.c_char_p, [C.c_int]),
-    "ss_last_error_string": (C.c_char_p, []),
-    "ss_abi_version": (C.c_int, []),
 }
 
 
-def lib():
-    """Load the shared library once.  torch is imported first when present so that both share one
-    HIP runtime (same SONAME libamdhip64.so.7; the loader reuses the copy torch already mapped)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path: str, lab: bool = False):
+    """dlopen one build of the library and give every entry point its prototype.  The ABI version is checked for EVERY build
+    (an older library would be driven with the current SsParams layout and prototypes: silent struct-layout errors); a symbol
+    the build lacks is an error unless SS_LIB_LENIENT=1 says the caller knows (A/B runs against an older library)."""
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
-            "(or `make -C mfcc-rust_amd/csrc`). speechsauce_amd has no CPU fallback."
+            f"{path} is missing: build it with `python __graft_entry__.py build` "
+            "(or `make -C mfcc-rust_amd/csrc [lab]`). speechsauce_amd has no CPU fallback."
         )
     try:
         import torch  # noqa: F401  (device memory / streams plumbing; also pins the HIP runtime)
     except Exception:  # pragma: no cover - torch is optional for the numpy host path
         pass
-    handle = C.CDLL(LIB_PATH)
-    # an explicit SS_LIB_PATH is an A/B run against another build (tools/ab_bench.sh), possibly an older one: symbols it lacks
-    # are skipped there; the in-tree library must have every one of them
-    lenient = bool(os.environ.get("SS_LIB_PATH"))
-    for name, (res, args) in PROTOTYPES.items():
+    handle = C.CDLL(path)
+    lenient = os.environ.get("SS_LIB_LENIENT") == "1"
+    protos = dict(PROTOTYPES, **LAB_PROTOTYPES) if lab else PROTOTYPES
+    for name, (res, args) in protos.items():
         fn = getattr(handle, name, None)
         if fn is None:
             if lenient:
                 continue
-            raise ImportError(f"{LIB_PATH} does not export {name}")
+            raise ImportError(f"{path} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if handle.ss_abi_version() != 4 and not lenient:
-        raise ImportError("libspeechsauce_amd.so ABI version mismatch")
-    _lib = handle
+    if not lab:  # a lab build handed in through SS_LIB_PATH (tools/): its test aids get their prototypes too
+        for name, (res, args) in LAB_PROTOTYPES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                continue
+            fn.restype = res
+            fn.argtypes = args
+    got = handle.ss_abi_version()
+    if got != ABI_VERSION:
+        msg = f"{path}: ABI version {got}, this front speaks {ABI_VERSION}"
+        if not lenient:
+            raise ImportError(msg + " (SS_LIB_LENIENT=1 to drive it anyway)")
+        import warnings
+
+        warnings.warn(msg)
+    return handle
+
+
+def lib():
+    """The library the front runs on, loaded once: the in-tree product build (or SS_LIB_PATH).  torch is imported first
+    when present so that both share one HIP runtime (same SONAME libamdhip64.so.7; the loader reuses the copy torch mapped)."""
+    global _lib
+    if _lib is None:
+        _lib = load(LIB_PATH)
     return _lib
+
+
+_lab = None
+_on_switch = []  # callbacks of the front (its memoised configs belong to one library)
+
+
+def lab():
+    """The lab build (libspeechsauce_amd_lab.so), loaded once and only on request: the ss_debug_* test aids live there."""
+    global _lab
+    if _lab is None:
+        _lab = load(LAB_LIB_PATH, lab=True)
+    return _lab
+
+
+class use_library:
+    """Context manager for tests: run the Python front on another build (the lab library) inside the block.  Configs are
+    per-library objects, so the front's memoised configs are dropped on the way in and out."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __enter__(self):
+        global _lib
+        self.prev = lib()
+        for cb in _on_switch:
+            cb()
+        _lib = self.handle
+        return self.handle
+
+    def __exit__(self, *exc):
+        global _lib
+        for cb in _on_switch:
+            cb()
+        _lib = self.prev
+        return False
 
 
 def check(status: int) -> None:

@@ -37,6 +37,20 @@ def sslib():
 
 
 @pytest.fixture(scope="session")
+def sslab(sslib):
+    """The LAB build of the library (same sources, -DSS_LAB=1; `make lab`): the only one that exports the process-wide test
+    aids of include/speechsauce_amd_debug.h.  Tests that poison LDS, force a kernel build or inject the tile fault load it
+    explicitly; everything else runs on the product library (`sslib`).  Loaded after the product library, never instead of it."""
+    import subprocess
+
+    from speechsauce_amd import _lib
+
+    if not os.path.exists(_lib.LAB_LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc"), "-j4", "lab"], check=True)
+    return _lib.lab()
+
+
+@pytest.fixture(scope="session")
 def ss():
     """The Python front on a real device (GPU tests only)."""
     import torch

@@ -26,7 +26,7 @@ def _has_gpu():
 DEBUG_HEADER = os.path.join(ROOT, "include", "speechsauce_amd_debug.h")
 
 
-def _declared_symbols(headers=(HEADER, DEBUG_HEADER)):
+def _declared_symbols(headers=(HEADER,)):
     names = set()
     for h in headers:
         text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
@@ -42,12 +42,25 @@ def test_every_declared_symbol_is_exported(sslib):
     for n in names:
         assert hasattr(sslib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in the Python front"
-    assert sslib.ss_abi_version() == 4
+    assert sslib.ss_abi_version() == 5
+
+
+def test_the_lab_library_carries_the_test_aids(sslab):
+    """include/speechsauce_amd_debug.h is the LAB library's header: every symbol it declares is exported there (and, by the
+    test below, by the lab library only)."""
+    from speechsauce_amd import _lib
+
+    names = [n for n in _declared_symbols((DEBUG_HEADER,)) if n.startswith("ss_debug_")]
+    assert len(names) >= 5
+    for n in names:
+        assert hasattr(sslab, n) and n in _lib.LAB_PROTOTYPES, n
+    assert sslab.ss_abi_version() == 5
 
 
 def test_the_product_library_exports_only_the_documented_abi():
-    """`nm -D` of the shipped library: every defined dynamic symbol is an ss_* entry point declared in one of the two
-    headers -- no C++ internals, no lab switches -- and no environment knob name is compiled in."""
+    """`nm -D` of the shipped library: every defined dynamic symbol is an ss_* entry point declared in
+    include/speechsauce_amd.h -- no C++ internals, no lab switches, NO ss_debug_* test aid (those change kernel selection or
+    inject faults process-wide: lab library only) -- and no environment knob name is compiled in."""
     import subprocess
 
     from speechsauce_amd import _lib
@@ -58,8 +71,9 @@ def test_the_product_library_exports_only_the_documented_abi():
     assert exported, "no dynamic symbols?"
     stray = [n for n in exported if n not in declared]
     assert not stray, f"exported but undocumented: {stray}"
+    assert not [n for n in exported if n.startswith("ss_debug")], "a process-wide test aid is exported by the product library"
     blob = open(_lib.LIB_PATH, "rb").read()
-    for knob in (b"SS_FORCE_GENERIC", b"SS_RES", b"SS_WAVES", b"SS_MEL_WAVES", b"SS_MEL_TILE", b"SS_HOST_CHUNK_MB", b"SS_HOST_SMALL_KB",
+    for knob in (b"SS_FORCE_GENERIC", b"SS_RES", b"SS_WAVES", b"SS_MEL_WAVES", b"SS_STFT_WAVES", b"SS_MEL_TILE", b"SS_HOST_CHUNK_MB", b"SS_HOST_SMALL_KB",
                  b"SS_DEBUG_TIMES", b"SS_DEBUG_ROWS"):
         assert knob + b"\0" not in blob, f"the product build still reads {knob.decode()}"
 

@@ -116,3 +116,25 @@ def test_struct_size_is_announced_by_the_library(sslib):
     p = SsParams()
     assert sslib.ss_params_default(C.byref(p), 16000) == 0
     assert p.struct_size == C.sizeof(SsParams) == 4 * len(header_struct())
+
+
+def test_mirrors_carry_the_reference_signatures_of_the_two_stage_functions():
+    """processing.rs:65-76 / :179: stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding) and
+    power_spectrum(frames, fft_points) -- the Rust shim and the C++ mirror offer exactly these argument lists (the config forms
+    are extras beside them), so a caller of the crate switches the `use` line and nothing else."""
+    import re
+
+    rs = open(os.path.join(ROOT, "mfcc-rust_amd", "rust-shim", "src", "lib.rs")).read()
+    flat = re.sub(r"\s+", " ", rs)
+    assert ("pub fn stack_frames(signal: ArrayView1<f32>, sample_rate: usize, frame_length: f32, frame_stride: f32, "
+            "filter: Option<fn(usize) -> Array2<f32>>, zero_padding: bool) -> Array2<f32>") in flat
+    assert "pub fn power_spectrum(frames: Array2<f32>, fft_points: usize) -> Array2<f32>" in flat
+    ref = re.sub(r"/\*.*?\*/", "", open("/root/reference/speechsauce/src/processing.rs").read(), flags=re.S) if os.path.exists("/root/reference") else None
+    if ref is not None:  # (this container only: the GPU box has no reference checkout)
+        rflat = re.sub(r"\s+", " ", ref)
+        assert "pub fn stack_frames( signal: ArrayView1<f32>, sample_rate: usize, frame_length: f32, frame_stride: f32, filter: Option<fn(usize) -> Array2<f32>>, zero_padding: bool, ) -> Array2<f32>" in rflat
+        assert "pub fn power_spectrum(frames: Array2<f32>, fft_points: usize ) -> Array2<f32>" in rflat
+    hpp = re.sub(r"\s+", " ", open(os.path.join(ROOT, "include", "speechsauce_amd.hpp")).read())
+    assert ("inline Array2 stack_frames(const float *signal, std::size_t n, std::size_t sample_rate, float frame_length, float frame_stride, "
+            "FrameFilter filter, bool zero_padding)") in hpp
+    assert "inline Array2 power_spectrum(const Array2 &frames, std::size_t fft_points)" in hpp

@@ -109,12 +109,24 @@ def test_mfe_batch_fast_path(ss, oracle, sslib):
     assert torch.all(feat == 1.1920929e-7) and torch.all(en == 1.1920929e-7)
 
 
+# kernel builds that `bench.py --workload cfgN` launches (the names ss_last_kernel_name() reports; the rocprofv3 traces under
+# profiles/ carry the same builds under their template spelling, profiles/pmc_traffic.json "kernel_full")
+BENCH_KERNELS = {
+    "cfg2": b"ss_mfcc_c256<10,exact,bank421,sym>",
+    "cfg3": b"ss_mel_c1024<w12,mel6321>",
+    "cfg5": b"ss_mfcc_c2048<exact,mel8321,w12>",
+}
+
+
 def test_cfg2_batch_1024(ss, oracle):
     import torch
 
     x = _signal(1, (1024, 16000))
     got = ss.mfcc_batch(torch.from_numpy(x).cuda(), 16000).cpu().numpy()
     assert got.shape == (1024, 98, 13)
+    # the build bench.py times and profiles/ traces for this workload: a dispatch change must not move the bench onto a
+    # build this comparison does not see
+    assert ss._lib.lib().ss_last_kernel_name() == BENCH_KERNELS["cfg2"], ss._lib.lib().ss_last_kernel_name()
     p = oracle.make_params(**CFG1)
     worst = 0.0
     for b in list(range(0, 1024, 37)) + [1023]:
@@ -224,7 +236,7 @@ def test_host_calls_small_and_chunked_give_the_device_bits(ss):
     np.testing.assert_array_equal(short, ss.mfcc_batch(xd[3:4, :8000].contiguous(), 16000).cpu().numpy()[0])
 
 
-def test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslib):
+def _on_lab_test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslib):
     """fft_points = 2048, three builds of one kernel family: eight waves per CU with the CU-wide whole-line tile (a clip's [mel][row]
     block collected in LDS, ss_mel_c1024<tile>; needs at least one clip per CU), eight waves with direct stores, and twelve waves
     (three per SIMD) with direct stores.  Shapes that give a CU one clip, an uneven number of clips, few row pairs per clip (most
@@ -273,6 +285,13 @@ def test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslib):
         sslib.ss_debug_mel_tile(1)
 
 
+def test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslab):
+    """Runs on the LAB library (the build selection / fault aids it needs are not in the product library): the front is
+    switched to it for the duration."""
+    with ss._lib.use_library(sslab):
+        _on_lab_test_mel_spectrogram_2048_whole_line_tile(ss, oracle, sslab)
+
+
 def test_mel_spectrogram_4096_kernel(ss, oracle, sslib):
     """mel_spectrogram at fft_points = 4096 (44.1 kHz, 1024- and 2048-sample chunks, 256 / 128 / 100 mels): one row per wave on
     the 4096-point FFT mapping; partial last chunks, clips shorter than a window."""
@@ -319,7 +338,7 @@ def test_stft_stage(ss, oracle, sslib):
     g = got[..., 0] + 1j * got[..., 1]
     assert np.abs(g - want).max() <= 1e-5 * np.abs(want).max()
     assert np.all(g[:, Rreal:] == 0)
-    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<stft>"
+    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<w12,stft>"  # input + output inside the Infinity Cache: the twelve-wave build
     # an odd number of rows (the last row pair is half empty) and a batch whose units span clip boundaries
     x = _signal(71, (37, 16100))
     R, Rreal = cfg.stft_rows(16100)
@@ -333,6 +352,27 @@ def test_stft_stage(ss, oracle, sslib):
         want = oracle.stft(oracle.make_params(**CFG3), x[b:b + 1])[0]
         assert np.abs(g[b] - want).max() <= 1e-5 * np.abs(want).max()
     assert np.all(g[:, Rreal:] == 0)
+    # the 1024-clip batch tools/stage_rate.py times (268.7 MB of output: beyond the Infinity Cache, the eight-wave build that asks
+    # for the next unit's samples ahead of its stores): that build, by name, against the oracle on sampled clips -- and the
+    # same clips through the twelve-wave build (a small batch) agree to f32 rounding of the transform
+    xb = _signal(72, (1024, 16000))
+    xbd = torch.from_numpy(xb).cuda()
+    outb = torch.empty((1024, 32, 1025, 2), dtype=torch.float32, device="cuda")
+    _lib.check(sslib.ss_stft_device(cfg.handle, xbd.data_ptr(), 1024, 16000, 16000, outb.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<stft>"
+    pick = [0, 300, 1023]
+    sub = torch.empty((3, 32, 1025, 2), dtype=torch.float32, device="cuda")
+    _lib.check(sslib.ss_stft_device(cfg.handle, xbd[pick].contiguous().data_ptr(), 3, 16000, 16000, sub.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<w12,stft>"
+    want = oracle.stft(oracle.make_params(**CFG3), xb[pick])
+    for i, b in enumerate(pick):
+        gb = outb[b].cpu().numpy()
+        gb = gb[..., 0] + 1j * gb[..., 1]
+        assert np.abs(gb - want[i]).max() <= 1e-5 * np.abs(want[i]).max(), b
+        assert np.all(gb[29:] == 0)
+        assert (sub[i] - outb[b]).abs().max().item() <= 1e-6 * outb[b].abs().max().item()
 
 
 @pytest.mark.parametrize("nfft,sr,hop,kernel", [(512, 16000, 256, b"ss_mel_c256<stft>"), (512, 16000, 160, b"ss_mel_c256<stft>"),
@@ -794,13 +834,21 @@ def test_cfg2_full_batch_properties(ss, sslib):
     assert ((lhs.double() - rhs).abs() / rhs).max().item() < 1e-5
 
 
-def test_cfg3_full_batch_properties(ss):
+def test_cfg3_full_batch_properties(ss, oracle):
     import torch
 
-    x = torch.from_numpy(_signal(22, (1024, 16000))).cuda()
+    xh = _signal(22, (1024, 16000))
+    x = torch.from_numpy(xh).cuda()
     kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
     a = ss.mel_spectrogram(x, 16000, **kw)
     assert a.shape == (1024, 128, 32)
+    # the 1024-clip batch is what bench.py --workload cfg3 times: that build, by name, against the oracle on sampled clips
+    # (feature.rs:163-174, functions.rs:86-170) -- the 16-clip test above lands on the eight-wave build
+    assert ss._lib.lib().ss_last_kernel_name() == BENCH_KERNELS["cfg3"], ss._lib.lib().ss_last_kernel_name()
+    pick = [0, 300, 511, 1023]
+    want = oracle.mel_spectrogram(oracle.make_params(**CFG3), xh[pick])
+    for i, b in enumerate(pick):
+        assert _rel(a[b].cpu().numpy(), want[i]) <= RTOL, b
     assert torch.equal(a, ss.mel_spectrogram(x, 16000, **kw))
     # one clip alone takes another build of the kernel (eight waves per CU) than the full batch (twelve): same arithmetic, but
     # the compiler's FMA fusion differs in the last bit -- f32 rounding of the transform, far inside the parity tolerance
@@ -820,6 +868,7 @@ def test_cfg5_full_batch(ss, oracle):
     kw = dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096)
     a = ss.mfcc_batch(torch.from_numpy(x).cuda(), 44100, **kw)
     assert a.shape == (512, 39, 40) and torch.isfinite(a).all()
+    assert ss._lib.lib().ss_last_kernel_name() == BENCH_KERNELS["cfg5"], ss._lib.lib().ss_last_kernel_name()
     assert torch.equal(a, ss.mfcc_batch(torch.from_numpy(x).cuda(), 44100, **kw))
     p = oracle.make_params(**CFG5)
     for b in (0, 255, 511):
@@ -1182,7 +1231,7 @@ def test_mfcc_256_kernel(ss, oracle, sslib):
     assert _rel(ss.mfcc(x1[1:], sr, fft_length=256), oracle.mfcc(p, x1[1:])) <= RTOL
 
 
-def test_kernel_variants_agree(ss, sslib):
+def _on_lab_test_kernel_variants_agree(ss, sslib):
     """The generic kernel and the production kernel compute the same MFCCs (ss_debug_force_generic, the test aid of
     include/speechsauce_amd_debug.h, routes every configuration to ss_front_generic)."""
     import torch
@@ -1198,3 +1247,12 @@ def test_kernel_variants_agree(ss, sslib):
         sslib.ss_debug_force_generic(0)
     assert names[0].startswith("ss_mfcc_c256<") and names[1].startswith("ss_front_generic")
     assert _rel(outs[1], outs[0]) <= 2e-5
+
+
+def test_kernel_variants_agree(ss, sslab):
+    """Runs on the LAB library (the build selection / fault aids it needs are not in the product library): the front is
+    switched to it for the duration."""
+    with ss._lib.use_library(sslab):
+        _on_lab_test_kernel_variants_agree(ss, sslab)
+
+

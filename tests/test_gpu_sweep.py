@@ -125,16 +125,17 @@ def test_random_mel_spectrogram_configurations(ss, oracle, sslib):
     assert ran >= 20
 
 
-def test_uninitialised_lds_never_reaches_results(ss, oracle, sslib):
+def test_uninitialised_lds_never_reaches_results(ss, oracle, sslab):
     """LDS keeps what the previous kernel left in it.  Every sweep configuration (and a list of named ones: windowed and
-    librosa builds, mel / stft kernels, chirp-z) runs once normally and once right after ss_debug_poison_lds has filled every
+    librosa builds, mel / stft kernels, chirp-z) runs once normally and once right after ss_debug_poison_lds (a kernel of the LAB
+    library; the launches under test are the product library's) has filled every
     CU's LDS with 0xFFFFFFFF (NaN as f32, -1 as i32): the results must be finite and bit-identical -- a kernel that multiplies
     a padded zero with a table word it never wrote, or reads a pad bin it never cleared, fails here."""
     import torch
 
     def both(fn):
         a = fn()
-        assert sslib.ss_debug_poison_lds(None) == 0
+        assert sslab.ss_debug_poison_lds(None) == 0
         b = fn()
         torch.cuda.synchronize()
         return a, b
@@ -183,7 +184,7 @@ def test_uninitialised_lds_never_reaches_results(ss, oracle, sslib):
         same(*both(lambda: ss.mel_spectrogram(x, sr, frame_length=hop / sr, frame_stride=hop / sr, num_filters=M, fft_length=nfft)), ("mel", nfft))
 
 
-def test_post_processing_on_poisoned_lds(ss, sslib):
+def test_post_processing_on_poisoned_lds(ss, sslab):
     """cmvn / cmvnw / derivative kernels (processing.rs:222-380) give bit-identical results after ss_debug_poison_lds."""
     import torch
 
@@ -191,6 +192,6 @@ def test_post_processing_on_poisoned_lds(ss, sslib):
     for fn in (lambda: ss.cmvn(feats, False), lambda: ss.cmvn(feats, True), lambda: ss.cmvnw(feats, 301, False),
                lambda: ss.cmvnw(feats, 51, True), lambda: ss.derivative_extraction(feats, 2), lambda: ss.extract_derivative_feature(feats)):
         a = fn().cpu().numpy()
-        assert sslib.ss_debug_poison_lds(None) == 0
+        assert sslab.ss_debug_poison_lds(None) == 0
         b = fn().cpu().numpy()
         assert np.all(np.isfinite(b)) and np.array_equal(a, b)

@@ -128,33 +128,60 @@ def test_mel_spectrogram_in_db(ss, oracle):
 
 
 @pytest.mark.gpu
-def test_stamp_buffer_reports_a_plausible_clock_and_leaves_results_alone(ss, sslib):
-    """ss_debug_stamp_buffer: while set, launches of the 512-point MFCC kernel write per-wave stamps (what bench.py turns into
-    roofline.clock_ghz_measured); the features must not change, and the stamps must describe a sane launch."""
+def test_shader_clock_diagnostic_is_per_call_and_leaves_results_alone(ss, sslib):
+    """ss_mfcc_shader_clock (the product library's own diagnostic, what bench.py turns into roofline.clock_ghz_measured): a
+    plausible clock for the 512-point kernel, SS_ERR_UNSUPPORTED for a configuration on another kernel, and no trace left
+    behind -- launches before and after give the same bits."""
+    import ctypes as C
+
     import torch
+
+    from speechsauce_amd import SpeechConfig, make_params
 
     x = torch.randn((1024, 16000), device="cuda") * 0.1
     want = ss.mfcc_batch(x, 16000)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    stamps = torch.zeros((ncu * 16, 6), dtype=torch.int64, device="cuda")
-    assert sslib.ss_debug_stamp_buffer(stamps.data_ptr()) == 0
-    try:
-        got = ss.mfcc_batch(x, 16000)
+    cfg = SpeechConfig(make_params(sample_rate=16000))
+    out = torch.empty_like(want)
+    ghz = C.c_float(0.0)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert sslib.ss_mfcc_shader_clock(cfg.handle, x.data_ptr(), 1024, 16000, 16000, out.data_ptr(), stream, 5, C.byref(ghz)) == 0
+    assert 1.0 < ghz.value < 3.0, ghz.value
+    assert torch.equal(out, want)                                   # the stamped launches compute the same features
+    assert torch.equal(ss.mfcc_batch(x, 16000), want)               # ... and nothing stays switched on
+    cfg5 = SpeechConfig(make_params(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100,
+                                    num_cepstral=40, num_filters=256))
+    x5 = torch.randn((4, 44100), device="cuda") * 0.1
+    o5 = torch.empty((4, 39, 40), device="cuda")
+    assert sslib.ss_mfcc_shader_clock(cfg5.handle, x5.data_ptr(), 4, 44100, 44100, o5.data_ptr(), stream, 2, C.byref(ghz)) == 5  # SS_ERR_UNSUPPORTED
+    assert sslib.ss_mfcc_shader_clock(cfg.handle, x.data_ptr(), 1024, 16000, 16000, out.data_ptr(), stream, 0, C.byref(ghz)) == 3  # SS_ERR_ARG
+
+
+@pytest.mark.gpu
+def test_lab_stamp_buffer_describes_a_sane_launch(ss, sslab):
+    """ss_debug_stamp_buffer (LAB library; tools/prof2.py, tools/dbg_times.py): while set, launches of the 512-point MFCC kernel
+    write per-wave stamps; the features must not change, and the stamps must describe a sane launch."""
+    import torch
+
+    with ss._lib.use_library(sslab):
+        x = torch.randn((1024, 16000), device="cuda") * 0.1
+        want = ss.mfcc_batch(x, 16000)
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        stamps = torch.zeros((ncu * 16, 6), dtype=torch.int64, device="cuda")
+        assert sslab.ss_debug_stamp_buffer(stamps.data_ptr()) == 0
+        try:
+            got = ss.mfcc_batch(x, 16000)
+            torch.cuda.synchronize()
+        finally:
+            assert sslab.ss_debug_stamp_buffer(None) == 0
+        assert torch.equal(got, want)
+        w = stamps.cpu().numpy()
+        ran = w[:, 2] != 0
+        assert ran.sum() == ncu * 12                                  # twelve waves per workgroup, one workgroup per CU
+        assert int((w[ran, 3] >> 32).sum()) == 1024 * 98 // 4          # every quad was claimed exactly once
+        stamps.zero_()
+        ss.mfcc_batch(x, 16000)                                         # switched off again: nothing is written
         torch.cuda.synchronize()
-    finally:
-        assert sslib.ss_debug_stamp_buffer(None) == 0
-    assert torch.equal(got, want)
-    w = stamps.cpu().numpy()
-    ran = w[:, 2] != 0
-    assert ran.sum() == ncu * 12                                  # twelve waves per workgroup, one workgroup per CU
-    assert int((w[ran, 3] >> 32).sum()) == 1024 * 98 // 4          # every quad was claimed exactly once
-    cyc = ran & ((w[:, 5] >> 40) == 1)
-    ghz = ((w[cyc, 5] - (1 << 40)) / ((w[cyc, 2] - w[cyc, 0]) / 100.0)).mean() / 1000.0
-    assert 1.0 < ghz < 3.0, ghz
-    stamps.zero_()
-    ss.mfcc_batch(x, 16000)                                         # switched off again: nothing is written
-    torch.cuda.synchronize()
-    assert int(stamps.abs().sum().item()) == 0
+        assert int(stamps.abs().sum().item()) == 0
 
 
 @pytest.mark.gpu

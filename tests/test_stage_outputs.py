@@ -132,6 +132,22 @@ def test_stack_frames(ss, oracle):
     np.testing.assert_array_equal(fr[100], big[32000:32320])
     with pytest.raises(ss.SpeechSauceError):
         ss.stack_frames(x[:100], 16000)
+    # stack_frames has no FFT dependency (processing.rs:65-129): frames longer than any FFT length of the MFCC path are fine
+    # (round 3 built its config with fft_length = 512 and rejected these)
+    for sr, fl, st in ((44100, 0.025, 0.010), (48000, 0.025, 0.010), (48000, 0.2, 0.1)):
+        sig = _signal(23, sr)
+        flen, step = int(np.floor(np.float32(sr) * np.float32(fl) + np.float32(0.5))), int(np.floor(np.float32(sr) * np.float32(st) + np.float32(0.5)))
+        T = int(np.floor(np.float32(sr - flen) / np.float32(step)))
+        host = ss.stack_frames(sig, sr, frame_length=fl, frame_stride=st)
+        assert host.shape == (T, flen), (sr, fl, host.shape)
+        idx = np.arange(T)[:, None] * step + np.arange(flen)[None, :]
+        np.testing.assert_array_equal(host, sig[idx])
+        np.testing.assert_array_equal(ss.stack_frames(torch.from_numpy(sig).cuda(), sr, frame_length=fl, frame_stride=st).cpu().numpy(), host)
+    # `filter`, as in the reference: a callable frame_len -> (1, frame_len) window (processing.rs:122-126)
+    ham = lambda n: np.hamming(n).astype(np.float32)[None, :]
+    np.testing.assert_array_equal(ss.stack_frames(x, 16000, 0.02, 0.01, ham), ss.stack_frames(x, 16000, 0.02, 0.01) * ham(320))
+    # the switch path of long frames picks an FFT length that holds the frame
+    assert ss.stack_frames(_signal(24, 44100), 44100, 0.025, 0.010, framing="center").shape[1] == 1103
 
 
 @pytest.mark.gpu
@@ -160,8 +176,7 @@ def test_stft_host_and_device(ss, oracle, sslib, sr, n_fft, hop, n):
     np.testing.assert_array_equal(one, host[1])
 
 
-@pytest.mark.gpu
-def test_a_lost_tile_hand_off_becomes_a_status(ss, sslib):
+def _on_lab_test_a_lost_tile_hand_off_becomes_a_status(ss, sslib):
     """ss_mel_c1024<tile>: with wave 0's row pairs withheld (ss_debug_tile_fault) the waiting waves run into their bound,
     set the config's device error word and stop.  The launch ends, the host-pointer call returns SS_ERR_DEVICE, the
     device-pointer path reports it at ss_config_device_status and refuses further launches until it has been read; after
@@ -213,7 +228,14 @@ def test_a_lost_tile_hand_off_becomes_a_status(ss, sslib):
 
 
 @pytest.mark.gpu
-def test_mel_build_switch_is_bit_identical(ss, sslib):
+def test_a_lost_tile_hand_off_becomes_a_status(ss, sslab):
+    """Runs on the LAB library (the build selection / fault aids it needs are not in the product library): the front is
+    switched to it for the duration."""
+    with ss._lib.use_library(sslab):
+        _on_lab_test_a_lost_tile_hand_off_becomes_a_status(ss, sslab)
+
+
+def _on_lab_test_mel_build_switch_is_bit_identical(ss, sslib):
     """ss_debug_mel_tile selects the build of the 2048-point mel kernel on one batch: the whole-line tile, eight waves with
     direct stores give the same bits, twelve waves the same values to f32 rounding."""
     import torch
@@ -233,6 +255,14 @@ def test_mel_build_switch_is_bit_identical(ss, sslib):
     assert torch.equal(outs[2], outs[0])
     scale = outs[2].abs().amax(dim=(1, 2), keepdim=True)  # the twelve-wave kernel: same arithmetic, FMA fusion may differ in the last bit
     assert ((outs[3] - outs[2]).abs() <= 1e-6 * scale).all()
+
+
+@pytest.mark.gpu
+def test_mel_build_switch_is_bit_identical(ss, sslab):
+    """Runs on the LAB library (the build selection / fault aids it needs are not in the product library): the front is
+    switched to it for the duration."""
+    with ss._lib.use_library(sslab):
+        _on_lab_test_mel_build_switch_is_bit_identical(ss, sslab)
 
 
 @pytest.mark.gpu
@@ -257,8 +287,21 @@ def test_cpp_mirror_stage_outputs(tmp_path, oracle):
         "  std::vector<float> x(2 * 16000); FILE *f = std::fopen(argv[1], \"rb\");\n"
         "  if (!f || std::fread(x.data(), 4, x.size(), f) != x.size()) return 2; std::fclose(f);\n"
         "  speechsauce::SpeechConfig cfg = speechsauce::SpeechConfigBuilder(16000).build();\n"
-        "  auto fr = speechsauce::stack_frames(x.data(), 16000, cfg);\n"
-        "  auto ps = speechsauce::power_spectrum(fr, cfg);\n"
+        # the reference's own argument lists (processing.rs:65-76, :179): no config in sight
+        "  auto fr = speechsauce::stack_frames(x.data(), 16000, 16000, 0.02f, 0.01f, nullptr, false);\n"
+        "  auto ps = speechsauce::power_spectrum(fr, 512);\n"
+        # ... the config forms give the same bits, a window comes through `filter`, zero_padding adds the tail frames
+        "  auto fr_c = speechsauce::stack_frames(x.data(), 16000, cfg);\n"
+        "  auto ps_c = speechsauce::power_spectrum(fr, cfg);\n"
+        "  if (fr_c.data != fr.data || ps_c.data != ps.data) return 5;\n"
+        "  auto half = [](std::size_t n) { speechsauce::Array2 w{1, n, std::vector<float>(n, 0.5f)}; return w; };\n"
+        "  auto fr_w = speechsauce::stack_frames(x, 16000, 0.02f, 0.01f, +half, false);\n"
+        "  for (std::size_t i = 0; i < fr.data.size(); ++i) if (fr_w.data[i] != 0.5f * fr.data[i]) return 6;\n"
+        "  std::vector<float> x1(x.begin(), x.begin() + 16000);\n"
+        "  auto fr_p = speechsauce::stack_frames(x1, 16000, 0.02f, 0.02f, nullptr, true);\n"
+        "  if (fr_p.rows != 49 || fr_p.cols != 320) return 7;\n"
+        "  auto fr_44 = speechsauce::stack_frames(x1, 44100, 0.025f, 0.010f, nullptr, false);  // 1103-sample frames: no FFT length involved\n"
+        "  if (fr_44.cols != 1103 || fr_44.rows != 33 || fr_44(3, 5) != x1[3 * 441 + 5]) return 8;\n"
         "  speechsauce::SpeechConfig sc = speechsauce::SpeechConfigBuilder(16000).fft_points(2048).frame_length(0.032f).frame_stride(0.032f).num_filters(128).build();\n"
         "  auto s2 = speechsauce::stft2(x.data(), 2, 16000, sc);\n"
         "  auto s1 = speechsauce::stft1(x.data() + 16000, 16000, sc);\n"
