@@ -351,9 +351,14 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 // phases of the exchange fill it (left half-defined, the "undefined" halves are carried around the loop and spilled).
 // Twelve exchange regions + the tables are 134 KB of LDS, so the CU-wide whole-line tile of the 8-wave build (55 KB) does not
 // fit beside them: the rows leave as 8-byte pieces of lines (HBM writes 1.4x the output, traffic 1.09x the algorithmic bytes).
-template <bool FIXMEL, bool STFT = false>
+// ROWS4 (mel output, an even number of row pairs per clip): the work item is FOUR consecutive rows of a clip -- two units run back
+// to back by the same wave, the first one's four mel values kept in registers -- and the rows leave as 16-byte pieces
+// out[clip][m][4c .. 4c + 3] (two v_permlane32_swap per filter pair hand each half-wave both halves' values): half the pieces
+// per 128-byte line, a quarter of the store instructions, one claim per four rows.
+template <bool FIXMEL, bool STFT = false, bool ROWS4 = false>
 __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a)
 {
+    static_assert(!(STFT && ROWS4), "the four-row item is a mel-output build");
     constexpr int kWavesM = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
     const unsigned pairs = (a.rows + 1) / 2;
-    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    // work items: units (row pairs), or pairs of units (ROWS4)
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs / (ROWS4 ? 2 : 1);
     const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
     const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
     {
@@ -374,9 +380,16 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
     const int M = static_cast<int>(a.n_filters);
 
-    unsigned unit = u_lo + wave;
+    unsigned item = u_lo + wave;
     SS_PRIOL(SS_P_TOP);
-    while (unit < u_hi) {
+    while (item < u_hi) {
+      // the claim of the next item is issued here and read at the end of the iteration
+      unsigned next_v = 0;
+      if ((static_cast<int>(threadIdx.x) & 63) == 0) next_v = atomicAdd(s_next, 1u);
+      float mva[4] = {0.f, 0.f, 0.f, 0.f};  // ROWS4: the first unit's mel values
+#pragma unroll 1
+      for (int sub = 0; sub < (ROWS4 ? 2 : 1); ++sub) {
+        const unsigned unit = ROWS4 ? 2 * item + sub : item;
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
         const int lane = lane_it;
@@ -387,10 +400,6 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         const float4 *s_tw2 = reinterpret_cast<const float4 *>(s_tab + L::kTw2 + j * L::kTw2Pitch);
         const float4 *s_twn4 = reinterpret_cast<const float4 *>(s_tab + L::kTwn + j * L::kTwnPitch);
         const float4 *s_win4 = reinterpret_cast<const float4 *>(s_tab + L::kWin + j * L::kWinPitch);
-        // the claim of the next unit is issued here and read at the end of the iteration
-        unsigned next_v = 0;
-        if (lane == 0) next_v = atomicAdd(s_next, 1u);
-
         const unsigned clip = unit / pairs;
         const int r = static_cast<int>(unit - clip * pairs) * 2 + half;
         const bool in_rows = r < R;
@@ -561,8 +570,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             buf_store(make_float2(a.scale * u[16].x, -a.scale * u[16].y), srs, j == 0 ? srow_off + 512 * 8 : kOobOffset);  // X[512] = conj Z[512]
             wave_order();
             SS_PRIOL(SS_P_TOP);
-            unit = __builtin_amdgcn_readfirstlane(next_v);
-            continue;
+            continue;  // (the one pass of the sub loop ends here)
         }
         if (j == 0) {
             const float2 z = u[16];  // X[512] = conj Z[512]
@@ -587,7 +595,28 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                     off += a.mel_q4[s];
                 }
             }
-            if (in_rows) {
+            if (ROWS4) {
+                if (sub == 0) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) mva[s] = mv[s];
+                } else {
+                    // rows 4c + half (first unit, mva) and 4c + 2 + half (this one, mv).  After the swaps the lower half-wave
+                    // holds rows 4c .. 4c + 3 of its filters fi[0], fi[1], the upper one those of its filters fi[2], fi[3]
+                    // (fi depends on j only): one 16-byte piece per lane and filter, dropped by the range check where a slot has
+                    // no filter (counted stores, ss_wave.h)
+                    float a0 = mva[0], b0 = mva[2], a1 = mva[1], b1 = mva[3], c0 = mv[0], d0 = mv[2], c1 = mv[1], d1 = mv[3];
+                    swap_halves(a0, b0);
+                    swap_halves(a1, b1);
+                    swap_halves(c0, d0);
+                    swap_halves(c1, d1);
+                    const unsigned clip_s = __builtin_amdgcn_readfirstlane(clip);
+                    const __amdgpu_buffer_rsrc_t ors = out_rsrc(a.out + static_cast<unsigned long long>(clip_s) * M * R, static_cast<unsigned>(M * R) * 4u);
+                    const int r4 = (r - half - 2) * 4;  // byte offset of row 4c within a filter's line
+                    const int f0 = half ? fi[2] : fi[0], f1 = half ? fi[3] : fi[1];
+                    buf_store(make_float4(a0, b0, c0, d0), ors, f0 >= 0 ? f0 * R * 4 + r4 : kOobOffset);
+                    buf_store(make_float4(a1, b1, c1, d1), ors, f1 >= 0 ? f1 * R * 4 + r4 : kOobOffset);
+                }
+            } else if (in_rows) {
                 float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -596,7 +625,8 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         }
         wave_order();
         SS_PRIOL(SS_P_TOP);
-        unit = __builtin_amdgcn_readfirstlane(next_v);
+      }
+      item = __builtin_amdgcn_readfirstlane(next_v);
     }
 }
 
@@ -646,6 +676,26 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
     };
     if (a.out_stft) return go(ss_mel_c1024_w12<false, true>, "ss_mel_c1024<w12,stft>");
     const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+#if SS_LAB
+    // Four consecutive rows per work item (16-byte output pieces; ROWS4 above): measured and not kept -- cfg3 49.3 against 46.8 us
+    // on one box (profiles/r04/ab_cfg3_rows4.txt).  A CU's 64 two-row units spread over twelve waves of different speeds better
+    // than 32 four-row items do; what the wider pieces save in L2 is far less than what the coarser items cost at the end of the
+    // launch.  SS_MEL_ROWS4=1 (lab build) selects it.
+    static const char *r4 = std::getenv("SS_MEL_ROWS4");
+    if (r4 && std::atoi(r4) == 1 && a.rows % 4 == 0 && static_cast<unsigned long long>(a.n_filters) * a.rows * 4ull < 0x7fffffffull) {
+        // (the grid is sized on four-row items)
+        const unsigned long long items = units / 2, blocks4 = (items + kWavesM - 1) / kWavesM;
+        const unsigned grid4 = static_cast<unsigned>(blocks4 < cap ? blocks4 : cap);
+        auto go4 = [&](auto kern, const char *name) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+            if (info) *info = LaunchInfo{name, grid4, static_cast<unsigned>(kWavesM * 64), lds};
+            hipLaunchKernelGGL(kern, dim3(grid4), dim3(kWavesM * 64), lds, stream, a);
+            return hipGetLastError();
+        };
+        return m6321 ? go4(ss_mel_c1024_w12<true, false, true>, "ss_mel_c1024<w12,mel6321,rows4>") : go4(ss_mel_c1024_w12<false, false, true>, "ss_mel_c1024<w12,rows4>");
+    }
+#endif
     return m6321 ? go(ss_mel_c1024_w12<true>, "ss_mel_c1024<w12,mel6321>") : go(ss_mel_c1024_w12<false>, "ss_mel_c1024<w12>");
 }
 

@@ -93,15 +93,6 @@ constexpr int kFRowOff = L::kPRow;        // ln(mel) row [256] behind the P row 
 constexpr int kSRowOff = kFRowOff + 256;  // s and d rows of the symmetric DCT (4 segments of 64 + 4 floats), behind the ln(mel) row
 constexpr int kSegPitch = 68;
 
-// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.  Inline assembly: hipcc 7.2 drops the
-// second result of __builtin_amdgcn_permlane32_swap (both extracts read the first register).  The s_nop covers the
-// VALU-write -> permlane-read hazard, which the assembler does not see.
-__device__ __forceinline__ void swap_halves(float &a, float &b)
-{
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
-
 
 template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false, bool FIXMEL = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfcc4096Args a)

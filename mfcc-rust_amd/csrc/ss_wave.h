@@ -98,6 +98,14 @@ __device__ __forceinline__ float half_sum(float v)
     return v;
 }
 
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.  Inline assembly: hipcc 7.2 drops the
+// second result of __builtin_amdgcn_permlane32_swap (both extracts read the first register).  The s_nop covers the
+// VALU-write -> permlane-read hazard, which the assembler does not see.
+__device__ __forceinline__ void swap_halves(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 // A register that the compiler has to treat as defined, at no cost: an empty asm statement "writes" it.  For arrays that are
 // filled under complementary lane masks (the two half-wave phases of the transposing exchange): left half-defined, the
 // "undefined" halves are carried around the loop as if they were values and spilled.
