@@ -446,9 +446,40 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
     std::vector<int32_t> order(M);
     for (size_t m = 0; m < M; ++m) order[m] = static_cast<int32_t>(m);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return t.bank.len[a] > t.bank.len[b]; });
-    int32_t maxlen[3] = {0, 0, 0};
-    for (size_t q = 0; q < M; ++q) maxlen[q / 16] = std::max(maxlen[q / 16], t.bank.len[order[q]]);
-    for (int s = 0; s < 3; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    // (slot, lane) cell -> filter, -1: unused
+    std::vector<int32_t> cell(48, -1);
+    for (size_t q = 0; q < M; ++q) cell[q] = order[q];
+    auto spans = [&](const std::vector<int32_t> &c, int32_t (&q4)[3]) {
+        int32_t maxlen[3] = {0, 0, 0};
+        for (size_t q = 0; q < 48; ++q)
+            if (c[q] >= 0) maxlen[q / 16] = std::max(maxlen[q / 16], t.bank.len[c[q]]);
+        for (int s = 0; s < 3; ++s) q4[s] = (maxlen[s] + 3) / 4;
+    };
+    spans(cell, f.q4);
+    if (M == 40 && !f.fullp) {
+        // PAIRED layout for the symmetric DCT of the default filter count (ss_mfcc512.hip): the DCT needs s[m] = L[m] + L[39-m] and
+        // d[m] = L[m] - L[39-m]; with filter 39 - m in slot 0 and filter m in slot 2 (m < 8) or slot 1 (8 <= m < 16) of the SAME
+        // lane m, and the pairs (16 + i, 23 - i) in neighbouring lanes 2i, 2i + 1 of slot 1, every s and d is formed in registers -- no ln(mel) row in
+        // LDS, two dependent LDS round trips fewer per quad.  Which lane of a slot holds which filter is free as far as the taps'
+        // bank placement goes (that depends on the SET of first bins in the slot).  Taken when it needs no wider slot than the
+        // sorted layout.
+        // (cells 0 .. 39 only: the other builds of the kernel take their DCT over the first 40 cells of the (slot, lane) row)
+        std::vector<int32_t> pc(48, -1);
+        for (int j = 0; j < 16; ++j) pc[j] = 39 - j;       // slot 0: the wide filters 39 .. 24
+        for (int j = 0; j < 8; ++j) pc[32 + j] = j;        // slot 2, lanes 0 .. 7: filters 0 .. 7
+        for (int j = 8; j < 16; ++j) pc[16 + j] = j;       // slot 1, lanes 8 .. 15: filters 8 .. 15
+        for (int i = 0; i < 4; ++i) {                      // slot 1, lanes 0 .. 7: the middle pairs
+            pc[16 + 2 * i] = 16 + i;
+            pc[16 + 2 * i + 1] = 23 - i;
+        }
+        int32_t pq4[3];
+        spans(pc, pq4);
+        if (pq4[0] <= f.q4[0] && pq4[1] <= f.q4[1] && pq4[2] <= f.q4[2]) {
+            cell = pc;
+            f.paired = true;
+            for (int s = 0; s < 3; ++s) f.q4[s] = pq4[s];
+        }
+    }
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2]);
     if (f.wpitch == 0) f.wpitch = 4;
     if (f.wpitch > 160) return;
@@ -477,8 +508,8 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
         for (int j = 0; j < 16; ++j) {
             const size_t q = static_cast<size_t>(s) * 16 + j;
             lo[j] = hi[j] = 0;
-            if (q >= M) continue;
-            const int32_t m = order[q], st = t.bank.start[m], len = t.bank.len[m];
+            if (cell[q] < 0) continue;
+            const int32_t m = cell[q], st = t.bank.start[m], len = t.bank.len[m];
             hi[j] = std::min(st, kRow - span);          // the lock-step loop reads `span` taps: st + span stays inside the row
             lo[j] = std::max<int32_t>(0, st + len - span);  // the filter's last tap stays inside the span
             if (lo[j] > hi[j]) lo[j] = hi[j];
@@ -502,24 +533,24 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
                     return false;
                 };
                 for (int j = 0; j < 16; ++j) {
-                    if (static_cast<size_t>(s) * 16 + j >= M) continue;
+                    if (cell[static_cast<size_t>(s) * 16 + j] < 0) continue;
                     std::vector<char> seen(16, 0);
                     place(j, seen);  // unmatched lanes keep their latest admissible first bin
                 }
                 // an unused (slot, lane) reads the same words as a used one (same address: a broadcast, never a conflict)
                 int used = -1;
                 for (int j = 0; j < 16; ++j)
-                    if (static_cast<size_t>(s) * 16 + j < M) used = j;
+                    if (cell[static_cast<size_t>(s) * 16 + j] >= 0) used = j;
                 for (int j = 0; j < 16; ++j)
-                    if (static_cast<size_t>(s) * 16 + j >= M && used >= 0) chosen[j] = chosen[used];
+                    if (cell[static_cast<size_t>(s) * 16 + j] < 0 && used >= 0) chosen[j] = chosen[used];
             }
         }
         for (int j = 0; j < 16; ++j) {
             const size_t q = static_cast<size_t>(s) * 16 + j;
             start[q] = chosen[j];
             filt[q] = -1;
-            if (q >= M) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
-            const int32_t m = order[q];
+            if (cell[q] < 0) continue;  // unused (slot, lane): zero weights -> 0 -> EPS -> ln, times a zero cosine column
+            const int32_t m = cell[q];
             filt[q] = m;
             const int32_t len = t.bank.len[m];
             const int32_t st = chosen[j];

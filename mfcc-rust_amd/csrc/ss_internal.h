@@ -83,6 +83,7 @@ struct Fast512Tables {
     int32_t q4[3] = {0, 0, 0};  // taps / 4 per slot
     int32_t wpitch = 0;
     bool fullp = false;         // the bank reaches above bin 128 (librosa-style banks): the kernel keeps all 257 P bins
+    bool paired = false;        // 40 filters: (slot, lane) cells laid out for the in-register symmetric DCT (build_fast512)
     int32_t win_floats = 0;     // frame window appended behind the mel rows (kMelW + 16 * wpitch): 512 floats (zero beyond flen), 0 = rectangular
 };
 void build_fast512(const HostTables &t, Fast512Tables &f);

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     const float *smem_f = reinterpret_cast<const float *>(smem);
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     constexpr bool SYM = (RES & 4) != 0;  // 40 filters: DCT against sum/difference rows with the half cosine row in registers
+    constexpr bool PAIRED = (RES & 8) != 0;  // SYM with the host's paired cell layout: s and d are formed in registers
     const int fidx0 = (MFE || SYM) ? s_filt[j] : 0, fidx1 = (MFE || SYM) ? s_filt[16 + j] : 0, fidx2 = (MFE || SYM) ? s_filt[32 + j] : 0;
     float4 ch[SYM ? 5 : 1];
     if (SYM && TABREG) {
@@ -404,7 +405,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     }
     // SYM: where this lane's three ln(mel) values go in the natural-order row (slots without a filter go to the pad entries)
     float *fr0 = frow + (fidx0 >= 0 ? fidx0 : 47), *fr1 = frow + (fidx1 >= 0 ? fidx1 : 47), *fr2 = frow + (fidx2 >= 0 ? fidx2 : 47);
-    float *sd = ALIAS ? prow + 192 : wbase + 192 + f * 40;  // s[20] = L[m] + L[39-m], d[20] = L[m] - L[39-m] of this frame
+    // s[20] = L[m] + L[39-m], d[20] = L[m] - L[39-m] of this frame (PAIRED: rows 48 floats apart -- room for the writes' dump
+    // words, and the four rows' ds_read_b128 stay in different banks)
+    float *sd = ALIAS ? prow + 192 : wbase + 192 + f * (PAIRED ? 48 : 40);
     const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + j * a.mel_wpitch);
     const float4 *c4 = reinterpret_cast<const float4 *>(s_cos + j * 52);
     float2 twn[8];  // exp(-2 pi i (j + 16 r) / 512): resident when the register budget allows (<= 3 waves per SIMD)
@@ -660,6 +663,35 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         float acc = 0.f;
         if (SS_ABLATE & 32) {
             acc = ln_scaled(m0 + m1 + m2);
+        } else if (SYM && PAIRED) {
+            // ---- DCT-II with cos(pi c (2(39-m)+1)/80) = (-1)^c cos(pi c (2m+1)/80): an even coefficient is a 20-term product with
+            // s[m] = L[m] + L[39-m], an odd one with d[m] = L[m] - L[39-m].  The host laid the cells out so that this lane's slot 0
+            // holds filter 39 - j and its slot 2 (j < 8) or slot 1 (j >= 8) filter j, and lanes 2i, 2i + 1 < 8 of slot 1 the pair
+            // (16 + i, 23 - i): every s and d is formed in registers and goes straight to the sum / difference row -- no ln(mel)
+            // row, one LDS round trip from the logarithms to the products instead of three ----
+            const float l0 = ln_scaled(m0 == 0.f ? kEps * kTwo32 : m0);  // L[39 - j]
+            const float l1 = ln_scaled(m1 == 0.f ? kEps * kTwo32 : m1);  // L[16 + j/2] (even j < 8), L[23 - j/2] (odd j < 8), L[j] (j >= 8)
+            const float l2 = ln_scaled(m2 == 0.f ? kEps * kTwo32 : m2);  // L[j] (j < 8)
+            const float p1 = dpp<0xB1>(l1);                               // quad_perm [1,0,3,2]: the neighbouring lane's
+            const float lj = j < 8 ? l2 : l1;
+            sd[j] = lj + l0;
+            sd[20 + j] = lj - l0;
+            // the four middle pairs, from the even lanes below 8; every other lane writes the row's dump words
+            const int mi = (j < 8 && !(j & 1)) ? 16 + (j >> 1) : 40 + (j & 3);
+            sd[mi] = l1 + p1;
+            sd[(mi < 40 ? 20 : 4) + mi] = l1 - p1;
+            wave_order();
+            const float4 *r4 = reinterpret_cast<const float4 *>(sd + ((j & 1) ? 20 : 0));
+            float4 rq[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) rq[i] = r4[i];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                acc = fmaf(rq[i].x, ch[i].x, acc);
+                acc = fmaf(rq[i].y, ch[i].y, acc);
+                acc = fmaf(rq[i].z, ch[i].z, acc);
+                acc = fmaf(rq[i].w, ch[i].w, acc);
+            }
         } else if (SYM) {
             // ---- DCT-II with cos(pi c (2(39-m)+1)/80) = (-1)^c cos(pi c (2m+1)/80): natural-order row, then the sum and
             // difference rows once per frame; an even coefficient is a 20-term product with s, an odd one with d ----
@@ -854,8 +886,10 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
         }
         if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 1>, "ss_mfcc_c256<10,exact,bank421,mfe>");
+        if (res == 6 && a.n_filters == 40 && a.paired && WAVES <= 12)
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 14>, "ss_mfcc_c256<10,exact,bank421,sym>");
         if (res == 6 && a.n_filters == 40)
-            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, WAVES <= 12 ? 6 : 4>, WAVES <= 12 ? "ss_mfcc_c256<10,exact,bank421,sym>" : "ss_mfcc_c256<10,exact,bank421,sym,w16>");
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, WAVES <= 12 ? 6 : 4>, WAVES <= 12 ? "ss_mfcc_c256<10,exact,bank421,symrow>" : "ss_mfcc_c256<10,exact,bank421,sym,w16>");
         if (res == 6) res = 2;  // the symmetric DCT is written for exactly 40 filters
         if (WAVES <= 12 && res == 1) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 1>, "ss_mfcc_c256<10,exact,bank421,res1>");
         if (WAVES <= 12 && res == 2) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2>, "ss_mfcc_c256<10,exact,bank421,res2>");
