@@ -85,6 +85,11 @@ constexpr bool kNoPrio = true;
 #else
 constexpr bool kNoPrio = false;
 #endif
+#if SS_LAB && defined(SS_PF5)
+constexpr bool kNoPf = false;  // A/B (lab builds, -DSS_PF5=1): the next frame's samples requested in front of the DCT stage
+#else
+constexpr bool kNoPf = true;   // measured and not kept (profiles/r04/ab_cfg5_prefetch.txt): 62.05 against 62.36 us, inside the noise
+#endif
 namespace L = mfcc4096_layout;
 constexpr int kClsStride = 16 * 34 + 8;    // float2 per class slice: +8 keeps the two classes of a write group 16 banks apart
 constexpr int kExFloats = (kClsStride + 16 * 34) * 2;  // exchange region (two classes x half the columns, 8768 B); P row + ln(mel) row reuse it
@@ -141,6 +146,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
     unsigned frame = f_lo + wave;
+    // PF (lab builds with -DSS_PF5=1; the twelve-wave build of the default cfg5 shape): the next frame's samples are requested in front of the DCT stage --
+    // the one stretch of the iteration in which the transform's 64 registers are free -- so their round trip runs under the
+    // stage's 32 table reads and 64 FMAs instead of being waited for at the top of the next iteration (12 % of a wave's time in
+    // the round-4 phase profile).  The stage's one output store is a counted store (ss_wave.h): the samples are then waited for
+    // with it still in flight.  Result: no change (three waves per SIMD already cover a wave's wait for its samples).
+    constexpr bool PF = LEAN && FIXMEL && EXACT && !MFE && !WIN && !PRE && !SS_PROF5 && SS_ABL5 == 0 && !kNoPf;
+    float2 vpf[PF ? 32 : 1];
+    if (PF) {
+        const unsigned fr0 = min(frame, f_hi - 1);  // (a wave without a frame loads the block's last one: no branch around the loads)
+        const unsigned clip0 = fr0 / a.n_frames;
+        const float2 *src0 = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip0) * a.ld + (fr0 - clip0 * a.n_frames) * a.step) + (threadIdx.x & 63);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) vpf[e] = src0[64 * e];
+        buf_store(0.f, out_rsrc(a.out, 0u), 0);  // both ways into the loop have one store behind the samples (see ss_mfcc512.hip)
+    }
 #if SS_PROF5
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -176,8 +196,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // (SS_ABL5 & 16: every frame reads clip 0 -- L2-resident samples; & 32: no sample loads at all)
         const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step) + lane;
         float2 v[32];
+        if (PF) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
+            for (int e = 0; e < 32; ++e) v[e] = vpf[e];
+        }
+#pragma unroll
+        for (int e = 0; e < (PF ? 0 : 32); ++e) {
             if (SS_ABL5 & 32) {
                 v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(frame & 255u));
                 continue;
@@ -422,10 +446,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         }
         wave_order();
         SS_PH(9);  // mel + ln
-        if (!SS_PROF5 && a.dbg && frame == 0) {
+#if SS_LAB
+        if (!SS_PROF5 && a.dbg && frame == 0) {  // SS_DEBUG_ROWS (lab builds): frame 0's P row and ln(mel) row
             for (int i = lane; i < 1028; i += 64) a.dbg[i] = prow[i];
             for (int i = lane; i < 256; i += 64) a.dbg[1028 + i] = frow[i];
         }
+#endif
 
         if (SS_ABL5 & 1) {
             if (lane < Cc) a.out[static_cast<unsigned long long>(frame) * Cc + lane] = frow[lane] + energy;
@@ -445,6 +471,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // three of them to scratch -- 1.5 MB of extra writes per cfg5 launch.  Re-deriving them per frame from an opaque copy
         // of the lane number removes the spills and measured 1.1 us slower, so they stay.)
         if (FIXMEL || a.dct_fold2) {  // (the FIXMEL build is only launched with the twice-folded table: no generic DCT code in it)
+            if (PF) {
+                const unsigned nf = min(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)), f_hi - 1);  // past the end: the last frame again, dropped
+                const unsigned nclip = nf / a.n_frames;
+                const float2 *nsrc = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(nclip) * a.ld + (nf - nclip * a.n_frames) * a.step) + lane;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) vpf[e] = nsrc[64 * e];
+            }
             float *seg = wbase + kSRowOff;
             {
                 const int m2 = lane + 64;
@@ -484,7 +517,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
                 if (kChunk < 16) __builtin_amdgcn_sched_barrier(0);
             }
             if (!even) acc += dpp<0xB1>(acc);  // quad_perm [1,0,3,2]: the coefficient's other half (nep is even)
-            if (lane < ne || (!even && !(lp & 1) && lp < Cc - 1)) {  // the lanes that hold a whole coefficient
+            const bool whole = lane < ne || (!even && !(lp & 1) && lp < Cc - 1);  // the lanes that hold a whole coefficient
+            if (PF) {
+                // scaling + column-0 replacement (feature.rs:126-146); an unconditional, counted store (ss_wave.h)
+                float o = acc * a.dct_scale_k;
+                if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
+                const unsigned frame_s = __builtin_amdgcn_readfirstlane(frame);
+                buf_store(o, out_rsrc(a.out + static_cast<unsigned long long>(frame_s) * Cc, static_cast<unsigned>(Cc) * 4u),
+                          whole ? (even ? 2 * lane : lp + 1) * 4 : kOobOffset);
+            } else if (whole) {
                 // scaling + column-0 replacement (feature.rs:126-146)
                 float o = acc * a.dct_scale_k;
                 if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
