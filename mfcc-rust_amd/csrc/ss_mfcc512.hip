@@ -931,6 +931,9 @@ hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cu
     static const char *w = std::getenv("SS_WAVES");  // A/B knob for occupancy experiments (lab build)
     if (w && std::atoi(w) == 8 && !a.fullp && !a.center) return launch_w<8>(a, stream, num_cus, info);
     if (w && std::atoi(w) == 16 && !a.fullp && !a.center) return launch_w<16>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 10 && !a.fullp && !a.center) return launch_w<10>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 11 && !a.fullp && !a.center) return launch_w<11>(a, stream, num_cus, info);
+    if (w && std::atoi(w) == 9 && !a.fullp && !a.center) return launch_w<9>(a, stream, num_cus, info);
 #endif
     return launch_w<12>(a, stream, num_cus, info);
 }
