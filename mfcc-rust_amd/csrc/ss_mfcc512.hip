@@ -23,15 +23,19 @@
 //     the VALU (measured: a VALU wave and an f32-MFMA wave on one SIMD take the SUM of their times),
 //     so a block-dense product costs 8x the sparse one (tools/ubench/mfma_valu_overlap.hip; the retired
 //     MFMA build of this kernel is tools/experiments/ss_mfcc512_mfma.hip).
-//   * DCT-II: with 40 filters the log-mel row is written in filter order, each frame forms s[m] = L[m] + L[39-m]
-//     and d[m] = L[m] - L[39-m] once, and lane c < n_ceps multiplies 20 terms of s (even c) or d (odd c) with its
-//     half cosine row held in registers (template RES bit 2).  Other filter counts: 48-entry (slot, lane)-ordered
-//     row against the lane's cosine row in LDS (pitch 52 floats: conflict-free).
-//   * What bounds it (round 2): a SIMD issues one VALU instruction per 2.1 cycles when two of its waves have
-//     one ready (tools/ubench/valu_issue.hip), which puts the VALU floor of a 1024-clip launch at ~16 us of its 32-36; the
-//     LDS array is ~40 % busy.  Neither is saturated -- LDS round trips that three waves per SIMD do not cover and the
-//     per-launch start / tail make up the rest -- but both matter, so the code is still written for instruction count:
-//     twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2 twiddles in registers (RES bit 1), ln on values
+//   * DCT-II: with 40 filters cos(pi c (2(39-m)+1)/80) = (-1)^c cos(pi c (2m+1)/80), so lane c < n_ceps multiplies 20 terms of
+//     s[m] = L[m] + L[39-m] (even c) or d[m] = L[m] - L[39-m] (odd c) with its half cosine row held in registers.  The host lays
+//     the (slot, lane) cells out so that a lane owns both filters of a pair (build_fast512, "paired", round 4): s and d are
+//     formed in registers and go straight to the row the products read (template RES bits 2 + 3).  Other filter counts:
+//     48-entry (slot, lane)-ordered ln(mel) row against the lane's cosine row in LDS (pitch 52 floats: conflict-free).
+//   * Output stores are counted stores (ss_wave.h): unconditional buffer stores whose descriptor drops what must not be written,
+//     so that the wait for the next quad's prefetched samples leaves them in flight (vmcnt(1) / (4) / (17) instead of vmcnt(0)).
+//   * What bounds it (round 4, DESIGN.md 4 / 5, profiles/r04/): 623 -> 619 VALU and 73 -> 66 LDS instructions per quad; a SIMD
+//     issues one VALU instruction per 2.14 cycles when two of its waves have one ready, and the launch runs at 0.54 of that
+//     floor (61 k shader cycles per 1024-clip launch; waves 20 % in s_waitcnt, 27 % stalled at issue, 11 % on the LDS queue; LDS
+//     array half busy, no bank conflicts).  The part trades clock for issue density: 8 .. 12 waves per CU all take 30.1 +- 0.5 us
+//     while the clock falls from 2.37 to 2.01 GHz (profiles/r04/ab_cfg2_waves_per_cu.txt).  The code is written for instruction
+//     count: twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2 twiddles in registers (RES bit 1), ln on values
 //     pre-scaled by 2^32, scalar frame -> (clip, t) division, conflict-free LDS accesses throughout.
 //   * Builds (template OUTK / FRONT): MFCC; mfe's (features, energy); power_spectrum rows; each optionally with a
 //     frame window and fused pre-emphasis on load.
