@@ -264,9 +264,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     float4 tw4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) tw4[i] = s_twn4[4 * hb + i];
-#if SS_LAB && defined(SS_XSTFT4)
-                    float4 xkeep = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         const int q = 8 * hb + qq;
@@ -280,16 +277,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         const float xr = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
                         const float xi = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
                         if (STFT) {
-#if SS_LAB && defined(SS_XSTFT4)
-                            // store-width probe (lab builds, results wrong by design): the same bytes as 16-byte stores
-                            static_assert(true, "");
-                            if (qq & 1) {
-                                buf_store(make_float4(cs * xr, cs * xi, xkeep.x, xkeep.y), srs, srow_off + (2 * j + 64 * (q >> 1)) * 8);
-                                buf_store(make_float4(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi), xkeep.z, xkeep.w), srs, srow_off + (1024 - 62 - 64 * (q >> 1) + 2 * j - 1) * 8);
-                            } else {
-                                xkeep = make_float4(cs * xr, cs * xi, cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi));
-                            }
-#elif SS_LAB && defined(SS_XAUX)
+#if SS_LAB && defined(SS_XAUX)
                             // cache-policy probe (lab builds): the row stores with other policy bits
                             buf_store<SS_XAUX>(make_float2(cs * xr, cs * xi), srs, srow_off + (j + 32 * q) * 8);
                             buf_store<SS_XAUX>(make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi)), srs, srow_off + (1024 - j - 32 * q) * 8);
