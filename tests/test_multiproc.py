@@ -2,12 +2,15 @@
 the oracle's f32 port (tests may use the oracle); on GPUs the same code path calls the HIP kernels."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -221,3 +224,60 @@ def test_abi_rccl_all_gather_single_rank(ss, sslib):
         assert sslib.ss_rccl_library(b"/nonexistent/librccl.so") == 3  # too late: RCCL is already resolved in this process
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+_MOCK_SCRIPT = r"""
+import ctypes as C, os, subprocess, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(ROOT, "mfcc-rust_amd"))
+import speechsauce_amd as ss
+from speechsauce_amd import _lib
+lib = _lib.lib()
+mock_path = os.path.join(TMP, "libmock_rccl.so")
+subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-o", mock_path], check=True)
+# a path that does not load is reported with the loader's message and can be corrected (nothing is cached until one resolves)
+assert lib.ss_rccl_library(b"/nonexistent/librccl.so") == 0
+x = torch.from_numpy((np.random.default_rng(3).standard_normal((12, 16000)) * 0.1).astype(np.float32)).cuda()
+feats = ss.mfcc_batch(x, 16000)                      # [12, 98, 13]: four "ranks" of three clips each
+world, per = 4, 3 * 98 * 13
+ranks = [C.c_int(r) for r in range(world)]
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+out = torch.zeros_like(feats)
+assert lib.ss_gather_features(C.byref(ranks[1]), feats[3:6].data_ptr(), per, None, 2, 1, world, stream) == 5   # SS_ERR_UNSUPPORTED
+assert b"nonexistent" in lib.ss_last_error_string(), lib.ss_last_error_string()
+assert lib.ss_rccl_library(mock_path.encode()) == 0
+mock = C.CDLL(mock_path)
+root = 2
+for r in (0, 1, 3):   # the peers only send; they may pass a null output
+    assert lib.ss_gather_features(C.byref(ranks[r]), feats[3 * r:3 * r + 3].contiguous().data_ptr(), per, None, root, r, world, stream) == 0
+assert lib.ss_gather_features(C.byref(ranks[root]), feats[3 * root:3 * root + 3].contiguous().data_ptr(), per, out.data_ptr(), root, root, world, stream) == 0
+torch.cuda.synchronize()
+assert torch.equal(out, feats), "blocks out of rank order"
+log = [mock.mock_log_at(i) for i in range(mock.mock_log_size())]
+assert log == [200 + root] * 3 + [1, 100, 101, 103, 2], log   # three sends to the root; one group with a receive per peer, in rank order
+# argument checks on the multi-rank path
+assert lib.ss_gather_features(C.byref(ranks[root]), feats.data_ptr(), per, None, root, root, world, stream) == 3   # the root needs an output buffer
+assert lib.ss_gather_features(C.byref(ranks[0]), feats.data_ptr(), per, None, 4, 0, world, stream) == 3           # bad root
+# all-gather on the mock: every rank's block lands at its rank's offset
+out.zero_()
+for r in range(world):
+    assert lib.ss_all_gather_features(C.byref(ranks[r]), feats[3 * r:3 * r + 3].contiguous().data_ptr(), per, out.data_ptr(), stream) == 0
+torch.cuda.synchronize()
+assert torch.equal(out, feats)
+assert lib.ss_rccl_library(b"/somewhere/else.so") == 3   # resolved now: too late
+print("MOCK-GATHER-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_gather_features_rank_order_on_a_mock_backend(tmp_path):
+    """ss_gather_features with more than one rank (peers: ncclSend; root: its own block by a device copy plus one ncclRecv per
+    peer inside a group; output in rank order) has never met a second GPU -- RCCL refuses two ranks on one device.  Here its
+    code paths run against a stand-in backend (tests/mock_rccl: send parks the pointer, recv copies from it) in a fresh process,
+    since the resolved RCCL is process-wide: the library's logic is checked, RCCL and xGMI are not.  Also: an ss_rccl_library
+    path that fails to load is reported with the loader's message and can be corrected by a second call."""
+    import subprocess
+
+    script = "ROOT = %r\nTMP = %r\n" % (ROOT, str(tmp_path)) + _MOCK_SCRIPT
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MOCK-GATHER-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
