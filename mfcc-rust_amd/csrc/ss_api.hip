@@ -1101,9 +1101,14 @@ bool rccl_from(void *handle, const char *origin, Rccl &r)
     return r.ok();
 }
 
-const Rccl *rccl()
+// (why: the reason of a failed resolution, copied under the lock)
+const Rccl *rccl(std::string *why = nullptr)
 {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
+    struct Report {
+        std::string *out;
+        ~Report() { if (out) *out = g_rccl_error; }
+    } report{why};
     if (g_rccl) return g_rccl.get();  // only a successful resolution is kept
     std::unique_ptr<Rccl> r(new Rccl());
     auto keep = [&]() {
@@ -1174,8 +1179,9 @@ int ss_all_gather_features(void *nccl_comm, const float *d_block, size_t elems_p
 {
     if (!nccl_comm || !d_block || !d_out) return ss::fail(SS_ERR_ARG, "null argument");
     if (elems_per_rank == 0) return SS_OK;
-    const Rccl *r = rccl();
-    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (" + g_rccl_error + ")");
+    std::string why;
+    const Rccl *r = rccl(&why);
+    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (" + why + ")");
     // ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream)
     const int rc = r->all_gather(d_block, d_out, elems_per_rank, kNcclFloat32, nccl_comm, static_cast<hipStream_t>(stream));
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
@@ -1189,8 +1195,9 @@ int ss_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_r
     if (world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world) return ss::fail(SS_ERR_ARG, "bad world / rank / root");
     if (rank == root && !d_out) return ss::fail(SS_ERR_ARG, "the root needs an output buffer");
     if (elems_per_rank == 0) return SS_OK;
-    const Rccl *r = rccl();
-    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (" + g_rccl_error + ")");
+    std::string why;
+    const Rccl *r = rccl(&why);
+    if (!r) return ss::fail(SS_ERR_UNSUPPORTED, "RCCL could not be resolved (" + why + ")");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (rank != root) {
         const int rc = r->send(d_block, elems_per_rank, kNcclFloat32, root, nccl_comm, st);

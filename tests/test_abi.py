@@ -231,3 +231,18 @@ def test_cpp_mirror_header_compiles_and_fails_loudly(tmp_path, sslib):
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     rc = subprocess.run([str(exe)]).returncode
     assert rc == (0 if _has_gpu() else 10)
+
+
+def test_the_front_can_be_pointed_at_the_lab_build_and_back(sslib, sslab):
+    """speechsauce_amd._lib.use_library: inside the block the front runs on the given build (the lab library, for tests that
+    need its aids), configs memoised by the front are dropped on the way in and out (a config belongs to the library that
+    created it), and the product library is back afterwards."""
+    import speechsauce_amd as ss
+    from speechsauce_amd import _lib
+
+    assert _lib.lib() is sslib and sslib is not sslab
+    with _lib.use_library(sslab) as h:
+        assert h is sslab and _lib.lib() is sslab
+        assert ss._get_speech_config.cache_info().currsize == 0
+    assert _lib.lib() is sslib
+    assert _lib.lab() is sslab  # loaded once
