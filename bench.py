@@ -69,6 +69,58 @@ def synth_batch(torch, batch, n, seed, device):
     return torch.randn((batch, n), generator=g, device=device, dtype=torch.float32).mul_(0.1)
 
 
+class BoardProbe:
+    """Socket power and shader clock of this process's GPU, read from its hwmon directory (found by PCI address: a box has eight)
+    every 10 ms on a thread while the untimed pre-roll launches run -- the timed region itself is too short to sample.  Context for
+    `roofline.frac`: on random samples the kernels sit at the board's power cap and below its peak clock.  None where
+    the files cannot be read."""
+
+    def __init__(self, torch, device):
+        import glob
+        import threading
+
+        self.samples, self.done, self.thread = [], False, None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            self.pw = [p for h in hw for n in ("power1_average", "power1_input") for p in glob.glob(f"{h}/{n}")]
+            self.fq = [p for h in hw for p in glob.glob(f"{h}/freq1_input")]
+            self.cap = self._read([p for h in hw for p in glob.glob(f"{h}/power1_cap")])
+        except Exception:
+            self.pw, self.fq, self.cap = [], [], None
+        if self.pw or self.fq:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+    @staticmethod
+    def _read(paths):
+        try:
+            return int(open(paths[0]).read().split()[0])
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self.done:
+            self.samples.append((self._read(self.pw), self._read(self.fq)))
+            time.sleep(0.01)
+
+    def stop(self):
+        self.done = True
+        if not self.thread:
+            return None
+        self.thread.join()
+        tail = self.samples[len(self.samples) // 2:]  # the second half: the sensors lag the load by tens of milliseconds
+        p = [a / 1e6 for a, _ in tail if a]
+        f = [b / 1e6 for _, b in tail if b]
+        if not p and not f:
+            return None
+        return {"power_w_mean": round(sum(p) / len(p)) if p else None, "power_w_max": round(max(p)) if p else None,
+                "power_cap_w": round(self.cap / 1e6) if self.cap else None,
+                "sclk_mhz_mean": round(sum(f) / len(f)) if f else None, "sclk_mhz_min": round(min(f)) if f else None,
+                "samples": len(tail), "when": "second half of the untimed pre-roll of the same launches (hwmon, 10 ms period)"}
+
+
 def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
     """Time the oracle's reference-shaped f32 port, single thread, on fresh clips until ~budget_s."""
     import numpy as np
@@ -200,7 +252,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="same as --gather-mode none")
     ap.add_argument("--gather-every", type=int, default=8, help="steps per gather bucket (fewer, larger collectives)")
     ap.add_argument("--force-generic", action="store_true", help="run on the generic kernel (ss_debug_force_generic): the 'generic us' columns of DESIGN.md")
-    ap.add_argument("--prewarm-ms", type=float, default=200.0, help="untimed launches before the warm-up steps, to leave the idle power state")
+    ap.add_argument("--prewarm-ms", type=float, default=500.0,
+                    help="untimed launches before the warm-up steps: leaves the idle power state (200 ms do) and lets the board's power sensor settle for roofline.board")
     ap.add_argument("--streams", type=int, default=1, help="issue successive steps round-robin on this many HIP streams "
                     "(independent batches in flight: one launch's tail overlaps the next one's head); the roofline block "
                     "is then per-step wall time, not a kernel duration -- not the headline setting")
@@ -400,8 +453,10 @@ def main():
         return {"elapsed": elapsed, "dev_ms": e0.elapsed_time(e1), "segs": segs, "comm_ms": comm_ms, "comm_steps": comm_steps}
 
     warm = Region(True)
+    board = None
     if args.prewarm_ms > 0:  # leave the idle power state before the (possibly few) warm-up steps
         pre = Region(False)
+        probe = BoardProbe(torch, device) if rank == 0 else None  # socket power / shader clock while these launches run
         t_end = time.perf_counter() + args.prewarm_ms * 1e-3
         k = 0
         while time.perf_counter() < t_end:
@@ -409,6 +464,8 @@ def main():
                 pre.step(k)
                 k += 1
             torch.cuda.synchronize()
+        if probe:
+            board = probe.stop()
     for i in range(args.warmup):  # warm-up runs the full step (with the collective when there is one)
         warm.step(i)
         warm.after_step(i, i + 1 == args.warmup)
@@ -508,6 +565,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kind, pkw, n_samples, args.cpu_seconds)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(kind, pkw, n_samples, args.cpu_seconds / 2)
+        if board:
+            res["roofline"]["board"] = board
         if clock_ghz is not None:
             rf = res["roofline"]
             rf["clock_ghz_measured"] = clock_ghz
