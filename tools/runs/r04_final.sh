@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -4
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
 python bench.py --steps 20 --warmup 5 2>/dev/null | tee gpurun_out/r04/bench_final_steps20.json | python -c "
