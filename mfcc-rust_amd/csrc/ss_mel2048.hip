@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         }
     };
 
-    unsigned unit = u_lo + wave;
+    unsigned unit = __builtin_amdgcn_readfirstlane(u_lo + wave);  // uniform: kept scalar
     float2 v[32];
     if (unit < u_hi) load_unit(unit, v);
     if (STFT) {

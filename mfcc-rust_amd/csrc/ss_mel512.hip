@@ -102,7 +102,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c256(const Mel512Args a)
             }
         }
     };
-    unsigned unit = u_lo + wave;
+    unsigned unit = __builtin_amdgcn_readfirstlane(u_lo + wave);  // uniform: kept scalar
     float2 vin[16];
     if (unit < u_hi) load_unit(unit, vin);
 

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c512(const Mfcc1024Args a)
     const bool pre = a.preemph != 0.f;  // fused pre-emphasis (run-time: a uniform branch in the loader)
     const unsigned psh = a.preemph_shift % a.n_samples;
 
-    unsigned unit = u_lo + wave;
+    unsigned unit = __builtin_amdgcn_readfirstlane(u_lo + wave);  // uniform: kept scalar
     while (unit < u_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c512(const Mel2048Args a)
     const float hs = 0.25f * a.scale * a.scale;                    // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
     const bool k1z = k1 == 0;
 
-    unsigned unit = u_lo + wave;
+    unsigned unit = __builtin_amdgcn_readfirstlane(u_lo + wave);  // uniform: kept scalar
     while (unit < u_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c1024(const Mfcc2048Args a
     constexpr bool pre = PRE;  // fused pre-emphasis: builds of their own (LIB layout: they also serve centred frames)
     const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
-    unsigned unit = u_lo + wave;
+    unsigned unit = __builtin_amdgcn_readfirstlane(u_lo + wave);  // uniform: kept scalar
     while (unit < u_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256x2(const Mfcc256Args a
         for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) *s_next = o_lo + WAVES;
     }
-    unsigned oct = o_lo + wave;
+    unsigned oct = __builtin_amdgcn_readfirstlane(o_lo + wave);  // uniform: kept scalar
     float2 vin[NE];
     unsigned tA_next = 0, tB_next = 0;
     const bool pre = a.preemph != 0.f;  // pre-emphasised samples are formed at load time: no prefetch across the iteration then

@@ -145,7 +145,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     constexpr bool pre = PRE;  // fused pre-emphasis: builds of their own (the taps cost registers the plain builds do not have)
     const unsigned psh = PRE ? a.preemph_shift % a.n_samples : 0u;
 
-    unsigned frame = f_lo + wave;
+    // (uniform, but born from the wave number: without the readfirstlane it is a VGPR to the compiler and the clip / frame split and
+    // the 64-bit source address of every iteration are computed on the VALU -- ~25 instructions with five quarter-rate multiplies)
+    unsigned frame = __builtin_amdgcn_readfirstlane(f_lo + wave);
     // PF (lab builds with -DSS_PF5=1; the twelve-wave build of the default cfg5 shape): the next frame's samples are requested in front of the DCT stage --
     // the one stretch of the iteration in which the transform's 64 registers are free -- so their round trip runs under the
     // stage's 32 table reads and 64 FMAs instead of being waited for at the top of the next iteration (12 % of a wave's time in
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mel_c2048(const Mel2048Args a)
     const float hs = 0.25f * a.scale * a.scale;                      // |X wnorm|^2 = (wnorm^2 / 4) |2X|^2
     const bool k1z = k1 == 0;
 
-    unsigned row = f_lo + wave;
+    unsigned row = __builtin_amdgcn_readfirstlane(f_lo + wave);  // uniform: kept scalar
     while (row < f_hi) {
         unsigned next = 0;
         if (lane == 0) next = atomicAdd(s_next, 1u);

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     // first quad of this wave; its loads are in flight across the barrier (a wave without a quad loads the block's last
     // one: no branch around the loads).  The table waves ask for their samples right behind their table loads, before they
     // wait for the tables: vector loads return in order, so the tables still come first.
-    unsigned quad = q_lo + wave;
+    unsigned quad = __builtin_amdgcn_readfirstlane(q_lo + wave);  // uniform: kept scalar
     float2 vin[NE];
     float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin

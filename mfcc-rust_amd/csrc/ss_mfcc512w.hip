@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256w(const Mfcc256Args a)
         for (int i = tid; i < n4; i += WAVES * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) *s_next = q_lo + WAVES;
     }
-    unsigned quad = q_lo + wave;
+    unsigned quad = __builtin_amdgcn_readfirstlane(q_lo + wave);  // uniform: kept scalar
     float2 vin[NE];
     unsigned t_next = 0;
     const bool pre = a.preemph != 0.f;  // pre-emphasised samples are formed at load time: no prefetch across the iteration then
