@@ -10,6 +10,7 @@ tools/profile.sh r04_cfg2 > gpurun_out/r04/cfg2_pmc_summary.txt 2>&1
 tools/profile.sh r04_cfg3 --workload cfg3 --steps 1000 --warmup 100 > gpurun_out/r04/cfg3_pmc_summary.txt 2>&1
 tools/profile.sh r04_cfg5 --workload cfg5 --steps 1000 --warmup 100 > gpurun_out/r04/cfg5_pmc_summary.txt 2>&1
 for w in cfg2 cfg3 cfg5; do cp gpurun_out/prof_r04_$w/trace/*/*kernel_stats.csv gpurun_out/r04/${w}_kernel_stats.csv; cp gpurun_out/prof_r04_$w/summary.json gpurun_out/r04/${w}_pmc_summary.json; done
+rm -rf gpurun_out/prof_r04_*  # raw traces: more than gpurun copies back; the summaries above are what is kept
 python tools/stage_rate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04/stage_rate.txt
 python tools/stft_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04/stft_vs_batch.txt
 for f in gpurun_out/r04/bench_cfg*.json; do python -c "
