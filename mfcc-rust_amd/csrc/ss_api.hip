@@ -298,7 +298,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.center = centre;
         f.pad_reflect = a.pad_reflect;
         f.fullp = cfg->fast.fullp;
-        f.paired = cfg->fast.paired ? 1 : 0;
+        f.paired = cfg->fast.paired ? (cfg->fast.tight ? 2 : 1) : 0;
 #if SS_LAB
         if (dbg_path && !dbg_done && !f.out_mfe) {
             dbg_done = true;

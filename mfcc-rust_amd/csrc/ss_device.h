@@ -132,7 +132,8 @@ struct Fast512Args {
     int32_t center;         // frame t covers x[t*step - flen/2 : t*step + flen/2); flen % 4 == 0
     int32_t pad_reflect;    // center: np.pad 'reflect' outside the clip (else zeros)
     int32_t fullp;          // the table block was built for P rows of all 257 bins
-    int32_t paired;         // 40 filters: filter m in slot 2 and 39 - m in slot 0 of one lane, (16 + i, 23 - i) in lanes 2i, 2i + 1 of slot 1
+    int32_t paired;         // 40 filters: filter m in slot 2 and 39 - m in slot 0 of one lane, (16 + i, 23 - i) in lanes 2i, 2i + 1 of slot 1;
+                            // 2: and the filters of slots 1 / 2 lie inside the slots' first 6 / 2 taps
     unsigned long long *dbg;  // diagnostic runs only: per-wave realtime stamps, or null
     // filled by launch_mfcc_c256: floor(x / n_frames) = umulhi(x, nf_magic) >> nf_shift for x < 2^31 (nf_magic = 0: divide)
     uint32_t nf_magic, nf_shift;

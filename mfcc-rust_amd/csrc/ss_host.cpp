@@ -480,6 +480,20 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
             for (int s = 0; s < 3; ++s) f.q4[s] = pq4[s];
         }
     }
+    // TIGHT (the default bank: 16 / 5 / 1 taps at most in the three slots): the filters of slots 1 and 2 are placed inside the
+    // slots' first 6 and 2 taps, and the paired build of the kernel reads and multiplies no more than those (the slots keep
+    // their float4 pitch, and every other build of the kernel reads the same table with its 8 and 4 taps: zeros behind).
+    int32_t tspan[3] = {4 * f.q4[0], 4 * f.q4[1], 4 * f.q4[2]};
+    if (f.paired && f.q4[0] == 4 && f.q4[1] == 2 && f.q4[2] == 1) {
+        int32_t maxlen[3] = {0, 0, 0};
+        for (size_t q = 0; q < 48; ++q)
+            if (cell[q] >= 0) maxlen[q / 16] = std::max(maxlen[q / 16], t.bank.len[cell[q]]);
+        if (maxlen[1] <= 6 && maxlen[2] <= 2) {
+            f.tight = true;
+            tspan[1] = 6;
+            tspan[2] = 2;
+        }
+    }
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2]);
     if (f.wpitch == 0) f.wpitch = 4;
     if (f.wpitch > 160) return;
@@ -511,7 +525,7 @@ void build_fast512(const HostTables &t, Fast512Tables &f)
             if (cell[q] < 0) continue;
             const int32_t m = cell[q], st = t.bank.start[m], len = t.bank.len[m];
             hi[j] = std::min(st, kRow - span);          // the lock-step loop reads `span` taps: st + span stays inside the row
-            lo[j] = std::max<int32_t>(0, st + len - span);  // the filter's last tap stays inside the span
+            lo[j] = std::max<int32_t>(0, st + len - tspan[s]);  // the filter's last tap stays inside the span (TIGHT: the taps the kernel reads)
             if (lo[j] > hi[j]) lo[j] = hi[j];
         }
         {

@@ -84,6 +84,7 @@ struct Fast512Tables {
     int32_t wpitch = 0;
     bool fullp = false;         // the bank reaches above bin 128 (librosa-style banks): the kernel keeps all 257 P bins
     bool paired = false;        // 40 filters: (slot, lane) cells laid out for the in-register symmetric DCT (build_fast512)
+    bool tight = false;         // paired, and every filter of slot 1 / slot 2 lies inside the slot's first 6 / 2 taps (the kernel reads no more)
     int32_t win_floats = 0;     // frame window appended behind the mel rows (kMelW + 16 * wpitch): 512 floats (zero beyond flen), 0 = rectangular
 };
 void build_fast512(const HostTables &t, Fast512Tables &f);

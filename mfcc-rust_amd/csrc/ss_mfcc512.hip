@@ -256,6 +256,26 @@ __device__ __forceinline__ float mel_slot_fixed(const float4 *w4, const float *p
     return acc;
 }
 
+// One mel slot with a compile-time tap count that need not be a multiple of 4 (TIGHT builds): whole float4s of weights, T taps
+template <int T>
+__device__ __forceinline__ float mel_slot_taps(const float4 *w4, const float *p)
+{
+    constexpr int Q = (T + 3) / 4;
+    float4 w[Q];
+    float t[T];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) w[i] = w4[i];
+#pragma unroll
+    for (int i = 0; i < T; ++i) t[i] = p[i];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const float wi = (i & 3) == 0 ? w[i / 4].x : (i & 3) == 1 ? w[i / 4].y : (i & 3) == 2 ? w[i / 4].z : w[i / 4].w;
+        acc = fmaf(wi, t[i], acc);
+    }
+    return acc;
+}
+
 // Same with a run-time tap count (configurations other than the default bank shape): chunks of 4, 2 and 1 float4 of
 // weights, so that a slot costs a few LDS round trips instead of one per four taps.
 __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p, int q4)
@@ -400,6 +420,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     const int *s_filt = reinterpret_cast<const int *>(s_tab + L::kFilt);
     constexpr bool SYM = (RES & 4) != 0;  // 40 filters: DCT against sum/difference rows with the half cosine row in registers
     constexpr bool PAIRED = (RES & 8) != 0;  // SYM with the host's paired cell layout: s and d are formed in registers
+    constexpr bool TIGHT = (RES & 16) != 0;  // PAIRED with the host's tight tap placement: slots 1 / 2 read 6 / 2 taps
     const int fidx0 = (MFE || SYM) ? s_filt[j] : 0, fidx1 = (MFE || SYM) ? s_filt[16 + j] : 0, fidx2 = (MFE || SYM) ? s_filt[32 + j] : 0;
     float4 ch[SYM ? 5 : 1];
     if (SYM && TABREG) {
@@ -630,8 +651,9 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         }
         if (BANK421) {
             m0 = mel_slot_fixed<4>(w4, smem_f + st0);
-            m1 = mel_slot_fixed<2>(w4 + 4, smem_f + st1);
-            m2 = mel_slot_fixed<1>(w4 + 6, smem_f + st2);
+            // TIGHT: the host placed every filter of slots 1 / 2 inside the first 6 / 2 taps (the dropped products are x * 0)
+            m1 = TIGHT ? mel_slot_taps<6>(w4 + 4, smem_f + st1) : mel_slot_fixed<2>(w4 + 4, smem_f + st1);
+            m2 = TIGHT ? mel_slot_taps<2>(w4 + 6, smem_f + st2) : mel_slot_fixed<1>(w4 + 6, smem_f + st2);
         } else {
             m0 = mel_slot_loop(w4, smem_f + st0, a.mel_q4[0]);
             m1 = mel_slot_loop(w4 + a.mel_q4[0], smem_f + st1, a.mel_q4[1]);
@@ -890,8 +912,10 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 0, 3>, "ss_mfcc_c256<10,exact,bank421,win,pre>");
         }
         if (a.out_mfe) return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 2, 1>, "ss_mfcc_c256<10,exact,bank421,mfe>");
+        if (res == 6 && a.n_filters == 40 && a.paired == 2 && WAVES <= 12)
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 30>, "ss_mfcc_c256<10,exact,bank421,sym>");
         if (res == 6 && a.n_filters == 40 && a.paired && WAVES <= 12)
-            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 14>, "ss_mfcc_c256<10,exact,bank421,sym>");
+            return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, 14>, "ss_mfcc_c256<10,exact,bank421,sym,taps84>");
         if (res == 6 && a.n_filters == 40)
             return go(ss_mfcc_c256<10, true, false, WAVES, true, 10, WAVES <= 12 ? 6 : 4>, WAVES <= 12 ? "ss_mfcc_c256<10,exact,bank421,symrow>" : "ss_mfcc_c256<10,exact,bank421,sym,w16>");
         if (res == 6) res = 2;  // the symmetric DCT is written for exactly 40 filters
