@@ -409,8 +409,14 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                     else v[e] = src[32 * e];
                 }
 #else
+                // (uniform base -- the unit's first row -- + this lane's 32-bit byte offset: loads in the SGPR-base form)
+                const unsigned unit_s = __builtin_amdgcn_readfirstlane(unit);
+                const unsigned clip_s = unit_s / pairs;
+                const long long start0 = static_cast<long long>((unit_s - clip_s * pairs) * 2 + a.n_pad + 1) * static_cast<long long>(a.hop) - 2048;
+                const char *sb = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>(clip_s) * a.ld) + start0 * 4;
+                const unsigned so = static_cast<unsigned>(half) * a.hop * 4u + static_cast<unsigned>(j) * 8u;
 #pragma unroll
-                for (int e = 0; e < 32; ++e) v[e] = src[32 * e];
+                for (int e = 0; e < 32; ++e) v[e] = *reinterpret_cast<const float2 *>(sb + so + 256u * e);
 #endif
             } else {
                 // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows: see ss_mel_c1024

@@ -196,7 +196,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         const unsigned t = frame - clip * a.n_frames;
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
         // (SS_ABL5 & 16: every frame reads clip 0 -- L2-resident samples; & 32: no sample loads at all)
-        const float2 *src = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step) + lane;
+        // (uniform base + this lane's 32-bit byte offset: the loads take the SGPR-base form, no 64-bit address is formed on the VALU)
+        const char *src_b = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step);
+        const unsigned src_o = static_cast<unsigned>(lane) * 8u;
+        const float2 *src = reinterpret_cast<const float2 *>(src_b + src_o);
         float2 v[32];
         if (PF) {
 #pragma unroll
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
                 v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(frame & 255u));
                 continue;
             }
-            if (EXACT) v[e] = src[64 * e];
+            if (EXACT) v[e] = *reinterpret_cast<const float2 *>(src_b + src_o + 512u * e);
             else {  // zero pad, processing.rs:147-156; an odd frame length ends in a half pair
                 const int rem = static_cast<int>(a.flen) - 2 * (lane + 64 * e);
                 v[e] = rem >= 2 ? src[64 * e] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[128 * e] : 0.f, 0.f);

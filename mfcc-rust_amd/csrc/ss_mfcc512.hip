@@ -214,24 +214,40 @@ __device__ __forceinline__ unsigned load_quad(const Fast512Args &a, unsigned qua
 }
 
 // Contract framing only: where this lane's frame of `quad` starts (frame t of its clip begins at sample t * step), and t.
-__device__ __forceinline__ const float2 *quad_src(const Fast512Args &a, unsigned quad, unsigned total, int f, unsigned &t_out)
+// `quad` is uniform: the clip / frame split of the quad's first frame, the clip's address and the frame's offset in it are scalar
+// work, and what a lane adds is a 32-bit byte offset (its frame within the quad, its sample pair, one conditional step into the
+// next clip) -- the loads take the SGPR-base + VGPR-offset form and no 64-bit address is formed on the VALU.
+struct QuadSrc {
+    const char *base;  // uniform
+    unsigned off;      // this lane's byte offset
+};
+__device__ __forceinline__ QuadSrc quad_src(const Fast512Args &a, unsigned quad, unsigned total, int f, int j, unsigned &t_out)
 {
     const unsigned q4 = quad * 4;
-    const unsigned fl = min(static_cast<unsigned>(f), total - 1 - q4);
-    unsigned clip, t;
+    const unsigned fl = min(static_cast<unsigned>(f), total - 1 - q4);  // lanes past the last frame redo it
     if (a.nf_magic) {
-        clip = __umulhi(q4, a.nf_magic) >> a.nf_shift;
-        t = q4 - clip * a.n_frames + fl;
-        const bool wrap = t >= a.n_frames;
-        t -= wrap ? a.n_frames : 0u;
-        clip += wrap ? 1u : 0u;
-    } else {
-        const unsigned gf = q4 + fl;
-        clip = gf / a.n_frames;
-        t = gf - clip * a.n_frames;
+        const unsigned clip = __umulhi(q4, a.nf_magic) >> a.nf_shift;
+        const unsigned t0 = q4 - clip * a.n_frames;
+        const unsigned traw = t0 + fl;
+        const bool wrap = traw >= a.n_frames;
+        t_out = min(traw, traw - a.n_frames);  // (unsigned: the difference is huge unless the frame belongs to the next clip)
+        // a step into the next clip: + ld samples, - n_frames * step of them
+        const unsigned into_next = (static_cast<unsigned>(a.ld) - a.n_frames * a.step) * 4u;
+        QuadSrc r;
+        r.base = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>(clip) * a.ld + static_cast<unsigned long long>(t0) * a.step);
+        r.off = __umul24(fl, a.step * 4u) + static_cast<unsigned>(j) * 8u + (wrap ? into_next : 0u);
+        return r;
     }
+    // clips of fewer than four frames (no reciprocal: a quad may span several clips): the lane's offset from the first clip's first
+    // sample, which launch_w has checked to fit 32 bits for the whole batch
+    const unsigned gf = q4 + fl;
+    const unsigned clip = gf / a.n_frames;
+    const unsigned t = gf - clip * a.n_frames;
     t_out = t;
-    return reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip) * a.ld + t * a.step);
+    QuadSrc r;
+    r.base = reinterpret_cast<const char *>(a.x);
+    r.off = (clip * static_cast<unsigned>(a.ld) + t * a.step) * 4u + static_cast<unsigned>(j) * 8u;
+    return r;
 }
 
 // One mel slot with a compile-time tap count (multiple of 4): weights and P taps are all requested before
@@ -524,8 +540,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         // order: behind a burst of vector-memory instructions its own VALU work waits); no branch surrounds them -- the last
         // iteration of a wave fetches the block's last quad again and drops it
         constexpr bool SPREAD = PREFETCH && EXACT && !PRE && !CENTER && !(SS_ABLATE & 16);
-        const float2 *nsrc = nullptr;
-        if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, t_next) + j;
+        QuadSrc nsrc{nullptr, 0u};
+        if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, j, t_next);
         if (!SPREAD && PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
         float2 u[16];
 #pragma unroll
@@ -546,10 +562,10 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             u[2 * p + 1] = cmul(u[2 * p + 1], make_float2(w2.x, w2.y));
             if (p < 7) u[2 * p + 2] = cmul(u[2 * p + 2], make_float2(w2.z, w2.w));
             if (SPREAD) {
-                if (p < NE) vin[p] = nsrc[16 * p];
+                if (p < NE) vin[p] = *reinterpret_cast<const float2 *>(nsrc.base + nsrc.off + 128 * p);
                 if (p == 7) {
 #pragma unroll
-                    for (int e = 8; e < NE; ++e) vin[e] = nsrc[16 * e];
+                    for (int e = 8; e < NE; ++e) vin[e] = *reinterpret_cast<const float2 *>(nsrc.base + nsrc.off + 128 * e);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -836,6 +852,8 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             const unsigned __int128 num = static_cast<unsigned __int128>(1) << (31 + l);
             a.nf_magic = static_cast<uint32_t>((num + d - 1) / d);
             a.nf_shift = l - 1;
+        } else if (static_cast<unsigned long long>(a.batch) * a.ld * 4ull >= (1ull << 32)) {
+            return hipErrorInvalidValue;  // without the reciprocal the kernel addresses a lane's frame by a 32-bit offset from the batch's first sample
         }
     }
     const size_t lds = (static_cast<size_t>(WAVES) * (WAVES > 12 ? 4 * kZStride * 2 : kWaveFloats) + L::kMelW + 16 * a.mel_wpitch + (a.win_floats > 0 ? a.win_floats : 0)) * sizeof(float) + 16;
