@@ -467,6 +467,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
 #pragma unroll
         for (int p = 0; p < 8; ++p) tw2r[p] = s_tw2[p * 16 + j];
     }
+    // column scale of this lane (feature.rs:126-146): column 0 has its own (and none when the frame energy replaces it)
+    const float sc_lane = j == 0 ? (a.dc_elimination ? 0.f : a.dct_scale_0) : a.dct_scale_k;
     if (!SS_PROF2 && a.dbg) stamp(1, __builtin_amdgcn_s_memrealtime());
 #if SS_PROF2
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -796,13 +798,14 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         // ---- scaling + column-0 replacement (feature.rs:126-146) and the store ----
         {
             const unsigned gf = quad * 4 + f;
-            float o = acc * a.dct_scale_k;
-            if (j == 0) {
-                if (a.dc_elimination) {
-                    o = ln_scaled(energy);
-                } else {
-                    o = acc * (t_cur == 0 ? a.dct_scale_00 : a.dct_scale_0);
-                }
+            // (sc_lane: this lane's column scale, a loop invariant; the two special cases of column 0 sit behind a uniform branch each,
+            // so that the default path pays one product and one select)
+            float o = acc * sc_lane;
+            if (a.dc_elimination) {
+                const float le = ln_scaled(energy);
+                o = j == 0 ? le : o;
+            } else if (t_cur == 0 && j == 0) {
+                o = acc * a.dct_scale_00;
             }
             // unconditional, counted store (ss_wave.h): the descriptor covers the quad's valid frames, lanes j >= n_ceps are
             // dropped by its range check -- the next quad's samples are waited for with this store still in flight

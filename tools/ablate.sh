@@ -11,7 +11,7 @@ make -C mfcc-rust_amd/csrc -j8 lab 2>&1 | grep -E "error" || true
 mkdir -p ab
 L=mfcc-rust_amd/lib/lab
 SRC=${SRC:-ss_mfcc512}
-BASE=${BASE--fno-slp-vectorize}
+BASE=${BASE--fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None}
 for kv in "$@"; do
   n=${kv%%=*}; fl=${kv#*=}
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Imfcc-rust_amd/csrc -DSS_LAB=1 $BASE $fl \

@@ -5,7 +5,7 @@ set -e
 R="$(cd "$(dirname "$0")/.." && pwd)"
 F=$1; shift; FLT=${1:-}; [ $# -gt 0 ] && shift
 mkdir -p /tmp/dis
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$R/include" -I"$R/mfcc-rust_amd/csrc" -fno-slp-vectorize "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$R/include" -I"$R/mfcc-rust_amd/csrc" -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" \
   -S --cuda-device-only "$R/mfcc-rust_amd/csrc/$F.hip" -o /tmp/dis/$F.s 2>&1 | grep -v "hip-link" || true
 python3 "$R/tools/vmcnt_audit.py" /tmp/dis/$F.s $FLT | cut -c1-230
 python3 - "$F" "$FLT" <<'PY'
