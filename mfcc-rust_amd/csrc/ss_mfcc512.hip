@@ -280,7 +280,12 @@ __device__ __forceinline__ float mel_slot_taps(const float4 *w4, const float *p)
     float4 w[Q];
     float t[T];
 #pragma unroll
-    for (int i = 0; i < Q; ++i) w[i] = w4[i];
+    for (int i = 0; i < Q; ++i) {
+        w[i] = w4[i];
+        // (whole 16-byte reads: left alone, the compiler narrows the partly used float4s and merges two of them into one
+        // ds_read2_b64, whose four words per lane collide between lanes at the rows' 28-float pitch -- 8 conflict cycles per quad)
+        asm volatile("" : "+v"(w[i].x), "+v"(w[i].y), "+v"(w[i].z), "+v"(w[i].w));
+    }
 #pragma unroll
     for (int i = 0; i < T; ++i) t[i] = p[i];
     float acc = 0.f;
