@@ -17,7 +17,7 @@
 //   * |X|/N for bins 0..128 goes to a P row in LDS (the mel bank ends at bin (F+1)/2, feature.rs:69-70);
 //     all 257 bins feed the frame energy, reduced over the DPP row.
 //   * mel: banded reduction -- each lane owns up to three filters (host-sorted by tap count so the
-//     lock-step loops are short: 16/6/1 taps at the defaults); weights are per-lane rows in LDS read as
+//     lock-step loops are short: 16 / 5 / 1 taps at the defaults, read as 16 / 6 / 2); weights are per-lane rows in LDS read as
 //     ds_read_b128, all fetches of a stage issue back to back before the FMAs (LDS latency under load
 //     is several hundred cycles).  Not MFMA: on gfx950 v_mfma_f32_* shares the FP32 datapath with
 //     the VALU (measured: a VALU wave and an f32-MFMA wave on one SIMD take the SUM of their times),
@@ -30,13 +30,17 @@
 //     48-entry (slot, lane)-ordered ln(mel) row against the lane's cosine row in LDS (pitch 52 floats: conflict-free).
 //   * Output stores are counted stores (ss_wave.h): unconditional buffer stores whose descriptor drops what must not be written,
 //     so that the wait for the next quad's prefetched samples leaves them in flight (vmcnt(1) / (4) / (17) instead of vmcnt(0)).
-//   * What bounds it (round 4, DESIGN.md 4 / 5, profiles/r04/): 623 -> 619 VALU and 73 -> 66 LDS instructions per quad; a SIMD
-//     issues one VALU instruction per 2.14 cycles when two of its waves have one ready, and the launch runs at 0.54 of that
-//     floor (61 k shader cycles per 1024-clip launch; waves 20 % in s_waitcnt, 27 % stalled at issue, 11 % on the LDS queue; LDS
-//     array half busy, no bank conflicts).  The part trades clock for issue density: 8 .. 12 waves per CU all take 30.1 +- 0.5 us
-//     while the clock falls from 2.37 to 2.01 GHz (profiles/r04/ab_cfg2_waves_per_cu.txt).  The code is written for instruction
-//     count: twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2 twiddles in registers (RES bit 1), ln on values
-//     pre-scaled by 2^32, scalar frame -> (clip, t) division, conflict-free LDS accesses throughout.
+//   * What bounds it (round 4, DESIGN.md 4 / 5, profiles/r04/): the launch runs at the board's 1400 W power cap (1320-1360 W on random
+//     samples, shader clock 2.0-2.25 of 2.4 GHz; all-zero samples: 1.0 kW at 2.4 GHz and the 59 k cycles the kernel needs), so time is
+//     energy per launch over the cap: 8 .. 12 waves per CU all take 30.1 +- 0.5 us while the clock falls from 2.37 to 2.01 GHz
+//     (profiles/r04/power_probe.txt, ab_cfg2_waves_per_cu.txt), and what shortens a launch is fewer instructions per frame.  Round 4:
+//     623 -> 601 executed VALU and 73 -> 65 LDS instructions per quad (paired DCT layout; tight mel taps: the host places the filters
+//     of slots 1 / 2 inside 6 / 2 taps and only those are read; sample loads with a scalar base and a 32-bit lane offset -- no 64-bit
+//     address arithmetic or quarter-rate multiplies on the VALU; no aggregation scaffold around the work counter's atomic).  A SIMD
+//     issues one VALU instruction per 2.14 cycles when two of its waves have one ready, and the launch runs at 0.52-0.54 of that
+//     floor (waves 20 % in s_waitcnt, 27 % stalled at issue, 11 % on the LDS queue; LDS array half busy, no bank conflicts).
+//     Also written for instruction count: twiddle magnitudes folded into butterfly FMAs (ss_fft_reg.h), pass-2 twiddles in
+//     registers (RES bit 1), ln on values pre-scaled by 2^32, conflict-free LDS accesses throughout.
 //   * Builds (template OUTK / FRONT): MFCC; mfe's (features, energy); power_spectrum rows; each optionally with a
 //     frame window and fused pre-emphasis on load.
 //   * HBM traffic: samples once (the 50 % frame overlap is served by L1/L2), n_ceps floats per frame out.
