@@ -380,7 +380,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         const unsigned unit = ROWS4 ? 2 * item + sub : item;
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
-        const int lane = lane_it;
+        const int lane = lane_it & 63;     // (the mask tells the compiler the range again: 24-bit multiplies, no sign extensions)
         const int half = lane >> 5;  // frame within the wave
         const int j = lane & 31;     // lane within the frame
         float *wbase = reinterpret_cast<float *>(smem) + wave * kWaveFloatsM;

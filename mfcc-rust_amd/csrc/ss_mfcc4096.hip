@@ -97,6 +97,7 @@ constexpr bool kDbgStages = false;        // true: SS_DEBUG_ROWS also dumps fram
 constexpr int kFRowOff = L::kPRow;        // ln(mel) row [256] behind the P row (both inside the exchange region)
 constexpr int kSRowOff = kFRowOff + 256;  // s and d rows of the symmetric DCT (4 segments of 64 + 4 floats), behind the ln(mel) row
 constexpr int kSegPitch = 68;
+constexpr int kMelPitch8321 = 60;  // floats per lane row of mel weights for the 8 / 3 / 2 / 1 bank (14 float4s + 1: odd pitch in 16-byte units)
 
 
 template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false, bool FIXMEL = false>
@@ -177,10 +178,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // (~40 integer instructions per frame) instead of occupying ~40 of the 168 registers for the whole kernel.
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         if (LEAN) asm volatile("" : "+v"(lane_it));
-        const int lane = lane_it;
+        const int lane = lane_it & 63;  // (the mask tells the compiler the range again: 24-bit multiplies, no sign extensions)
         const int k1 = lane & 31, d = lane >> 5;   // reader view: column k1, half a = d
         const int cls = lane & 1, bw = lane >> 1;  // writer view: n1 = lane = cls + 2 bw
-        const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * a.mel_wpitch);
+        // (FIXMEL: the 8 / 3 / 2 / 1 bank's rows are 15 float4s apart -- checked by the launcher -- so the lane's row is two shifts,
+        // not a quarter-rate multiply each time the compiler derives it again)
+        const float4 *w4 = reinterpret_cast<const float4 *>(s_melw + lane * (FIXMEL ? kMelPitch8321 : static_cast<int>(a.mel_wpitch)));
         const int paddr = ((((32 - k1) & 31) | ((1 - d) << 5))) << 2;  // lane holding Z[2048 - k]
         float2 *exw = ex + cls * kClsStride + 34 * (bw >> 1) + (bw & 1);  // writer base (float2 units)
         const float2 *exr = ex + d * kClsStride + 2 * (k1 & 15);        // reader base
@@ -857,7 +860,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         // only the default cfg5 shape (exact frames, magnitude spectrum, 8/3/2/1 bank, twice-folded DCT, no window / mfe) has a
         // 12-wave build
         const bool lean_ok = exact && !pow2 && !a.window && !a.out_mfe && a.dct_fold2 && a.mel_q4[0] == 8 && a.mel_q4[1] == 3 &&
-                             a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+                             a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321;
         if (!lean_ok) return hipErrorInvalidValue;
         return go(ss_mfcc_c2048<true, false, 12, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321,w12>");
     } else {
@@ -883,7 +886,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES, true>, "ss_mfcc_c2048<exact,pow2,mfe>") : go(ss_mfcc_c2048<true, false, WAVES, true>, "ss_mfcc_c2048<exact,mfe>");
         return pow2 ? go(ss_mfcc_c2048<false, true, WAVES, true>, "ss_mfcc_c2048<pow2,mfe>") : go(ss_mfcc_c2048<false, false, WAVES, true>, "ss_mfcc_c2048<mfe>");
     }
-    const bool m8321 = a.mel_q4[0] == 8 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+    const bool m8321 = a.mel_q4[0] == 8 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321;
     if (exact && m8321 && !pow2 && a.dct_fold2) return go(ss_mfcc_c2048<true, false, WAVES, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321>");
     if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
     return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
