@@ -431,6 +431,59 @@ static void place_taps_b128(int lanes, const std::vector<int32_t> &lo4, const st
     }
 }
 
+// Re-deals the filters over the slots before they are placed (place_taps_b128 works slot by slot).  `order` deals the filters
+// by span, longest first, `lanes` per slot, and the slots' spans (q4) follow from that; but short filters cluster at the low
+// bins, and a slot can only take `lanes / 16` filters per float4 residue without a bank conflict (cfg3: seven of the 32
+// shortest filters could not be matched).  A short filter also fits a longer slot, so one matching over the cells of ALL slots
+// -- filter m may take cell (slot s, group g, residue r) if its span fits slot s and a start with that residue is admissible
+// there -- finds a deal in which every slot can be placed conflict-free, where one exists.  Only for banks that fill every slot
+// (the per-slot loops take `lanes` consecutive entries of `order`); `order` is left alone when no complete matching exists.
+static void balance_slots(const HostTables &t, int lanes, int nslots, const int32_t *q4, int32_t kRow, std::vector<int32_t> &order)
+{
+    const int M = static_cast<int>(order.size());
+    if (M != lanes * nslots) return;
+    const int groups = lanes / 16, cells = nslots * lanes;
+    std::vector<int> owner(cells, -1);  // cell = slot * lanes + group * 16 + residue -> filter
+    std::vector<int> cell_of(M, -1), home(M, 0);
+    for (int q = 0; q < M; ++q) home[order[q]] = q / lanes;
+    auto window = [&](int m, int s, int32_t &lo, int32_t &hi) {
+        const int32_t span = 4 * q4[s], len = t.bank.len[m], st = len ? t.bank.start[m] : 0;
+        if (span == 0) return false;
+        hi = len ? std::min(st, kRow - span) / 4 : (kRow - span) / 4;
+        lo = std::max<int32_t>(0, st + len - span + 3) / 4;
+        if (lo > hi && s == home[m]) lo = hi;  // (in the slot the sorted deal gave it the per-slot placement accepts it this way)
+        return lo <= hi;
+    };
+    std::function<bool(int, std::vector<char> &)> place = [&](int m, std::vector<char> &seen) -> bool {
+        for (int s = nslots - 1; s >= 0; --s) {  // the shortest slot that takes it first
+            int32_t lo, hi;
+            if (!window(m, s, lo, hi)) continue;
+            for (int32_t b = hi; b >= lo && b > hi - 16; --b)
+                for (int g = 0; g < groups; ++g) {
+                    const int c = s * lanes + g * 16 + (b & 15);
+                    if (seen[c]) continue;
+                    seen[c] = 1;
+                    if (owner[c] < 0 || place(owner[c], seen)) {
+                        owner[c] = m;
+                        cell_of[m] = c;
+                        return true;
+                    }
+                }
+        }
+        return false;
+    };
+    for (int q = 0; q < M; ++q) {
+        std::vector<char> seen(cells, 0);
+        if (!place(order[q], seen)) return;  // no complete matching: the sorted deal stays
+    }
+    std::vector<int32_t> dealt;
+    dealt.reserve(M);
+    for (int s = 0; s < nslots; ++s)
+        for (int q = 0; q < M; ++q)
+            if (cell_of[order[q]] / lanes == s) dealt.push_back(order[q]);
+    order = dealt;
+}
+
 void build_fast512(const HostTables &t, Fast512Tables &f)
 {
     namespace L = fast512_layout;
@@ -797,6 +850,7 @@ static void build_mel2048_bank(const HostTables &t, Mel2048Tables &f)
     int32_t maxlen[4] = {0, 0, 0, 0};
     for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], alen(order[q]));
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    balance_slots(t, 32, 4, f.q4, kRow, order);  // (the slots keep their spans; see balance_slots)
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
     if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the lanes' ds_read_b128 of their rows spread over all banks
@@ -901,6 +955,7 @@ static void build_1024(const HostTables &t, Mfcc1024Tables &f, bool mel)
     int32_t maxlen[4] = {0, 0, 0, 0};
     for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], alen(order[q]));
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    balance_slots(t, 32, 4, f.q4, kRow, order);  // (the slots keep their spans; see balance_slots)
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
     if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: conflict-free ds_read_b128 of the lanes' rows
@@ -994,6 +1049,7 @@ void build_mfcc2048(const HostTables &t, Mfcc2048Tables &f)
     int32_t maxlen[4] = {0, 0, 0, 0};
     for (size_t q = 0; q < M; ++q) maxlen[q / 32] = std::max(maxlen[q / 32], alen(order[q]));
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    balance_slots(t, 32, 4, f.q4, kRow, order);  // (the slots keep their spans; see balance_slots)
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
     if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: conflict-free ds_read_b128 of the lanes' rows
@@ -1072,6 +1128,7 @@ static void build_4096(const HostTables &t, Mfcc4096Tables &f, bool mel)
     int32_t maxlen[4] = {0, 0, 0, 0};
     for (size_t q = 0; q < M; ++q) maxlen[q / 64] = std::max(maxlen[q / 64], alen(order[q]));
     for (int s = 0; s < 4; ++s) f.q4[s] = (maxlen[s] + 3) / 4;
+    balance_slots(t, 64, 4, f.q4, kRow, order);  // (the slots keep their spans; see balance_slots)
     f.wpitch = 4 * (f.q4[0] + f.q4[1] + f.q4[2] + f.q4[3]);
     if (f.wpitch == 0) f.wpitch = 4;
     if ((f.wpitch / 4) % 2 == 0) f.wpitch += 4;  // odd pitch in 16-byte units: the lanes' ds_read_b128 of their rows spread over all banks
