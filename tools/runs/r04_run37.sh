@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04
+SS_LIB_PATH=$PWD/ab/lib_prof5.so python tools/prof5.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04/phase_profile_cfg5.txt
+SS_LIB_PATH=$PWD/ab/lib_prof2.so python tools/prof2.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04/phase_profile_cfg2.txt
