@@ -415,8 +415,10 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 const long long start0 = static_cast<long long>((unit_s - clip_s * pairs) * 2 + a.n_pad + 1) * static_cast<long long>(a.hop) - 2048;
                 const char *sb = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>(clip_s) * a.ld) + start0 * 4;
                 const unsigned so = static_cast<unsigned>(half) * a.hop * 4u + static_cast<unsigned>(j) * 8u;
+                unsigned so2[2] = {so, so + 4096u};  // (a 32-bit lane offset per 4096 bytes, pinned: left alone the second half's addresses become 64-bit VALU sums)
+                asm volatile("" : "+v"(so2[1]));
 #pragma unroll
-                for (int e = 0; e < 32; ++e) v[e] = *reinterpret_cast<const float2 *>(sb + so + 256u * e);
+                for (int e = 0; e < 32; ++e) v[e] = *reinterpret_cast<const float2 *>(sb + so2[e / 16] + 256u * (e % 16));
 #endif
             } else {
                 // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows: see ss_mel_c1024

@@ -203,6 +203,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         const char *src_b = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step);
         const unsigned src_o = static_cast<unsigned>(lane) * 8u;
         const float2 *src = reinterpret_cast<const float2 *>(src_b + src_o);
+        unsigned src_o4[4] = {src_o, src_o + 4096u, src_o + 8192u, src_o + 12288u};
+        asm volatile("" : "+v"(src_o4[1]), "+v"(src_o4[2]), "+v"(src_o4[3]));  // (kept as 32-bit offsets: left alone they become 64-bit VALU address sums)
         float2 v[32];
         if (PF) {
 #pragma unroll
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
                 v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(frame & 255u));
                 continue;
             }
-            if (EXACT) v[e] = *reinterpret_cast<const float2 *>(src_b + src_o + 512u * e);
+            if (EXACT) v[e] = *reinterpret_cast<const float2 *>(src_b + src_o4[e / 8] + 512u * (e % 8));  // (a 32-bit lane offset per 4096 bytes: the rest fits the instruction)
             else {  // zero pad, processing.rs:147-156; an odd frame length ends in a half pair
                 const int rem = static_cast<int>(a.flen) - 2 * (lane + 64 * e);
                 v[e] = rem >= 2 ? src[64 * e] : make_float2(rem == 1 ? reinterpret_cast<const float *>(src)[128 * e] : 0.f, 0.f);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
 #pragma unroll
         for (int s = 0; s < 4; ++s) sf[s] = s_start[s * 64 + lane];
         auto st = [&](int s) { return sf[s] & 0xffff; };
-        auto fi = [&](int s) { return sf[s] >> 16; };
+        auto fi = [&](int s) { return FIXMEL ? static_cast<int>(static_cast<unsigned>(sf[s]) >> 16) : sf[s] >> 16; };  // (FIXMEL: never negative)
         // (LEAN: two batches of eight bin pairs, each with its own twiddle and partner fetches)
         constexpr int kUb = LEAN ? 8 : 16;
         if (lane < 3 && !LEAN) prow[1025 + lane] = 0.f;  // pad bins read (with zero weight) by the mel stage
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
             for (int s = 0; s < 4; ++s) {
                 float m = hscale32 * (fixed8321 ? mfix[s] : mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st(s)), a.mel_q4[s]));
                 m = m == 0.f ? kEps * kTwo32 : m;
-                if (fi(s) >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none
+                if (FIXMEL || fi(s) >= 0) {  // fewer than 256 filters: some (slot, lane) pairs own none (FIXMEL: 256 filters, checked by the launcher)
                     if (MFE) a.out[static_cast<unsigned long long>(frame) * a.n_filters + fi(s)] = m * (1.0f / kTwo32);  // exact: power of two
                     else frow[fi(s)] = ln_scaled(m);
                 }
@@ -860,7 +862,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         // only the default cfg5 shape (exact frames, magnitude spectrum, 8/3/2/1 bank, twice-folded DCT, no window / mfe) has a
         // 12-wave build
         const bool lean_ok = exact && !pow2 && !a.window && !a.out_mfe && a.dct_fold2 && a.mel_q4[0] == 8 && a.mel_q4[1] == 3 &&
-                             a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321;
+                             a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321 && a.n_filters == 256;
         if (!lean_ok) return hipErrorInvalidValue;
         return go(ss_mfcc_c2048<true, false, 12, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321,w12>");
     } else {
@@ -886,7 +888,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
         if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES, true>, "ss_mfcc_c2048<exact,pow2,mfe>") : go(ss_mfcc_c2048<true, false, WAVES, true>, "ss_mfcc_c2048<exact,mfe>");
         return pow2 ? go(ss_mfcc_c2048<false, true, WAVES, true>, "ss_mfcc_c2048<pow2,mfe>") : go(ss_mfcc_c2048<false, false, WAVES, true>, "ss_mfcc_c2048<mfe>");
     }
-    const bool m8321 = a.mel_q4[0] == 8 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321;
+    const bool m8321 = a.mel_q4[0] == 8 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321 && a.n_filters == 256;
     if (exact && m8321 && !pow2 && a.dct_fold2) return go(ss_mfcc_c2048<true, false, WAVES, false, false, false, true>, "ss_mfcc_c2048<exact,mel8321>");
     if (exact) return pow2 ? go(ss_mfcc_c2048<true, true, WAVES>, "ss_mfcc_c2048<exact,pow2>") : go(ss_mfcc_c2048<true, false, WAVES>, "ss_mfcc_c2048<exact>");
     return pow2 ? go(ss_mfcc_c2048<false, true, WAVES>, "ss_mfcc_c2048<pow2>") : go(ss_mfcc_c2048<false, false, WAVES>, "ss_mfcc_c2048");
