@@ -23,6 +23,11 @@ own time and the per-link rate it reached, so the line says how much of the step
 cfg4 (the 100 h corpus, 360 000 clips) is the one strong-scaling workload: the corpus is split into
 contiguous clip shards (speechsauce_amd.distributed.shard_bounds), one launch per shard per step.
 
+A default N = 1 run (headline workload, no measurement switches) also times, after the headline region and outside it, the other
+BASELINE configurations -- `secondary.cfg3`, `secondary.cfg5` (200 steps each) and `secondary.cfg4` (the whole 360 000-clip corpus
+in one launch, 5 steps) -- and the headline workload once more with successive steps alternating over two HIP streams
+(`value_pipelined`: one launch's tail under the next one's head; whole-job throughput, not a kernel duration and no part of `roofline`).
+
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (4 B per input
 sample + 4 B per output element) / average launch duration measured with HIP events
 on the launch stream over the timed (path-only when N > 1) region.  `cpu_baseline` = the oracle's
@@ -121,6 +126,29 @@ class BoardProbe:
                 "samples": len(tail), "when": "second half of the untimed pre-roll of the same launches (hwmon, 10 ms period)"}
 
 
+def timed_port(kind, p, probe_clip):
+    """The port function bench.py times: the build for THIS host (oracle/Makefile `native`: -O3 -march=native, no fast-math, no FMA
+    contraction -- compiled here, now, by gcc), checked against the f64 checker on one clip before it is timed; the portable -O2
+    build of libss_oracle.so when the native build is not possible.  Returns (callable, flags text)."""
+    import functools
+
+    import numpy as np
+
+    import oracle_c
+
+    base = oracle_c.port_mfcc if kind == "mfcc" else oracle_c.port_mel_spectrogram
+    nat, flags = oracle_c.native_port()
+    if nat is None:
+        return base, f"portable build (gcc -O2 -ffp-contract=off; {flags})"
+    fn = functools.partial(base, from_lib=nat)
+    want = (oracle_c.mfcc if kind == "mfcc" else oracle_c.mel_spectrogram)(p, probe_clip)
+    got = fn(p, probe_clip)
+    err = float(np.abs(got - want).max() / np.abs(want).max())
+    if not err <= 1e-4:
+        raise SystemExit(f"bench.py: the native CPU port disagrees with the checker (rel err {err}): not timing it")
+    return fn, flags + f"; checked against the f64 oracle on one clip first (rel err {err:.1e})"
+
+
 def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
     """Time the oracle's reference-shaped f32 port, single thread, on fresh clips until ~budget_s."""
     import numpy as np
@@ -129,9 +157,9 @@ def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
 
     p = oracle_c.make_params(**pkw)
     rng = np.random.default_rng(1234)
-    fn = oracle_c.port_mfcc if kind == "mfcc" else oracle_c.port_mel_spectrogram
     rows_per_clip = oracle_c.num_frames(p, n_samples) if kind == "mfcc" else oracle_c.stft_rows(p, n_samples)[0]
     pool = (rng.standard_normal((64, n_samples)) * 0.1).astype(np.float32)
+    fn, flags = timed_port(kind, p, pool[0])
     fn(p, pool[0])  # warm
     clips, t0 = 0, time.perf_counter()
     while True:
@@ -145,9 +173,11 @@ def cpu_baseline(kind, pkw, n_samples, budget_s=12.0):
         "unit": "frames/s",
         "cores": 1,
         "kind": "port",
-        "note": "lower bound on the Rust crate: a textbook radix-2 FFT with a per-call plan where rustfft picks SIMD mixed-radix plans",
+        "note": "lower bound on the Rust crate: a textbook radix-2 FFT with a per-call plan where rustfft picks SIMD mixed-radix plans; "
+                "build flags: " + flags,
         "sample": f"{clips} x {n_samples}-sample clips ({clips * rows_per_clip} frames) in {el:.1f} s, single thread, "
-                  f"oracle/ss_oracle.c port_{'mfcc' if kind == 'mfcc' else 'mel_spectrogram'}_f32; host has {os.cpu_count()} logical cores",
+                  f"oracle/ss_oracle.c port_{'mfcc' if kind == 'mfcc' else 'mel_spectrogram'}_f32 built with [{flags.split(';')[0]}]; "
+                  f"host has {os.cpu_count()} logical cores",
     }
 
 
@@ -161,10 +191,10 @@ def cpu_baseline_all_cores(kind, pkw, n_samples, budget_s=6.0):
     import oracle_c
 
     p = oracle_c.make_params(**pkw)
-    fn = oracle_c.port_mfcc if kind == "mfcc" else oracle_c.port_mel_spectrogram
     rows_per_clip = oracle_c.num_frames(p, n_samples) if kind == "mfcc" else oracle_c.stft_rows(p, n_samples)[0]
     cores = os.cpu_count() or 1
     pool = (np.random.default_rng(4321).standard_normal((16, n_samples)) * 0.1).astype(np.float32)
+    fn, _ = timed_port(kind, p, pool[0])
     fn(p, pool[0])
     counts = [0] * cores
     stop = time.perf_counter() + budget_s
@@ -215,6 +245,130 @@ def load_profile(kernel_name, workload, headline):
     return out
 
 
+def load_pmc(workload):
+    """Stored PMC entry of a workload (profiles/pmc_traffic.json) or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
+
+
+def probe_clock(torch, lib, step, avg_s, device, probe_us=2000):
+    """Shader clock (GHz) the device holds while `step` launches run: enough launches for ~3 probe lengths go out on the launch
+    stream, then the library's one-wave probe (ss_shader_clock_probe: s_memtime against the 100 MHz s_memrealtime, asleep in
+    between) runs on a side stream beside them.  Outside every timed region.  None when the probe fails."""
+    side = torch.cuda.Stream(device=device)
+    n = max(8, int(3 * probe_us * 1e-6 / max(avg_s, 1e-6)))
+    for i in range(n // 4):  # the probe starts once the load is established
+        step(i)
+    g = C.c_float(0.0)
+    for i in range(n - n // 4):
+        step(i)
+    rc = lib.ss_shader_clock_probe(C.c_void_p(side.cuda_stream), int(probe_us), C.byref(g))
+    torch.cuda.synchronize()
+    return float(g.value) if rc == 0 and g.value > 0 else None
+
+
+def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=300.0, streams=1, probe_board=True, ring_mib=300):
+    """One N = 1 measurement of a BASELINE configuration outside the headline region: `steps` launches of the hot path over batches
+    resident in HBM (rotated over > 256 MiB of distinct inputs, like the headline), HIP events on the launch stream around them,
+    wall clock between synchronize pairs.  streams > 1: successive steps alternate over that many streams (independent batches in
+    flight), so the per-step figure is wall time, not a kernel duration."""
+    from speechsauce_amd import SpeechConfig, _lib, make_params
+
+    lib = _lib.lib()
+    desc, pkw, n_samples, clips, kind = WORKLOADS[workload]
+    cfg = SpeechConfig(make_params(**pkw))
+    if kind == "mfcc":
+        rows = cfg.num_frames(n_samples)
+        out_shape = (clips, rows, cfg.params.num_cepstral)
+    else:
+        rows, _ = cfg.stft_rows(n_samples)
+        out_shape = (clips, cfg.params.num_filters, rows)
+    out_elems = out_shape[0] * out_shape[1] * out_shape[2]
+    bytes_per_launch = 4 * clips * n_samples + 4 * out_elems
+    big = 4 * clips * n_samples > ring_mib * 2**20  # cfg4: one 23 GB batch is its own ring
+    n_buf = 1 if big else max(2, -(-ring_mib * 2**20 // (4 * clips * n_samples)))
+    xs = [synth_batch(torch, clips, n_samples, 7001 + i, device) for i in range(n_buf)]
+    main = torch.cuda.current_stream()
+    sts = [main] + [torch.cuda.Stream(device=device) for _ in range(max(0, streams - 1))]
+    sptrs = [C.c_void_p(st.cuda_stream) for st in sts]
+    outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(1 if big else max(2, 2 * streams))]
+    fn = lib.ss_mfcc_batch_device if kind == "mfcc" else lib.ss_mel_spectrogram_device
+
+    def step(i):
+        rc = fn(cfg.handle, xs[i % n_buf].data_ptr(), clips, n_samples, n_samples, outs[i % len(outs)].data_ptr(), sptrs[i % len(sptrs)])
+        if rc:
+            _lib.check(rc)
+
+    board = None
+    if prewarm_ms > 0:
+        probe = BoardProbe(torch, device) if probe_board else None
+        t_end = time.perf_counter() + prewarm_ms * 1e-3
+        k = 0
+        while True:
+            for _ in range(1 if big else 50):
+                step(k)
+                k += 1
+            torch.cuda.synchronize()
+            if time.perf_counter() >= t_end:
+                break
+        if probe:
+            board = probe.stop()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    for st in sts[1:]:  # the other streams start behind the start event
+        st.wait_event(e0)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    for st in sts[1:]:
+        ev = torch.cuda.Event()
+        ev.record(st)
+        main.wait_event(ev)
+    e1.record(main)
+    while not e1.query():
+        pass
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_s = e0.elapsed_time(e1) * 1e-3
+    kernel = lib.ss_last_kernel_name().decode()
+    avg = dev_s / steps
+    clock_ghz = probe_clock(torch, lib, step, avg, device) if streams == 1 else None
+    del xs, outs
+    torch.cuda.empty_cache()
+    res = {
+        "workload": desc, "kernel": kernel, "steps": steps, "warmup": warmup, "streams": streams,
+        "metric": "mfcc_frames_per_sec" if kind == "mfcc" else "mel_rows_per_sec",
+        "value": clips * rows * steps / elapsed, "ms_per_step": elapsed * 1e3 / steps,
+        "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
+        "achieved": bytes_per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS,
+        "frames_per_launch": clips * rows,
+    }
+    e = load_pmc(workload)
+    if e and kernel.split("<")[0] in e.get("kernel_full", ""):
+        res["traffic"] = e.get("hbm_bytes_per_launch")
+        res["traffic_source"] = f"profiles/pmc_traffic.json (stored, {e.get('profiled', '?')}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
+        if e.get("valu_insts_per_launch"):
+            res["valu_insts_per_launch"] = e["valu_insts_per_launch"]
+    else:
+        res["traffic"] = None
+    if board:
+        res["board"] = board
+    if clock_ghz:
+        # shader cycles per launch at the clock a probe wave read beside these same launches right after the timed ones (the hwmon
+        # figure in `board` reads up to 10 % higher): the figure to compare across boxes that hold different clocks at the power cap
+        res["clock_ghz_measured"] = clock_ghz
+        res["cycles_per_launch"] = avg * 1e9 * clock_ghz
+        if res.get("valu_insts_per_launch"):
+            res["valu_floor_frac"] = res["valu_insts_per_launch"] / 1024.0 * 2.14 / res["cycles_per_launch"]
+    return res
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE set) and
     relay rank 0's JSON line.  Runs before this process imports torch or touches the GPU; nothing is re-exec'd."""
@@ -260,7 +414,14 @@ def main():
     ap.add_argument("--params", default="", help='JSON dict of extra ss_params switches, e.g. \'{"mfcc_window": 1, "preemph_coef": 0.97}\' (not the headline config)')
     ap.add_argument("--kind", default="", choices=["", "mfcc", "mel"], help="run the workload's clips through the other path (mfcc / mel_spectrogram); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="single-thread CPU baseline budget (the all-cores run takes half of it)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg5 / cfg4 lines and value_pipelined that a default N = 1 run appends")
+    ap.add_argument("--corpus-clips", type=int, default=0, help="cfg4: size of the corpus that is split over the ranks (default 360 000); keeps strong scaling, unlike --clips")
+    ap.add_argument("--gather-chunks", type=int, default=8, help="cfg4 with a gather: a rank's shard is computed and gathered in this many chunks, "
+                    "chunk i's collective under chunk i+1's kernel")
+    ap.add_argument("--ring-mib", type=int, default=300, help="size of the rotated input ring (measurement aid: below 256 MiB the Infinity Cache serves the input)")
+    ap.add_argument("--one-device", action="store_true", help="test aid: every rank uses device 0 (gloo instead of RCCL; control flow only)")
+    ap.add_argument("--link-gbps", type=float, default=64.0, help="one-way xGMI rate per link assumed by scaling_model (unmeasured here)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -280,8 +441,8 @@ def main():
     n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
     if n_dev == 0:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    shared_device = world > n_dev or bool(os.environ.get("SS_BENCH_ONE_DEVICE"))  # several ranks per GPU: control-flow check only
-    local_rank = 0 if os.environ.get("SS_BENCH_ONE_DEVICE") else local_rank % n_dev
+    shared_device = world > n_dev or args.one_device  # several ranks per GPU: control-flow check only
+    local_rank = 0 if args.one_device else local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = None
@@ -310,15 +471,21 @@ def main():
     if args.kind and args.kind != kind:
         kind = args.kind
         desc += " through the " + ("mel_spectrogram" if kind == "mel" else "mfcc") + " path"
-    strong = args.workload == "cfg4"
+    strong = args.workload == "cfg4" and not args.clips
+    corpus = shard_max = None
     if args.clips:
         clips = args.clips
     elif strong:  # fixed corpus: this rank's contiguous shard
-        from speechsauce_amd.distributed import shard_bounds
+        from speechsauce_amd.distributed import shard_bounds, shard_sizes
 
-        lo, hi = shard_bounds(clips, world, rank)
+        corpus = args.corpus_clips or clips
+        desc = desc.replace("360 000", f"{corpus:,}".replace(",", " ")) if args.corpus_clips else desc
+        lo, hi = shard_bounds(corpus, world, rank)
         clips = hi - lo
-    if args.force_generic or os.environ.get("SS_FORCE_GENERIC"):  # (the env spelling keeps the tools/*_rate.sh scripts working)
+        shard_max = max(shard_sizes(corpus, world))
+        if clips == 0:
+            raise SystemExit("bench.py: --corpus-clips is smaller than the number of ranks")
+    if args.force_generic:
         # a process-wide kernel-selection override: a test aid of the LAB library (include/speechsauce_amd_debug.h), so this
         # measurement aid runs the whole bench on that build
         _lib._lib = _lib.lab()
@@ -337,7 +504,7 @@ def main():
     frames_per_launch = clips * rows
 
     # distinct input batches totalling > 256 MiB so the Infinity Cache cannot hold the stream
-    ring_mib = int(os.environ.get("SS_BENCH_RING_MIB", "300"))  # (measurement aid: size of the rotated input ring)
+    ring_mib = args.ring_mib
     n_buf = max(1 if strong else 2, -(-ring_mib * 1024 * 1024 // (4 * clips * n_samples)))
     xs = [synth_batch(torch, clips, n_samples, 1 + rank * 100 + i, device) for i in range(n_buf)]
     stream = torch.cuda.current_stream()
@@ -351,13 +518,26 @@ def main():
     # [world, G, ...] (on rank 0, or on every rank) on a side stream while the following steps compute into the other bucket.
     from speechsauce_amd.distributed import all_gather_into, gather_into
 
-    G = 1 if strong else max(1, args.gather_every)  # a corpus shard's block is already a large message
-    buckets = gathered = comm_stream = None
+    # cfg4 (strong): a rank's shard is computed AND gathered in CH chunks -- chunk c's collective runs on the side stream under chunk
+    # c+1's kernel, so only the last chunk's transfer is exposed (one block of 229 MB per rank at N = 8 would take ~3 ms over a link
+    # after 1.1 ms of compute).  Shards are padded to the largest one for the collective (360 000 divides evenly by 1, 2, 4, 8).
+    G = 1 if strong else max(1, args.gather_every)
+    CH = max(1, min(args.gather_chunks, shard_max)) if strong else 1
+    buckets = gathered = comm_stream = chunk_bounds = None
     if do_gather:
-        buckets = [torch.empty((G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
-        if gather_mode == "all" or rank == 0:
-            gathered = [torch.empty((world * G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
+        if strong:
+            from speechsauce_amd.distributed import shard_bounds as _sb
+
+            chunk_bounds = [_sb(shard_max, CH, c) for c in range(CH)]
+            buckets = [torch.empty((shard_max,) + out_shape[1:], dtype=torch.float32, device=device) for _ in range(2)]
+            if gather_mode == "all" or rank == 0:
+                gathered = [torch.empty((world, shard_max) + out_shape[1:], dtype=torch.float32, device=device) for _ in range(2)]
+        else:
+            buckets = [torch.empty((G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
+            if gather_mode == "all" or rank == 0:
+                gathered = [torch.empty((world * G,) + out_shape, dtype=torch.float32, device=device) for _ in range(2)]
         comm_stream = torch.cuda.Stream(device=device)
+    row_elems = out_shape[1] * out_shape[2]
 
     class Region:
         """One timed (or warm-up) sequence of steps; with_gather routes the outputs through the buckets and the collective."""
@@ -377,7 +557,7 @@ def main():
 
         def after_step(self, i, last):
             """Launch the gather of a bucket once its last step has been issued."""
-            if not self.g or not ((i + 1) % G == 0 or last):
+            if not self.g or strong or not ((i + 1) % G == 0 or last):
                 return
             b = (i // G) % 2
             n = i % G + 1  # filled slots (a run's last bucket may be partial: only what was computed is gathered)
@@ -395,7 +575,41 @@ def main():
             self.comm_events.append((c0, c1, n))
             self.bucket_done[b] = c1
 
+        def launch(self, x_ptr, n, o_ptr, sp):
+            fn = lib.ss_mfcc_batch_device if kind == "mfcc" else lib.ss_mel_spectrogram_device
+            rc = fn(cfg.handle, x_ptr, n, n_samples, n_samples, o_ptr, sp)
+            if rc:
+                _lib.check(rc)
+
+        def step_chunked(self, i):
+            """cfg4 with a gather: the shard in CH chunks, each chunk's gather issued right behind its kernel."""
+            b = i % 2
+            x = xs[i % n_buf]
+            if self.bucket_done[b] is not None:  # the bucket's previous gathers must have read it
+                stream.wait_event(self.bucket_done[b])
+            for c0, c1 in chunk_bounds:
+                n = min(c1, clips) - c0  # a shorter shard computes what it has and sends the padded chunk
+                if n > 0:
+                    self.launch(x.data_ptr() + 4 * c0 * n_samples, n, buckets[b].data_ptr() + 4 * c0 * row_elems, sptr)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ev)
+                    e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e_a.record(comm_stream)
+                    parts = [gathered[b][r, c0:c1] for r in range(world)] if gathered is not None else None
+                    if gather_mode == "all":
+                        all_gather_into(None, buckets[b][c0:c1], parts=parts)
+                    else:
+                        gather_into(None, buckets[b][c0:c1], dst=0, parts=parts)
+                    e_b.record(comm_stream)
+                self.comm_events.append((e_a, e_b, 1.0 / CH))
+                self.bucket_done[b] = e_b
+            return buckets[b]
+
         def step(self, i):
+            if self.g and strong:
+                return self.step_chunked(i)
             x, o, sp = xs[i % n_buf], self.out_for(i), sptrs[i % len(sptrs)]
             if kind == "mfcc":
                 rc = lib.ss_mfcc_batch_device(cfg.handle, x.data_ptr(), clips, n_samples, n_samples, o.data_ptr(), sp)
@@ -489,7 +703,7 @@ def main():
 
     if rank == 0:
         kernel = lib.ss_last_kernel_name().decode()
-        total_frames = frames_per_launch * args.steps * world  # equal shards (360 000 divides by 1, 2, 4, 8)
+        total_frames = (corpus * rows if strong else frames_per_launch * world) * args.steps  # strong: the corpus once per step, whatever the shard sizes
         value = total_frames / elapsed
         avg_launch_s = dev_ms * 1e-3 / args.steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
@@ -501,6 +715,7 @@ def main():
                 "mode": gather_mode,
                 "collective": "ncclAllGather (all_gather_into_tensor)" if gather_mode == "all" else "grouped ncclSend/ncclRecv to rank 0 (torch.distributed.gather)",
                 "bucket_steps": G,
+                "chunks_per_step": CH,
                 "bytes_per_rank_per_step": 4 * out_elems,
                 "bytes_into_root_per_step" if gather_mode == "root" else "bytes_received_per_rank_per_step": 4 * out_elems * (world - 1),
                 # what one direct link (peer -> root, or peer -> peer in the all-gather) carried per second of the timed region
@@ -519,7 +734,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if strong and not args.clips else "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic N(0,0.1) clips generated on device, resident in HBM; "
@@ -529,7 +744,8 @@ def main():
                 "clips_per_gpu": clips,
                 "samples_per_clip": n_samples,
                 "frames_per_clip": rows,
-                "parallelism": f"clip-sharded x{world}" + (f" + gather of the output blocks ({gather_mode}) over {backend} in buckets of {G} steps, overlapped"
+                "parallelism": f"clip-sharded x{world}" + ((f" + gather of the output blocks ({gather_mode}) over {backend} in "
+                                                               + (f"{CH} chunks per shard" if strong else f"buckets of {G} steps") + ", overlapped")
                                                               if do_gather else ", no collective")
                                + (f", {args.streams} streams" if args.streams > 1 else ""),
             },
@@ -562,6 +778,25 @@ def main():
                          if not (args.params or args.kind) else None),
             },
         }
+        if world > 1:
+            # How to read an N > 1 line (UNMEASURED ON HARDWARE until a SCALE record exists): the path shards with no collective, so
+            # `value_path_only` is N independent runs (efficiency against N x this rank's kernel-only rate: launch gaps + the barrier's
+            # skew); with the gather every rank's features cross ONE direct xGMI link to the root (root mode) or to each peer (all),
+            # and a rank makes features faster than a link carries them -- `value` is bounded by N links x link rate / bytes per frame.
+            out_bytes_per_frame = 4.0 * out_shape[2] if kind == "mfcc" else 4.0 * out_shape[1]
+            kernel_only = frames_per_launch / avg_launch_s
+            res["scaling_model"] = {
+                "path_only_efficiency": res["value_path_only"] / (world * kernel_only) if not strong else res["value_path_only"] / (corpus * rows / avg_launch_s),
+                "path_only_efficiency_against": "N x rank 0's kernel-only frames/s of this run (HIP events)",
+                "feature_bytes_per_frame": out_bytes_per_frame,
+                "features_gbps_per_rank_at_kernel_speed": kernel_only * out_bytes_per_frame / 1e9,
+                "link_gbps_assumed_one_way": args.link_gbps,
+                "gather_bound_frames_per_s": world * args.link_gbps * 1e9 / out_bytes_per_frame,
+                "gather_bound_efficiency": min(1.0, args.link_gbps * 1e9 / out_bytes_per_frame / kernel_only),
+                "value_over_gather_bound": value / (world * args.link_gbps * 1e9 / out_bytes_per_frame),
+                "note": "root mode: (N-1) peers each fill one direct link into rank 0; the bound counts N producers at one link's rate each "
+                        "(rank 0's own block needs no link, so it is slightly pessimistic); unmeasured on hardware",
+            }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kind, pkw, n_samples, args.cpu_seconds)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(kind, pkw, n_samples, args.cpu_seconds / 2)
@@ -570,10 +805,29 @@ def main():
         if clock_ghz is not None:
             rf = res["roofline"]
             rf["clock_ghz_measured"] = clock_ghz
+            # shader cycles per launch: the figure to compare between boxes / rounds (boxes hold 1.9-2.25 GHz at the power cap)
+            rf["cycles_per_launch"] = avg_launch_s * 1e9 * clock_ghz
             if rf.get("valu_insts_per_launch"):
                 # ONE VALU-issue-floor fraction: the kernel's instruction count (2.14 cycles per instruction per SIMD, 1024 SIMDs;
                 # tools/ubench/valu_issue.hip) over THIS run's launch duration at the clock THIS device held in THIS run
                 rf["valu_floor_frac"] = rf["valu_insts_per_launch"] / 1024.0 * 2.14 / (avg_launch_s * 1e9 * clock_ghz)
+        headline = world == 1 and args.workload == "cfg2" and args.streams == 1 and not (
+            args.params or args.kind or args.clips or args.force_generic or args.no_secondary or args.ring_mib != 300)
+        if headline:
+            # the other BASELINE configurations and the pipelined headline, after and outside the headline's timed region
+            del xs[:], outs[:]
+            torch.cuda.empty_cache()
+            pl = measure_simple(torch, ss, "cfg2", device, steps=max(args.steps, 400), warmup=50, prewarm_ms=100.0, streams=2, probe_board=False)
+            res["value_pipelined"] = pl["value"]
+            res["pipelined"] = {"streams": 2, "steps": pl["steps"], "ms_per_step": pl["ms_per_step"], "kernel": pl["kernel"],
+                                "note": "same workload, successive steps alternate over two HIP streams (independent batches): one launch's tail "
+                                        "runs under the next one's head; wall time per step, not a kernel duration, not part of `roofline`"}
+            res["secondary"] = {}
+            for wl, st, wu in (("cfg3", 200, 20), ("cfg5", 200, 20), ("cfg4", 5, 1)):
+                try:
+                    res["secondary"][wl] = measure_simple(torch, ss, wl, device, steps=st, warmup=wu, prewarm_ms=300.0)
+                except Exception as e:  # a secondary line must never take the headline down with it
+                    res["secondary"][wl] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
 
     if world > 1:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 5 /* 5: config-free stack_frames entry points, ss_mfcc_shader_clock; the ss_debug_* test aids left the product library */
+#define SS_ABI_VERSION 6 /* 6: ss_shader_clock_probe; 5: config-free stack_frames entry points, ss_mfcc_shader_clock; the ss_debug_* test aids left the product library */
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -162,7 +162,7 @@ int ss_stft(const ss_config *cfg, const float *x, size_t channels, size_t n_samp
  * (the `filter` argument; mfcc_window switch): frames [n_frames x frame_len], sizes from ss_num_frames / ss_frame_sizes. */
 int ss_stack_frames(const ss_config *cfg, const float *x, size_t n_samples, float *frames);
 /* The same function with the reference's own argument list and nothing else -- no SpeechConfig, no FFT length (the reference's
- * stack_frames has no FFT dependency: 44.1 kHz x 25 ms frames of 1102 samples are fine): contract framing
+ * stack_frames has no FFT dependency: 44.1 kHz x 25 ms frames of round(1102.5) = 1103 samples are fine): contract framing
  * frames[t][i] = x[t * step + i], frame_len = round(sample_rate * frame_length), step likewise (processing.rs:77-78),
  * floor((n - frame_len) / step) frames, or ceil with the tail reading appended zeros when zero_padding != 0 (:85-106).
  * `window`: frame_len floats that multiply every frame -- row 0 of the Array2 the reference's `filter(frame_len)` returns
@@ -290,6 +290,14 @@ int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_
  * SS_ERR_UNSUPPORTED for configurations served by another kernel. */
 int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_out,
                          void *stream, int launches, float *ghz);
+
+/* Shader clock (GHz) of the device while WHATEVER ELSE runs on it: one wave on `stream` reads the shader-cycle counter and the
+ * constant 100 MHz counter, sleeps (no memory traffic, no LDS, a handful of registers) for about `micros` microseconds and reads
+ * both again; *ghz = cycles / time.  Launch the kernels of interest on their own stream first and call this with a side stream:
+ * the probe wave fits beside the persistent workgroups (they leave wave slots free) and sees the clock the part holds under that
+ * load (the power cap).  Works for every kernel of the library (bench.py's secondary.*.clock_ghz_measured);
+ * synchronises `stream` only.  10 <= micros <= 1 000 000. */
+int ss_shader_clock_probe(void *stream, uint32_t micros, float *ghz);
 
 /* Process-wide test aids (LDS poisoning, kernel-selection overrides, fault injection, a stamp buffer) are NOT part of this
  * library: include/speechsauce_amd_debug.h, exported by the lab build libspeechsauce_amd_lab.so only. */

@@ -77,7 +77,8 @@ private:
     ss_params p_{};
 };
 
-// config.rs:99-190.  Immutable after creation: unlike the reference there is no STFT carry-over state.
+// config.rs:98-190.  Immutable after creation: unlike the reference there is no STFT carry-over state.  Copyable like the
+// reference's `#[derive(Clone)]` (config.rs:98): copies share one device handle, released with the last of them.
 class SpeechConfig {
 public:
     // SpeechConfig::new, config.rs:140-150
@@ -93,27 +94,48 @@ public:
         p_.low_frequency = low_frequency;
         p_.high_frequency = high_frequency;
         p_.dc_elimination = dc_elimination;
-        check(ss_config_create(&p_, &h_));
+        create_();
     }
-    explicit SpeechConfig(const ss_params &p) : p_(p) { check(ss_config_create(&p_, &h_)); }
+    explicit SpeechConfig(const ss_params &p) : p_(p) { create_(); }
     SpeechConfig() : SpeechConfig(SpeechConfigBuilder(16000).build()) {}  // Default, config.rs:133-137
-    SpeechConfig(SpeechConfig &&o) noexcept : p_(o.p_), h_(o.h_) { o.h_ = nullptr; }
-    SpeechConfig &operator=(SpeechConfig &&o) noexcept { std::swap(p_, o.p_); std::swap(h_, o.h_); return *this; }
-    SpeechConfig(const SpeechConfig &) = delete;
-    SpeechConfig &operator=(const SpeechConfig &) = delete;
-    ~SpeechConfig() { ss_config_destroy(h_); }
 
     const ss_params &params() const { return p_; }
-    const ss_config *handle() const { return h_; }
+    const ss_config *handle() const { return h_.get(); }
+    // the reference's public plain-data fields (config.rs:100-126) as accessors
     std::size_t sample_rate() const { return p_.sample_rate; }
     std::size_t window_size() const { return p_.fft_points; }
+    std::size_t window_size_half() const { return p_.fft_points / 2; }
     std::size_t freq_size() const { return p_.fft_points / 2 + 1; }
+    std::size_t frame_size() const { return frame_size_; }    // trunc(frame_length * sample_rate), config.rs:154
+    float frame_length() const { return p_.frame_length; }
+    float frame_stride() const { return p_.frame_stride; }
     std::size_t num_cepstral() const { return p_.num_cepstral; }
     std::size_t num_filters() const { return p_.num_filters; }
+    float low_frequency() const { return p_.low_frequency; }
+    float high_frequency() const { return p_.high_frequency; }
+    bool dc_elimination() const { return p_.dc_elimination != 0; }
+    float wnorm() const { return wnorm_; }                    // 2 frame_size / fft_points^2, config.rs:178
+    const std::vector<float> &window() const { return window_; }  // Vorbis window of window_size points, config.rs:151-160
 
 private:
+    void create_()
+    {
+        ss_config *h = nullptr;
+        check(ss_config_create(&p_, &h));
+        h_ = std::shared_ptr<ss_config>(h, [](ss_config *c) { ss_config_destroy(c); });
+        // config.rs:154 / :178, the reference's own f32 arithmetic (every config has these two, not only the STFT-capable ones
+        // ss_stft_sizes answers for): frame_size = trunc(frame_length * sample_rate), wnorm = 1 / (fft_points^2 / (2 frame_size))
+        frame_size_ = static_cast<std::size_t>(p_.frame_length * static_cast<float>(p_.sample_rate));
+        const std::size_t n2 = static_cast<std::size_t>(p_.fft_points) * p_.fft_points;
+        wnorm_ = 1.0f / (static_cast<float>(n2) / static_cast<float>(2 * frame_size_));
+        window_.resize(p_.fft_points);
+        check(ss_vorbis_window(window_.size(), window_.data()));
+    }
     ss_params p_{};
-    ss_config *h_ = nullptr;
+    std::shared_ptr<ss_config> h_;
+    std::size_t frame_size_ = 0;
+    float wnorm_ = 0.f;
+    std::vector<float> window_;
 };
 
 inline SpeechConfig SpeechConfigBuilder::build() const { return SpeechConfig(p_); }

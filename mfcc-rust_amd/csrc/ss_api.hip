@@ -1089,6 +1089,7 @@ std::mutex g_rccl_mu;
 std::string g_rccl_path;       // ss_rccl_library
 std::unique_ptr<Rccl> g_rccl;  // set once a resolution has succeeded
 std::string g_rccl_error;      // why the last attempt failed
+bool g_rccl_absent = false;    // the auto-discovery found nothing: not repeated per call (ss_rccl_library resets it)
 
 bool rccl_from(void *handle, const char *origin, Rccl &r)
 {
@@ -1109,26 +1110,38 @@ const Rccl *rccl(std::string *why = nullptr)
         std::string *out;
         ~Report() { if (out) *out = g_rccl_error; }
     } report{why};
-    if (g_rccl) return g_rccl.get();  // only a successful resolution is kept
+    if (g_rccl) {  // only a successful resolution is kept
+        g_rccl_error.clear();  // (a stale reason of an earlier, corrected attempt must not reach `why` on success)
+        return g_rccl.get();
+    }
     std::unique_ptr<Rccl> r(new Rccl());
     auto keep = [&]() {
         g_rccl = std::move(r);
+        g_rccl_error.clear();
         return g_rccl.get();
+    };
+    // a handle THIS function opened and that did not resolve is closed again (one reference would leak per call)
+    auto from_opened = [&](void *h, const char *origin) {
+        if (!h) return false;
+        if (rccl_from(h, origin, *r)) return true;
+        (void)dlclose(h);
+        return false;
     };
     if (!g_rccl_path.empty()) {
         void *h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (h && rccl_from(h, g_rccl_path.c_str(), *r)) return keep();
+        const char *de = h ? nullptr : dlerror();
+        if (from_opened(h, g_rccl_path.c_str())) return keep();
         // an explicit path that does not load is an error, not a reason to guess; nothing is cached, so a corrected
         // ss_rccl_library call is accepted and tried again
-        const char *de = h ? nullptr : dlerror();
         g_rccl_error = g_rccl_path + (h ? ": ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd not all found" : std::string(": ") + (de ? de : "dlopen failed"));
         return nullptr;
     }
     g_rccl_error = "no mapped copy, librccl.so.1 / librccl.so not loadable";
+    if (g_rccl_absent) return nullptr;  // looked already: the lookups, the /proc scan and four dlopen attempts are not repeated per call
     if (rccl_from(RTLD_DEFAULT, "already in the global symbol scope", *r)) return keep();
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
         void *h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-        if (h && rccl_from(h, "already mapped (RTLD_NOLOAD)", *r)) return keep();
+        if (from_opened(h, "already mapped (RTLD_NOLOAD)")) return keep();
     }
     {
         // a copy mapped under another name (torch/lib/librccl.so is loaded by path): look through the process's objects
@@ -1146,13 +1159,14 @@ const Rccl *rccl(std::string *why = nullptr)
         }
         if (!ctx.path.empty()) {
             void *h = dlopen(ctx.path.c_str(), RTLD_NOW | RTLD_NOLOAD);
-            if (h && rccl_from(h, ctx.path.c_str(), *r)) return keep();
+            if (from_opened(h, ctx.path.c_str())) return keep();
         }
     }
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
         void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (h && rccl_from(h, name, *r)) return keep();
+        if (from_opened(h, name)) return keep();
     }
+    g_rccl_absent = true;  // (a later ss_rccl_library call, e.g. after the caller has loaded RCCL, asks again)
     return nullptr;
 }
 
@@ -1172,6 +1186,7 @@ int ss_rccl_library(const char *path)
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl) return ss::fail(SS_ERR_ARG, "RCCL was already resolved (" + g_rccl->origin + "): ss_rccl_library must precede the first collective");
     g_rccl_path = path ? path : "";
+    g_rccl_absent = false;
     return SS_OK;
 }
 
@@ -1611,6 +1626,45 @@ int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, s
     }
     if (n == 0) return ss::fail(SS_ERR_DEVICE, "no wave reported its lifetime");
     *ghz = static_cast<float>(sum / static_cast<double>(n));
+    return SS_OK;
+}
+
+namespace {
+// One wave: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over about `ticks` of the latter,
+// asleep in between (s_sleep: no issue slots, no memory traffic -- the workload beside it is not disturbed).
+static __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, unsigned ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        t = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c1 - c0;
+    out[1] = t1 - t0;
+}
+}  // namespace
+
+int ss_shader_clock_probe(void *stream, uint32_t micros, float *ghz)
+{
+    if (!ghz || micros < 10 || micros > 1000000) return ss::fail(SS_ERR_ARG, "bad clock probe request");
+    *ghz = 0.f;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DeviceBuf db;
+    int rc = db.alloc(2 * sizeof(unsigned long long));
+    if (rc) return rc;
+    SS_HIP(hipMemsetAsync(db.p, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, db.as<unsigned long long>(), micros * 100u);
+    SS_HIP(hipGetLastError());
+    unsigned long long w[2] = {0, 0};
+    SS_HIP(hipMemcpyAsync(w, db.p, sizeof w, hipMemcpyDeviceToHost, s));
+    SS_HIP(hipStreamSynchronize(s));
+    if (w[1] == 0) return ss::fail(SS_ERR_DEVICE, "the clock probe reported nothing");
+    *ghz = static_cast<float>(static_cast<double>(w[0]) / (static_cast<double>(w[1]) * 10.0));  // cycles per ns
     return SS_OK;
 }
 

@@ -864,6 +864,15 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             const unsigned __int128 num = static_cast<unsigned __int128>(1) << (31 + l);
             a.nf_magic = static_cast<uint32_t>((num + d - 1) / d);
             a.nf_shift = l - 1;
+            // quad_src (the SPREAD builds' sample addresses): a lane's 32-bit byte offset from the quad's uniform base reaches
+            // 3 frames + one step into the next clip + its 16 sample pairs + the sixteen 128-byte strides of the loads, and the
+            // frame-in-quad product is a 24-bit multiply.  Row strides / hops beyond that go to the next kernel
+            // (launch_frames falls through on this value), which forms 64-bit addresses.
+            const unsigned long long span = static_cast<unsigned long long>(a.n_frames) * a.step;
+            // (centred frames never take quad_src, and their n_frames * step may exceed the clip: not checked)
+            if (!a.center && (a.ld < span || static_cast<unsigned long long>(a.step) * 4ull >= (1ull << 24) ||
+                              3ull * a.step * 4ull + (a.ld - span) * 4ull + 16ull * 8ull + 16ull * 128ull >= (1ull << 32)))
+                return hipErrorInvalidValue;
         } else if (static_cast<unsigned long long>(a.batch) * a.ld * 4ull >= (1ull << 32)) {
             return hipErrorInvalidValue;  // without the reciprocal the kernel addresses a lane's frame by a 32-bit offset from the batch's first sample
         }

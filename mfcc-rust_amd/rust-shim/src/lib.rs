@@ -1,6 +1,9 @@
 //! `speechsauce-amd`: the hot-path API of the `speechsauce` crate on an MI355X.
 //!
-//! Signatures follow the reference one for one so a caller switches by changing the `use` line:
+//! Drop-in by module path: the crate has the reference's public modules (`speechsauce/src/lib.rs:2-6`) -- `config`, `feature`,
+//! `functions`, `processing`, `util` -- so with `speechsauce = { package = "speechsauce-amd", path = ".." }` in Cargo.toml an
+//! existing `use speechsauce::feature::mfcc;` keeps compiling with no source edit.  Every item also stays at the crate root.
+//! Signatures follow the reference one for one:
 //!   speechsauce::feature::mfcc(ArrayView1<f32>, &SpeechConfig) -> Array2<f32>          (feature.rs:99)
 //!   speechsauce::feature::mfe(ArrayView1<f32>, &SpeechConfig) -> (Array2, Array1)       (feature.rs:200)
 //!   speechsauce::feature::mel_spectrogram1 / mel_spectrogram2                           (feature.rs:151,163)
@@ -15,12 +18,20 @@
 //! functions panic too, with the library's error text (`expect`-style), so behaviour under bad input is
 //! unchanged for existing callers; `try_*` variants return `Result`.
 //!
-//! This file is shipped uncompiled (the build image has no Rust toolchain).
+//! `SpeechConfig` is `Clone` like the reference's (config.rs:98): clones share one immutable device handle (`Arc`), which is
+//! released when the last clone drops.  Its public fields are the reference's plain-data fields (config.rs:100-126), including
+//! `window_size_half`, `frame_size`, `wnorm` and `window`; the reference's five fields that hold third-party plan objects or
+//! streaming state (`analysis_mem`, `dct_handler`, `fft_handler`, `fft_forward`, `analysis_scratch`) have no counterpart: the
+//! plans live on the device and the STFT starts from zero state per call.
+//!
+//! This file is shipped uncompiled (the build image has no Rust toolchain): NEVER COMPILED, checked textually by
+//! tests/test_binding_mirrors.py.
 
-use ndarray::{Array1, Array2, Array3, ArrayView1, ArrayView2};
+use ndarray::{Array, Array1, Array2, Array3, ArrayView1, ArrayView2, Dimension};
 use num_complex::Complex32;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_long, c_void};
+use std::sync::Arc;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
@@ -59,6 +70,8 @@ extern "C" {
     fn ss_config_destroy(cfg: *mut SsConfig);
     fn ss_num_frames(p: *const SsParams, n_samples: usize, n_frames: *mut usize) -> c_int;
     fn ss_stft_rows(p: *const SsParams, n_samples: usize, rows: *mut usize, real_rows: *mut usize) -> c_int;
+    fn ss_stft_sizes(p: *const SsParams, hop: *mut usize, n_pad: *mut usize, wnorm: *mut f32) -> c_int;  // (stft_sizes below)
+    fn ss_vorbis_window(n: usize, w: *mut f32) -> c_int;
     fn ss_mfcc(cfg: *const SsConfig, x: *const f32, n: usize, out: *mut f32) -> c_int;
     fn ss_mfe(cfg: *const SsConfig, x: *const f32, n: usize, feat: *mut f32, energy: *mut f32) -> c_int;
     fn ss_lmfe(cfg: *const SsConfig, x: *const f32, n: usize, feat: *mut f32) -> c_int;
@@ -117,6 +130,9 @@ pub unsafe fn gather_features(comm: *mut c_void, d_block: *const f32, elems_per_
     check(ss_gather_features(comm, d_block, elems_per_rank, d_out, root as c_int, rank as c_int, world as c_int, stream))
 }
 
+/// SS_ERR_ARG of include/speechsauce_amd.h
+pub const SS_ERR_ARG: i32 = 3;
+
 #[derive(Debug)]
 pub struct Error {
     pub status: i32,
@@ -132,8 +148,24 @@ fn check(status: c_int) -> Result<(), Error> {
 }
 
 /// config.rs:10-97
+#[derive(Clone)]
 pub struct SpeechConfigBuilder {
     p: SsParams,
+}
+impl Default for SpeechConfigBuilder {
+    /// config.rs:10 derives Default (every field zero); `SpeechConfig::builder()` hands that out (config.rs:187-189)
+    fn default() -> Self {
+        let mut b = SpeechConfigBuilder::new(16000);  // (the switches of ss_params keep their reference-mode defaults)
+        b.p.sample_rate = 0;
+        b.p.fft_points = 0;
+        b.p.frame_length = 0.0;
+        b.p.frame_stride = 0.0;
+        b.p.num_cepstral = 0;
+        b.p.num_filters = 0;
+        b.p.high_frequency = 0.0;
+        b.p.dc_elimination = 0;
+        b
+    }
 }
 
 impl SpeechConfigBuilder {
@@ -154,10 +186,21 @@ impl SpeechConfigBuilder {
     pub fn build(self) -> SpeechConfig { SpeechConfig::from_params(self.p).expect("SpeechConfig::new") }
 }
 
-/// config.rs:99-190.  Immutable after creation (no STFT carry-over), hence Send + Sync.
+/// The device-side half of a config: the opaque handle of include/speechsauce_amd.h, destroyed with the last clone.
+struct Handle(*mut SsConfig);
+// the handle is immutable after creation and safe for concurrent calls (speechsauce_amd.h, "Threading")
+unsafe impl Send for Handle {}
+unsafe impl Sync for Handle {}
+impl Drop for Handle {
+    fn drop(&mut self) { unsafe { ss_config_destroy(self.0) } }
+}
+
+/// config.rs:98-131.  Immutable after creation (no STFT carry-over), hence Send + Sync; `Clone` shares the device handle.
+#[derive(Clone)]
 pub struct SpeechConfig {
     pub sample_rate: usize,
     pub window_size: usize,
+    pub window_size_half: usize,
     pub frame_length: f32,
     pub frame_stride: f32,
     pub num_cepstral: usize,
@@ -165,12 +208,16 @@ pub struct SpeechConfig {
     pub low_frequency: f32,
     pub high_frequency: f32,
     pub freq_size: usize,
+    /// samples per STFT chunk = trunc(frame_length * sample_rate) (config.rs:154), as the library computes it
+    pub frame_size: usize,
     pub dc_elimination: bool,
+    /// 2 * frame_size / fft_points^2 (config.rs:178)
+    pub wnorm: f32,
+    /// the Vorbis power-complementary window of `window_size` points (config.rs:151-160)
+    pub window: Vec<f32>,
     params: SsParams,
-    handle: *mut SsConfig,
+    handle: Arc<Handle>,
 }
-unsafe impl Send for SpeechConfig {}
-unsafe impl Sync for SpeechConfig {}
 
 impl SpeechConfig {
     /// config.rs:140-150
@@ -191,9 +238,20 @@ impl SpeechConfig {
     pub fn from_params(p: SsParams) -> Result<Self, Error> {
         let mut h: *mut SsConfig = std::ptr::null_mut();
         check(unsafe { ss_config_create(&p, &mut h) })?;
+        let handle = Arc::new(Handle(h));  // from here on an early return releases the handle
+        // config.rs:154 / :178 in the reference's own f32 arithmetic (every config has these two, not only the STFT-capable
+        // ones ss_stft_sizes answers for; for those the library's values are the same numbers)
+        let frame_size = (p.frame_length * p.sample_rate as f32) as usize;
+        let wnorm = 1.0 / ((p.fft_points as usize).pow(2) as f32 / (2 * frame_size) as f32);
+        let mut window = vec![0f32; p.fft_points as usize];
+        check(unsafe { ss_vorbis_window(window.len(), window.as_mut_ptr()) })?;
         Ok(SpeechConfig {
             sample_rate: p.sample_rate as usize,
             window_size: p.fft_points as usize,
+            window_size_half: p.fft_points as usize / 2,
+            frame_size,
+            wnorm,
+            window,
             frame_length: p.frame_length,
             frame_stride: p.frame_stride,
             num_cepstral: p.num_cepstral as usize,
@@ -203,16 +261,18 @@ impl SpeechConfig {
             freq_size: p.fft_points as usize / 2 + 1,
             dc_elimination: p.dc_elimination != 0,
             params: p,
-            handle: h,
+            handle,
         })
     }
-    pub fn builder() -> SpeechConfigBuilder { SpeechConfigBuilder::new(16000) }
+    /// config.rs:187-189: the all-zero builder (set every field before `build()`, as with the reference)
+    pub fn builder() -> SpeechConfigBuilder { SpeechConfigBuilder::default() }
 }
 impl Default for SpeechConfig {
     fn default() -> Self { SpeechConfigBuilder::new(16000).build() }
 }
-impl Drop for SpeechConfig {
-    fn drop(&mut self) { unsafe { ss_config_destroy(self.handle) } }
+impl SpeechConfig {
+    /// the raw handle for the `extern "C"` calls below (valid while any clone lives)
+    fn raw(&self) -> *const SsConfig { self.handle.0 }
 }
 
 fn contiguous(signal: ArrayView1<f32>) -> std::borrow::Cow<[f32]> {
@@ -228,7 +288,7 @@ pub fn try_mfcc(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f3
     let mut t = 0usize;
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
     let mut out = Array2::<f32>::zeros((t, cfg.num_cepstral));
-    check(unsafe { ss_mfcc(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
+    check(unsafe { ss_mfcc(cfg.raw(), x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
     Ok(out)
 }
 pub fn mfcc(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_mfcc(signal, cfg).expect("mfcc") }
@@ -240,7 +300,7 @@ pub fn try_mfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<(Array2<f3
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
     let mut feat = Array2::<f32>::zeros((t, cfg.num_filters));
     let mut en = Array1::<f32>::zeros(t);
-    check(unsafe { ss_mfe(cfg.handle, x.as_ptr(), x.len(), feat.as_mut_ptr(), en.as_mut_ptr()) })?;
+    check(unsafe { ss_mfe(cfg.raw(), x.as_ptr(), x.len(), feat.as_mut_ptr(), en.as_mut_ptr()) })?;
     Ok((feat, en))
 }
 pub fn mfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> (Array2<f32>, Array1<f32>) { try_mfe(signal, cfg).expect("mfe") }
@@ -251,7 +311,7 @@ pub fn try_lmfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f3
     let mut t = 0usize;
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
     let mut feat = Array2::<f32>::zeros((t, cfg.num_filters));
-    check(unsafe { ss_lmfe(cfg.handle, x.as_ptr(), x.len(), feat.as_mut_ptr()) })?;
+    check(unsafe { ss_lmfe(cfg.raw(), x.as_ptr(), x.len(), feat.as_mut_ptr()) })?;
     Ok(feat)
 }
 pub fn lmfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_lmfe(signal, cfg).expect("lmfe") }
@@ -264,7 +324,7 @@ pub fn try_mel_spectrogram2(signal: ArrayView2<f32>, cfg: &SpeechConfig) -> Resu
     let (mut rows, mut real) = (0usize, 0usize);
     check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut real) })?;
     let mut out = Array3::<f32>::zeros((ch, cfg.num_filters, rows));
-    check(unsafe { ss_mel_spectrogram(cfg.handle, owned.as_ptr(), ch, n, out.as_mut_ptr()) })?;
+    check(unsafe { ss_mel_spectrogram(cfg.raw(), owned.as_ptr(), ch, n, out.as_mut_ptr()) })?;
     Ok(out)
 }
 pub fn mel_spectrogram2(signal: ArrayView2<f32>, cfg: &SpeechConfig) -> Array3<f32> {
@@ -286,7 +346,7 @@ pub fn try_mfcc_batch(signals: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Ar
     let mut t = 0usize;
     check(unsafe { ss_num_frames(&cfg.params, n, &mut t) })?;
     let mut out = Array3::<f32>::zeros((b, t, cfg.num_cepstral));
-    check(unsafe { ss_mfcc_batch(cfg.handle, owned.as_ptr(), b, n, n, out.as_mut_ptr()) })?;
+    check(unsafe { ss_mfcc_batch(cfg.raw(), owned.as_ptr(), b, n, n, out.as_mut_ptr()) })?;
     Ok(out)
 }
 
@@ -295,7 +355,7 @@ pub fn try_mfcc_batch(signals: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Ar
 /// `d_x` / `d_out` must be device allocations of the right size on the device the config was created on.
 pub unsafe fn mfcc_batch_device(cfg: &SpeechConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
                                 stream: *mut c_void) -> Result<(), Error> {
-    check(ss_mfcc_batch_device(cfg.handle, d_x, batch, n, ld, d_out, stream))
+    check(ss_mfcc_batch_device(cfg.raw(), d_x, batch, n, ld, d_out, stream))
 }
 
 /// functions.rs:86-123: `[channels, samples]` -> `Array3<Complex32>` `[channels, rows, freq_size]`
@@ -306,7 +366,7 @@ pub fn try_stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<Co
     check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut real) })?;
     let mut out = Array3::<Complex32>::zeros((ch, rows, cfg.freq_size));
     // Complex32 is #[repr(C)] { re: f32, im: f32 }: the interleaved block the ABI writes
-    check(unsafe { ss_stft(cfg.handle, owned.as_ptr(), ch, n, out.as_mut_ptr() as *mut f32) })?;
+    check(unsafe { ss_stft(cfg.raw(), owned.as_ptr(), ch, n, out.as_mut_ptr() as *mut f32) })?;
     Ok(out)
 }
 pub fn stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Array3<Complex32> { try_stft2(input, cfg).expect("stft2") }
@@ -330,14 +390,22 @@ pub fn try_stack_frames(signal: ArrayView1<f32>, sample_rate: usize, frame_lengt
                         filter: Option<fn(usize) -> Array2<f32>>, zero_padding: bool) -> Result<Array2<f32>, Error> {
     let x = contiguous(signal);
     let (mut t, mut flen) = (0usize, 0usize);
+    if sample_rate > u32::MAX as usize {
+        return Err(Error { status: SS_ERR_ARG, detail: "sample_rate does not fit 32 bits".to_string() });
+    }
     check(unsafe { ss_stack_frames_shape(x.len(), sample_rate as u32, frame_length, frame_stride, zero_padding as c_int, &mut t, &mut flen) })?;
-    let window: Option<Vec<f32>> = filter.map(|f| {
-        let w = f(flen);
-        // row 0 of the (1, frame_len) array; a (frame_len, 1) column (feature.rs:176-178 `_f_it`) is read down its column
-        let v: Vec<f32> = if w.nrows() == 1 { w.row(0).to_vec() } else { w.column(0).to_vec() };
-        assert_eq!(v.len(), flen, "filter(frame_len) must give frame_len values");
-        v
-    });
+    let window: Option<Vec<f32>> = match filter {
+        None => None,
+        Some(f) => {
+            let w = f(flen);
+            // row 0 of the (1, frame_len) array; a (frame_len, 1) column (feature.rs:176-178 `_f_it`) is read down its column
+            let v: Vec<f32> = if w.nrows() == 1 { w.row(0).to_vec() } else { w.column(0).to_vec() };
+            if v.len() != flen {  // the try_ form reports, it does not panic
+                return Err(Error { status: SS_ERR_ARG, detail: format!("filter({}) gave {} values", flen, v.len()) });
+            }
+            Some(v)
+        }
+    };
     let mut out = Array2::<f32>::zeros((t, flen));
     let wptr = window.as_ref().map_or(std::ptr::null(), |w| w.as_ptr());
     check(unsafe { ss_stack_frames_signal(x.as_ptr(), x.len(), sample_rate as u32, frame_length, frame_stride, wptr, zero_padding as c_int, out.as_mut_ptr()) })?;
@@ -356,7 +424,7 @@ pub fn try_stack_frames_with(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Res
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
     check(unsafe { ss_frame_sizes(&cfg.params, &mut flen, &mut step) })?;
     let mut out = Array2::<f32>::zeros((t, flen));
-    check(unsafe { ss_stack_frames(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
+    check(unsafe { ss_stack_frames(cfg.raw(), x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
     Ok(out)
 }
 pub fn stack_frames_with(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_stack_frames_with(signal, cfg).expect("stack_frames") }
@@ -367,9 +435,9 @@ pub fn stack_frames_with(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<
 pub fn try_power_spectrum(frames: Array2<f32>, fft_points: usize) -> Result<Array2<f32>, Error> {
     use std::collections::HashMap;
     use std::sync::{Mutex, OnceLock};
-    struct Handle(*mut SsConfig);
-    unsafe impl Send for Handle {}  // the handle is immutable after creation and thread-safe (speechsauce_amd.h)
-    static CACHE: OnceLock<Mutex<HashMap<usize, Handle>>> = OnceLock::new();
+    struct Kept(*mut SsConfig);
+    unsafe impl Send for Kept {}  // the handle is immutable after creation and thread-safe (speechsauce_amd.h)
+    static CACHE: OnceLock<Mutex<HashMap<usize, Kept>>> = OnceLock::new();
     let cache = CACHE.get_or_init(|| Mutex::new(HashMap::new()));
     let handle = {
         let mut map = cache.lock().expect("power_spectrum config cache");
@@ -385,7 +453,7 @@ pub fn try_power_spectrum(frames: Array2<f32>, fft_points: usize) -> Result<Arra
             p.num_cepstral = std::cmp::min(13, p.num_filters);
             let mut h: *mut SsConfig = std::ptr::null_mut();
             check(unsafe { ss_config_create(&p, &mut h) })?;
-            map.insert(fft_points, Handle(h));  // kept for the life of the process
+            map.insert(fft_points, Kept(h));  // kept for the life of the process
             h
         }
     };
@@ -402,7 +470,7 @@ pub fn try_power_spectrum_with(frames: Array2<f32>, cfg: &SpeechConfig) -> Resul
     let x = frames.as_standard_layout();
     let (rows, cols) = x.dim();
     let mut out = Array2::<f32>::zeros((rows, cfg.freq_size));
-    check(unsafe { ss_power_spectrum_frames(cfg.handle, x.as_ptr(), rows, cols, out.as_mut_ptr()) })?;
+    check(unsafe { ss_power_spectrum_frames(cfg.raw(), x.as_ptr(), rows, cols, out.as_mut_ptr()) })?;
     Ok(out)
 }
 pub fn power_spectrum_with(frames: Array2<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_power_spectrum_with(frames, cfg).expect("power_spectrum") }
@@ -413,12 +481,20 @@ pub fn try_power_spectrum_of_signal(signal: ArrayView1<f32>, cfg: &SpeechConfig)
     let mut t = 0usize;
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
     let mut out = Array2::<f32>::zeros((t, cfg.freq_size));
-    check(unsafe { ss_power_spectrum(cfg.handle, x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
+    check(unsafe { ss_power_spectrum(cfg.raw(), x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
     Ok(out)
 }
 
+/// (hop, n_pad, wnorm) of the STFT path as the library computes them (functions.rs:96-97, config.rs:178); `Err` for a config whose
+/// `fft_points < 2 * frame_size` (the reference's `frame_analysis` underflows there, functions.rs:136).
+pub fn stft_sizes(cfg: &SpeechConfig) -> Result<(usize, usize, f32), Error> {
+    let (mut hop, mut n_pad, mut wnorm) = (0usize, 0usize, 0f32);
+    check(unsafe { ss_stft_sizes(&cfg.params, &mut hop, &mut n_pad, &mut wnorm) })?;
+    Ok((hop, n_pad, wnorm))
+}
+
 /// Status of the asynchronous launches made on `cfg` (`Err` with status 6 after a device-side protocol error; cleared by the call).
-pub fn device_status(cfg: &SpeechConfig) -> Result<(), Error> { check(unsafe { ss_config_device_status(cfg.handle) }) }
+pub fn device_status(cfg: &SpeechConfig) -> Result<(), Error> { check(unsafe { ss_config_device_status(cfg.raw()) }) }
 
 /// processing.rs:31-53
 pub fn preemphasis(signal: Array1<f32>, shift: isize, cof: f32) -> Array1<f32> {
@@ -463,4 +539,78 @@ pub fn extract_derivative_feature(feature: Array2<f32>) -> Array3<f32> {
     let mut cube = Array3::<f32>::zeros((rows, cols, 3));
     check(unsafe { ss_extract_derivative_feature(x.as_ptr(), rows, cols, cube.as_mut_ptr()) }).expect("extract_derivative_feature");
     cube
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Scalar helpers the reference exports from `functions` (functions.rs:19-71) and `util` (util.rs:372-381): host arithmetic on a
+// handful of values, written here in plain Rust (nothing to launch a kernel for); the filterbank the kernels use is built by the
+// library from the same formulas in the same f32 operation order (ss_filterbank).
+// ---------------------------------------------------------------------------------------------------------------------------
+
+/// functions.rs:19-21: Hz -> mel, 1127 ln(1 + f / 700)
+pub fn frequency_to_mel(f: f32) -> f32 { 1127.0 * (1.0 + f / 700.0).ln() }
+/// functions.rs:23-29
+pub fn frequency_arr_to_mel<D: Dimension>(freq: Array<f32, D>) -> Array<f32, D> { freq.mapv(frequency_to_mel) }
+/// functions.rs:31-34 (the reference's unused type parameter is kept so `mel_to_frequency::<Ix1>(m)` still compiles)
+pub fn mel_to_frequency<D>(mel: f32) -> f32 { 700.0 * ((mel / 1127.0).exp() - 1.0) }
+/// functions.rs:36-41
+pub fn mel_arr_to_frequency<D: Dimension>(mel: Array<f32, D>) -> Array<f32, D> { mel.mapv(|m| 700.0 * ((m / 1127.0).exp() - 1.0)) }
+/// functions.rs:43-60: triangular weight over the half-open range [left, right); at x == middle the falling branch wins (= 1)
+pub fn triangle(arr: Array1<f32>, left: f32, middle: f32, right: f32) -> Array1<f32> {
+    arr.mapv(|x| {
+        if !(x >= left && x < right) {
+            return 0.0;
+        }
+        let mut w = 0.0;
+        if x <= middle { w = (x - left) / (middle - left); }
+        if x >= middle { w = (right - x) / (right - middle); }
+        w
+    })
+}
+/// functions.rs:66-71: exact zeros become f32::EPSILON
+pub fn zero_handling<D: Dimension>(x: Array<f32, D>) -> Array<f32, D> { x.mapv(|v| if v == 0.0 { f32::EPSILON } else { v }) }
+
+/// util.rs:372-381: natural logarithm of every element, in place
+pub trait ArrayLog<D: Dimension> {
+    fn log(self) -> Array<f32, D>;
+}
+impl<D: Dimension> ArrayLog<D> for Array<f32, D> {
+    fn log(mut self) -> Array<f32, D> {
+        self.mapv_inplace(f32::ln);
+        self
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The reference's module paths (speechsauce/src/lib.rs:2-6).  Re-exports only: one implementation, two spellings.
+// ---------------------------------------------------------------------------------------------------------------------------
+
+/// speechsauce::config (config.rs)
+pub mod config {
+    pub use super::{SpeechConfig, SpeechConfigBuilder};
+}
+/// speechsauce::feature (feature.rs): mfcc, mfe, mel_spectrogram1 / 2 (+ the private lmfe / extract_derivative_feature, public here)
+pub mod feature {
+    pub use super::{extract_derivative_feature, lmfe, mel_spectrogram1, mel_spectrogram2, mfcc, mfe};
+    pub use super::{try_lmfe, try_mel_spectrogram2, try_mfcc, try_mfcc_batch, try_mfe};
+}
+/// speechsauce::processing (processing.rs)
+pub mod processing {
+    pub use super::{cmvn, cmvnw, derivative_extraction, power_spectrum, preemphasis, stack_frames};
+    pub use super::{power_spectrum_with, stack_frames_with, try_power_spectrum, try_power_spectrum_of_signal, try_power_spectrum_with,
+                    try_stack_frames, try_stack_frames_with};
+}
+/// speechsauce::functions (functions.rs)
+pub mod functions {
+    pub use super::{frequency_arr_to_mel, frequency_to_mel, mel_arr_to_frequency, mel_to_frequency, stft1, stft2, triangle, try_stft2,
+                    zero_handling};
+}
+/// speechsauce::util: the `ArrayLog` trait of the hot path (util.rs:372-381).  The pad helpers of util.rs are not part of the path
+///  and are not provided.
+pub mod util {
+    pub use super::ArrayLog;
+}
+/// Not in the reference: the clip-sharding helpers and the RCCL gather of the final blocks.
+pub mod distributed {
+    pub use super::{all_gather_features, gather_features, shard_bounds};
 }

@@ -372,12 +372,16 @@ def stft(signal, sampling_frequency, frame_length=0.020, fft_length=512, **switc
 def stack_frames(signal, sampling_frequency, frame_length=0.020, frame_stride=0.020, filter=None, zero_padding=False, **switches):
     """``speechsauce::processing::stack_frames(signal, sample_rate, frame_length, frame_stride, filter, zero_padding)``
     (processing.rs:65-129): (num_frames, frame_len) frames of a 1-D signal, any sampling rate and frame length (the function
-    has no FFT dependency: 44.1 kHz x 25 ms = 1102-sample frames are fine).  ``filter``: as in the reference, a callable that
+    has no FFT dependency: 44.1 kHz x 25 ms = round(1102.5) = 1103-sample frames are fine).  ``filter``: as in the reference, a callable that
     gets frame_len and returns the window as a (1, frame_len) array (row 0 is used; a 1-D array of frame_len works too), or an
     array; ``zero_padding=True`` is the reference's flag (ceil instead of floor frames, the tail reading appended zeros).
     ``switches`` (``framing="literal" | "center"``, ``mfcc_window=``, ``pad_mode=``) go through a SpeechConfig instead and then
     need frame_len <= 8192."""
     sig = _require_f32(signal, (1,), "stack_frames")
+    if isinstance(filter, (bool, np.bool_)):
+        # round 3's signature had zero_padding in this position: an old positional call must fail clearly, not index a bool
+        raise TypeError("stack_frames: the fifth argument is `filter` (a callable or an array), as in the reference "
+                        "(processing.rs:65-76); pass zero_padding=... by keyword or as the sixth argument")
     lib = _lib.lib()
     L = sig.shape[0]
     if switches:

@@ -15,7 +15,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
 # the lab build (same sources, -DSS_LAB=1): the only library that exports the ss_debug_* test aids
 LAB_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd_lab.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED, SS_ERR_DEVICE = range(7)
 FRAMING = {"contract": 0, "literal": 1, "center": 2, "padded": 3}
@@ -125,6 +125,7 @@ PROTOTYPES = {
     "ss_time_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_time_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_mfcc_shader_clock": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
+    "ss_shader_clock_probe": (C.c_int, [C.c_void_p, C.c_uint, _P(C.c_float)]),
     "ss_stack_frames_shape": (C.c_int, [C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
     "ss_stack_frames_signal": (C.c_int, [_fp, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp]),
     "ss_stack_frames_signal_device": (C.c_int, [_fp, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp, C.c_void_p]),

@@ -30,8 +30,9 @@ def _backend(group=None) -> str:
     return str(dist.get_backend(group)).lower()
 
 
-def all_gather_into(out, block, group=None):
-    """One all-gather of equal blocks: `out` [world * B, ...] <- `block` [B, ...] of every rank.
+def all_gather_into(out, block, group=None, parts=None):
+    """One all-gather of equal blocks: `out` [world * B, ...] <- `block` [B, ...] of every rank.  `parts` (instead of `out`): one
+    receive view per rank, e.g. the slices [r, c0:c1] of a [world, shard, ...] result when a shard is gathered chunk by chunk.
 
     RCCL (backend "nccl") moves device tensors directly over xGMI.  Under gloo (the CPU tests, or several ranks sharing one
     GPU, which RCCL refuses) device blocks are staged through host memory: same result, no claim about speed."""
@@ -39,19 +40,27 @@ def all_gather_into(out, block, group=None):
     import torch.distributed as dist
 
     if _backend(group) == "nccl" or not block.is_cuda:
+        if parts is not None:
+            dist.all_gather(list(parts), block, group=group)
+            return parts
         dist.all_gather_into_tensor(out, block, group=group)
         return out
     world = dist.get_world_size(group)
     host = block.detach().cpu()
-    parts = [torch.empty_like(host) for _ in range(world)]
-    dist.all_gather(parts, host, group=group)
-    out.copy_(torch.cat(parts, dim=0).to(out.device, non_blocking=False))
+    hparts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(hparts, host, group=group)
+    if parts is not None:
+        for dst_view, h in zip(parts, hparts):
+            dst_view.copy_(h.to(dst_view.device, non_blocking=False))
+        return parts
+    out.copy_(torch.cat(hparts, dim=0).to(out.device, non_blocking=False))
     return out
 
 
-def gather_into(out, block, dst: int = 0, group=None):
+def gather_into(out, block, dst: int = 0, group=None, parts=None):
     """The north-star's collective: rank `dst` receives `out` [world * B, ...] <- `block` [B, ...] of every rank, in rank order;
-    the other ranks only send (`out` is ignored there and may be None).
+    the other ranks only send (`out` is ignored there and may be None).  `parts` (on `dst`, instead of `out`): one receive view
+    per rank -- a shard gathered chunk by chunk lands in the slices [r, c0:c1] of one [world, shard, ...] result.
 
     RCCL (backend "nccl"): torch.distributed.gather = grouped ncclSend / ncclRecv -- every peer has a direct xGMI link to the
     root, so the blocks arrive concurrently and nobody but the root spends HBM on them (an all-gather writes world - 1 foreign
@@ -63,15 +72,19 @@ def gather_into(out, block, dst: int = 0, group=None):
     rank = dist.get_rank(group)
     dst_global = dist.get_global_rank(group, dst) if group is not None else dst
     if _backend(group) == "nccl" or not block.is_cuda:
-        parts = list(out.chunk(world, dim=0)) if rank == dst else None
-        dist.gather(block, gather_list=parts, dst=dst_global, group=group)
-        return out if rank == dst else None
+        recv = (list(parts) if parts is not None else list(out.chunk(world, dim=0))) if rank == dst else None
+        dist.gather(block, gather_list=recv, dst=dst_global, group=group)
+        return (parts if parts is not None else out) if rank == dst else None
     host = block.detach().cpu()
-    parts = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
-    dist.gather(host, gather_list=parts, dst=dst_global, group=group)
+    hparts = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+    dist.gather(host, gather_list=hparts, dst=dst_global, group=group)
     if rank != dst:
         return None
-    out.copy_(torch.cat(parts, dim=0).to(out.device, non_blocking=False))
+    if parts is not None:
+        for dst_view, h in zip(parts, hparts):
+            dst_view.copy_(h.to(dst_view.device, non_blocking=False))
+        return parts
+    out.copy_(torch.cat(hparts, dim=0).to(out.device, non_blocking=False))
     return out
 
 

@@ -266,11 +266,31 @@ def extract_derivative_feature(feat):
 
 # ---- reference-shaped f32 port (timed CPU baseline) ----
 
-def port_mfcc(p, x):
+_native = None
+_native_flags = None
+
+
+def native_port():
+    """The port built for THIS host (`make native`: -O3 -march=native, no fast-math, no contraction) -- what bench.py's
+    cpu_baseline times.  Built on first use on the machine that runs it; (None, reason) when that fails (the caller then times
+    the portable -O2 build and says so).  Only port_* are taken from this library; the checker stays libss_oracle.so."""
+    global _native, _native_flags
+    if _native is None:
+        so = os.path.join(_HERE, "_native", "libss_oracle_native.so")
+        try:
+            subprocess.run(["make", "-C", _HERE, "-s", "-B", "native"], check=True, capture_output=True, timeout=300)
+            _native = C.CDLL(so)
+            _native_flags = open(os.path.join(_HERE, "_native", "flags.txt")).read().strip()
+        except Exception as e:  # no compiler / read-only tree: fall back, loudly, in the caller's report
+            _native, _native_flags = False, f"native build failed: {e!r}"
+    return (_native or None), _native_flags
+
+
+def port_mfcc(p, x, from_lib=None):
     x = _f32(x)
     T = num_frames(p, x.size)
     out = np.empty((T, p.num_cepstral), dtype=np.float32)
-    _chk(lib().port_mfcc_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(out, C.c_float)))
+    _chk((from_lib or lib()).port_mfcc_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(x.size), _ptr(out, C.c_float)))
     return out
 
 
@@ -283,11 +303,11 @@ def port_mfe(p, x):
     return feat, en
 
 
-def port_mel_spectrogram(p, x):
+def port_mel_spectrogram(p, x, from_lib=None):
     one_d = np.asarray(x).ndim == 1
     x = np.atleast_2d(_f32(x))
     ch, n = x.shape
     R, _ = stft_rows(p, n)
     out = np.empty((ch, p.num_filters, R), dtype=np.float32)
-    _chk(lib().port_mel_spectrogram_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(ch), C.c_size_t(n), _ptr(out, C.c_float)))
+    _chk((from_lib or lib()).port_mel_spectrogram_f32(C.byref(p), _ptr(x, C.c_float), C.c_size_t(ch), C.c_size_t(n), _ptr(out, C.c_float)))
     return out[0] if one_d else out

@@ -30,8 +30,8 @@ def sslib():
 
     from speechsauce_amd import _lib
 
-    if not os.path.exists(_lib.LIB_PATH):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc"), "-j4"], check=True)
+    # always: make is incremental, and a library older than its sources must never be what the tests exercise
+    subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc"), "-j4", "-s"], check=True)
 
     return _lib.lib()
 
@@ -45,8 +45,9 @@ def sslab(sslib):
 
     from speechsauce_amd import _lib
 
-    if not os.path.exists(_lib.LAB_LIB_PATH):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc"), "-j4", "lab"], check=True)
+    # always (incremental): the product and the lab library must come from the same sources -- a stale lab build with the same
+    # ABI number would silently run old kernels in the kernel-variant, tile and fault tests
+    subprocess.run(["make", "-C", os.path.join(ROOT, "mfcc-rust_amd", "csrc"), "-j4", "-s", "lab"], check=True)
     return _lib.lab()
 
 

@@ -755,6 +755,38 @@ def test_strided_batch_ld(ss, oracle, sslib):
         assert _rel(out[b].cpu().numpy(), oracle.mfcc(p, x[b, :16000])) <= RTOL
 
 
+@pytest.mark.parametrize("ld", [(1 << 30) - 1000, (1 << 30) + 20000, (1 << 32) + 2])
+def test_huge_row_stride_is_addressed_in_64_bits(ss, oracle, sslib, ld):
+    """A row stride of >= 2^30 floats (>= 4 GB between clips): the headline kernel addresses a lane's frame by a 32-bit byte offset
+    from its quad's base and must hand such batches to a kernel that forms 64-bit addresses instead of wrapping (round-4
+    advisor finding).  Three clips at that stride, compared bit for bit with the same clips at a small stride."""
+    import torch
+    from speechsauce_amd import _lib
+
+    B, n = 3, 16000
+    x = _signal(21, (B, n))
+    big = torch.zeros(((B - 1) * ld + n,), dtype=torch.float32, device="cuda")
+    for b in range(B):
+        big[b * ld: b * ld + n] = torch.from_numpy(x[b]).cuda()
+    cfg = _cfg(ss, **CFG1)
+    T = cfg.num_frames(n)
+    out = torch.empty((B, T, 13), dtype=torch.float32, device="cuda")
+    _lib.check(sslib.ss_mfcc_batch_device(cfg.handle, big.data_ptr(), B, n, ld, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    kernel_big = sslib.ss_last_kernel_name()
+    del big
+    small = torch.from_numpy(x).cuda()
+    want = torch.empty_like(out)
+    _lib.check(sslib.ss_mfcc_batch_device(cfg.handle, small.data_ptr(), B, n, n, want.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256<")
+    p = oracle.make_params(**CFG1)
+    for b in range(B):
+        assert _rel(out[b].cpu().numpy(), oracle.mfcc(p, x[b])) <= RTOL, (b, kernel_big)
+    if kernel_big.startswith(b"ss_mfcc_c256<"):  # strides the 32-bit offsets still cover stay on the headline kernel: same bits
+        assert torch.equal(out, want)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # committed golden fixtures (tests/golden/golden_v1.npz, generated by the numpy restatement)
 # ---------------------------------------------------------------------------------------------------------
@@ -915,7 +947,11 @@ def test_cpp_mirror_parity(tmp_path, oracle):
         "int main(int argc, char **argv) {\n"
         "  std::vector<float> x(16000); FILE *f = std::fopen(argv[1], \"rb\");\n"
         "  if (!f || std::fread(x.data(), 4, x.size(), f) != x.size()) return 2; std::fclose(f);\n"
-        "  speechsauce::SpeechConfig cfg = speechsauce::SpeechConfigBuilder(16000).build();\n"
+        "  speechsauce::SpeechConfig cfg0 = speechsauce::SpeechConfigBuilder(16000).build();\n"
+        "  speechsauce::SpeechConfig cfg = cfg0;  // Clone (config.rs:98): the copy shares the handle and outlives the original\n"
+        "  cfg0 = speechsauce::SpeechConfig(16000, 2048, 0.032f, 0.032f, 13, 128, 0.f, 8000.f, true);\n"
+        "  if (cfg.frame_size() != 320 || cfg.window_size_half() != 256 || cfg.window().size() != 512 || cfg.handle() == cfg0.handle()) return 5;\n"
+        "  if (cfg0.frame_size() != 512 || cfg0.wnorm() != 1.0f / (4194304.0f / 1024.0f) || cfg0.window()[0] <= 0.f) return 6;\n"
         "  auto m = speechsauce::mfcc(x, cfg);\n"
         "  auto n = speechsauce::cmvn(m.data, m.rows, m.cols, true);\n"
         "  f = std::fopen(argv[2], \"wb\"); std::fwrite(m.data.data(), 4, m.data.size(), f); std::fwrite(n.data(), 4, n.size(), f);\n"
@@ -1249,10 +1285,27 @@ def _on_lab_test_kernel_variants_agree(ss, sslib):
     assert _rel(outs[1], outs[0]) <= 2e-5
 
 
-def test_kernel_variants_agree(ss, sslab):
-    """Runs on the LAB library (the build selection / fault aids it needs are not in the product library): the front is
-    switched to it for the duration."""
+def test_kernel_variants_agree(ss, sslib, sslab):
+    """The dedicated kernel runs on the PRODUCT library (the code that ships: its kernels are compiled without the lab
+    switches), only the forced-generic reference on the LAB library (which owns ss_debug_force_generic); the product build's
+    dedicated kernel must also give the lab build's dedicated kernel's bits -- a miscompile or a dispatch difference of the
+    product objects would show here (round-4 advisor finding)."""
+    import torch
+
+    x = torch.from_numpy((np.random.default_rng(5).standard_normal((37, 16000)) * 0.1).astype(np.float32)).cuda()
+    prod = ss.mfcc_batch(x, 16000).cpu().numpy()
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mfcc_c256<")
     with ss._lib.use_library(sslab):
+        lab = ss.mfcc_batch(x, 16000).cpu().numpy()
+        assert sslab.ss_last_kernel_name() == sslib.ss_last_kernel_name()
+        try:
+            sslab.ss_debug_force_generic(1)
+            gen = ss.mfcc_batch(x, 16000).cpu().numpy()
+            assert sslab.ss_last_kernel_name().startswith(b"ss_front_generic")
+        finally:
+            sslab.ss_debug_force_generic(0)
         _on_lab_test_kernel_variants_agree(ss, sslab)
+    assert np.array_equal(prod, lab)
+    assert _rel(gen, prod) <= 2e-5
 
 

@@ -173,6 +173,74 @@ def test_bench_launches_its_own_ranks(mode):
     assert d["rccl_ranks"] == (2 if d["backend"] == "nccl" else 0)
 
 
+def _chunk_worker(rank, world, port, shard_max, chunks, mode, result_dir):
+    """A rank's shard gathered chunk by chunk into the slices [r, c0:c1] of one [world, shard, ...] result (bench.py's cfg4 path)."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mfcc-rust_amd"))
+    from speechsauce_amd.distributed import all_gather_into, gather_into, shard_bounds
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        block = torch.arange(shard_max * 6, dtype=torch.float32).reshape(shard_max, 2, 3) + 1000.0 * rank
+        holds = mode == "all" or rank == 0
+        full = torch.full((world, shard_max, 2, 3), -1.0) if holds else None
+        for c in range(chunks):
+            c0, c1 = shard_bounds(shard_max, chunks, c)
+            parts = [full[r, c0:c1] for r in range(world)] if holds else None
+            if mode == "all":
+                all_gather_into(None, block[c0:c1], parts=parts)
+            else:
+                gather_into(None, block[c0:c1], dst=0, parts=parts)
+        dist.barrier()
+        if holds:
+            np.save(os.path.join(result_dir, f"chunk_rank{rank}.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shard_max,chunks,mode", [(2, 16, 8, "root"), (2, 13, 8, "all"), (3, 5, 8, "root")])
+def test_chunked_gather_fills_the_rank_slices(tmp_path, world, shard_max, chunks, mode):
+    """gather_into / all_gather_into with per-rank receive views: uneven chunk sizes, more chunks than clips (empty chunks)."""
+    port = _free_port()
+    mp.spawn(_chunk_worker, args=(world, port, shard_max, chunks, mode, str(tmp_path)), nprocs=world, join=True)
+    want = np.stack([np.arange(shard_max * 6, dtype=np.float32).reshape(shard_max, 2, 3) + 1000.0 * r for r in range(world)])
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("chunk_rank"))
+    assert files == ([f"chunk_rank{r}.npy" for r in range(world)] if mode == "all" else ["chunk_rank0.npy"])
+    for f in files:
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), f)), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,corpus", [("root", 2048), ("all", 1001)])
+def test_bench_cfg4_strong_sharding_two_ranks(mode, corpus):
+    """`bench.py --workload cfg4 --gpus 2` at a reduced corpus (--corpus-clips keeps strong scaling; --clips would switch it
+    off): contiguous shards (uneven for 1001), each computed and gathered in 8 chunks.  Two ranks share the one device here, so
+    the collective runs over gloo: control flow only, no scaling claim."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg4", "--corpus-clips", str(corpus),
+                        "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--prewarm-ms", "0", "--gather-mode", mode],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["value_path_only"] > 0
+    assert d["config"]["clips_per_gpu"] == (corpus + 1) // 2
+    g = d["gather"]
+    assert g["mode"] == mode and g["chunks_per_step"] == 8 and g["collectives_timed"] == 4 * 8
+    m = d["scaling_model"]
+    assert 0 < m["path_only_efficiency"] <= 1.5 and m["gather_bound_frames_per_s"] > 0 and "unmeasured" in m["note"]
+    # frames per step = the whole corpus, whatever the shard sizes
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - corpus * d["config"]["frames_per_clip"]) < 1e-6 * corpus * 98
+
+
 def test_abi_shard_bounds_matches_the_python_partition(sslib):
     import ctypes as C
 

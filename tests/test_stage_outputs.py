@@ -27,6 +27,16 @@ def test_oracle_power_spectrum_frames_is_rfft_magnitude_over_n(oracle):
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
 
 
+def test_python_stack_frames_rejects_the_old_positional_flag(sslib):
+    """Round 3's stack_frames had zero_padding where the reference has `filter` (processing.rs:65-76): an old positional call
+    gets a clear TypeError before anything is indexed or launched (no device needed)."""
+    import speechsauce_amd as ss
+
+    x = _signal(1, 4000)
+    with pytest.raises(TypeError, match="filter"):
+        ss.stack_frames(x, 16000, 0.02, 0.01, True)
+
+
 def test_oracle_stack_frames_contract_and_padded(oracle):
     x = _signal(3, 16000)
     p = oracle.make_params()
@@ -258,11 +268,25 @@ def _on_lab_test_mel_build_switch_is_bit_identical(ss, sslib):
 
 
 @pytest.mark.gpu
-def test_mel_build_switch_is_bit_identical(ss, sslab):
-    """Runs on the LAB library (the build selection / fault aids it needs are not in the product library): the front is
-    switched to it for the duration."""
+def test_mel_build_switch_is_bit_identical(ss, sslib, sslab):
+    """The build switch is a LAB aid, so the builds are compared there; the PRODUCT library's own twelve-wave kernel (compiled
+    without the lab switches) must then give the lab build's bits for the same batch."""
+    import torch
+
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    x = torch.from_numpy(_signal(9, (2 * ncu + 5, 16000))).cuda()
+    kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+    prod = ss.mel_spectrogram(x, 16000, **kw)
+    assert sslib.ss_last_kernel_name() == b"ss_mel_c1024<w12,mel6321>"
     with ss._lib.use_library(sslab):
         _on_lab_test_mel_build_switch_is_bit_identical(ss, sslab)
+        try:
+            sslab.ss_debug_mel_tile(3)
+            lab = ss.mel_spectrogram(x, 16000, **kw)
+            assert sslab.ss_last_kernel_name() == b"ss_mel_c1024<w12,mel6321>"
+        finally:
+            sslab.ss_debug_mel_tile(1)
+    assert torch.equal(prod, lab)
 
 
 @pytest.mark.gpu

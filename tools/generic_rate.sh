@@ -1,5 +1,5 @@
 #!/bin/bash
-# generic kernel on the three BASELINE shapes (SS_FORCE_GENERIC=1): us per launch
+# generic kernel on the three BASELINE shapes (--force-generic): us per launch
 for w in cfg2 cfg3 cfg5; do
-  SS_FORCE_GENERIC=1 python bench.py --workload $w --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['roofline']['kernel'], round(d['roofline']['avg_launch_us'],1), 'us')"
+  python bench.py --force-generic --workload $w --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['roofline']['kernel'], round(d['roofline']['avg_launch_us'],1), 'us')"
 done

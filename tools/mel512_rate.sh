@@ -2,6 +2,6 @@
 # mel_spectrogram at fft_points = 512 (16 kHz, 16 ms chunks, 40 mels) on 1024 x 1 s clips: ss_mel_c256 vs the generic kernel
 P='{"fft_points": 512, "frame_length": 0.016, "frame_stride": 0.016, "num_filters": 40}'
 for g in 0 1; do
-  if [ $g = 1 ]; then export SS_FORCE_GENERIC=1; fi
-  python bench.py --workload cfg3 --params "$P" --steps 500 --warmup 50 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel'], round(d['roofline']['avg_launch_us'],1), 'us', round(d['roofline']['frac'],3))"
+  G=""; if [ $g = 1 ]; then G="--force-generic"; fi
+  python bench.py $G --workload cfg3 --params "$P" --steps 500 --warmup 50 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel'], round(d['roofline']['avg_launch_us'],1), 'us', round(d['roofline']['frac'],3))"
 done

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -5
+( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/r05/bench_default.json 2> gpurun_out/r05/bench_default.err
+tail -3 gpurun_out/r05/bench_default.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r05/bench_default.json').read().strip().splitlines()[-1])
+r=d['roofline']; print('headline', r['kernel'], round(r['avg_launch_us'],2), 'frac', round(r['frac'],4), 'clk', r.get('clock_ghz_measured'), 'cyc', r.get('cycles_per_launch'), 'valu', r.get('valu_floor_frac'))
+print('pipelined', d.get('value_pipelined'), d.get('pipelined'))
+for k,v in (d.get('secondary') or {}).items(): print(k, {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a not in ('workload','traffic_source')})
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['sample'])
+PY
+SS_LIB_PATH=$PWD/ab/lib_prof5.so python tools/prof5.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05/phase_profile_cfg5_base.txt
