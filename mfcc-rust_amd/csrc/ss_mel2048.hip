@@ -56,11 +56,47 @@ using namespace wv;
 #define SS_P_MEL 1
 #endif
 #define SS_P_FFT 0
+// Fair shares for the three waves of a SIMD -- measured in round 5 and NOT kept (lab builds: -DSS_FAIR=1 boosts among butterflies
+// only, =2 every phase).  Among waves of equal priority the arbiter takes the OLDEST first, and the unit timeline of cfg3
+// (tools/prof3.py, profiles/r05/unit_timeline_cfg3*.txt) shows three speed classes by dispatch order: waves 0-3 / 4-7 / 8-11 of a
+// workgroup take 5.3 / 5.8 / 6.3 us of compute and 1.55 / 1.8 / 2.2 us of waiting for samples per unit, so the oldest end 2 us
+// before the youngest.  Raising a wave's priority by one step in some of its units (youngest class in two of every three units,
+// middle class in one, oldest never: every wave first, second and third once) does equalise them when it applies to every phase
+// -- at 6.1 us of compute and 2.2 us of waiting for ALL classes: the boosted butterflies tie with the other waves' LDS phases,
+// which is what the phase priorities exist to prevent (cfg3 49.0 us against 45.0).  Among butterflies only it changes neither
+// the classes nor the time (45.8 against 45.4).
+#if SS_LAB && defined(SS_FAIR)
+#if SS_FAIR == 2
+#define SS_PRIOL(x) do { if (boost) __builtin_amdgcn_s_setprio((x) < 3 ? (x) + 1 : 3); else __builtin_amdgcn_s_setprio(x); } while (0)
+#else
+#define SS_PRIOL(x) do { if ((x) == 0) { if (boost) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } \
+                         else __builtin_amdgcn_s_setprio((x) >= 3 ? 3 : 2); } while (0)
+#endif
+#else
 #define SS_PRIOL(x) __builtin_amdgcn_s_setprio(x)
+#endif
 namespace L = mel2048_layout;
 constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
+
+// Row pairs of a clip a mel build spends a unit on.  Every pair, the trailing all-zero ones (functions.rs:121) included.
+// Round 5 measured the alternative (lab builds, -DSS_ZSKIP=1): only the pairs that hold a real row are units and the wave that
+// owns a clip's last one writes the zeros behind it -- cfg3: 15 units per clip instead of 16, 60 per CU instead of 64, 6.6 % fewer
+// VALU and LDS instructions (profiles/r05/pmc_cfg3_zskip.txt) -- and the launch takes 0.7 - 1.5 us LONGER on four boxes, on
+// zeros as on noise (profiles/r05/ab_cfg3_zskip.txt, power_cfg3_zskip.txt).  Why (unit timeline, tools/prof3.py): a CU's twelve
+// waves run in three speed classes and a unit is 7 - 8.5 us; with 64 units the four all-zero ones (no sample wait) are taken by
+// whichever waves finish first and run under the slow waves' last units, with 60 there is nothing to take and the launch still
+// waits for a young wave's fifth unit.  The zero units were free filler; the tail is one unit long either way.
+__host__ __device__ inline unsigned mel_work_pairs(unsigned rows, unsigned real_rows)
+{
+    const unsigned w = (real_rows + 1) / 2, all = (rows + 1) / 2;
+#if SS_LAB && defined(SS_ZSKIP)
+    return w == 0 ? (all ? 1u : 0u) : (w < all ? w : all);
+#endif
+    (void)w;
+    return all;
+}
 
 template <int kWavesM, bool STFT, bool FULLP = false>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
@@ -93,7 +129,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
         const int n4 = (L::kMelW + 32 * a.mel_wpitch + 4) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
         if (tid == 0) {
-            const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+            const unsigned long long units0 = static_cast<unsigned long long>(a.batch) * (STFT ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows));
             *s_next = static_cast<unsigned>(units0 * blockIdx.x / gridDim.x) + kWavesM;
         }
     }
@@ -112,7 +148,9 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 
     // work unit: two consecutive rows of one clip; the workgroup owns a contiguous range of units and its waves
     // pull them from an LDS counter
-    const unsigned pairs = (a.rows + 1) / 2;
+    // (mel builds: only the pairs that hold a real row are units; the wave that owns a clip's last one writes the zeros of the rows
+    // behind it -- see ss_mel_c1024_w12)
+    const unsigned pairs = STFT ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows);
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
     const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
     const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
@@ -323,6 +361,14 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         off += a.mel_q4[s];
                     }
                 }
+                if (unit - (unit / pairs) * pairs == pairs - 1) {  // the clip's last working pair: the all-zero rows behind it
+                    float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+                    for (int rz = r + 2; rz < R; rz += 2) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R + (rz - r)] = 0.f;
+                    }
+                }
                 wave_order();
             }
         }
@@ -353,7 +399,8 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     const int wave = tid >> 6;
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
-    const unsigned pairs = (a.rows + 1) / 2;
+    // Row pairs per clip that are units: all of them (see mel_work_pairs for the measured alternative)
+    const unsigned pairs = (STFT || ROWS4) ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows);
     // work items: units (row pairs), or pairs of units (ROWS4)
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs / (ROWS4 ? 2 : 1);
     const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
@@ -368,7 +415,22 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     const int R = static_cast<int>(a.rows), Rreal = static_cast<int>(a.real_rows);
     const int M = static_cast<int>(a.n_filters);
 
+#if SS_LAB && defined(SS_PROF3)
+    // unit timeline (lab builds, tools/prof3.py): lane 0 of every wave stamps the 100 MHz clock at the top of a unit, once its samples
+    // have arrived and at its end, into 32 words per wave BEHIND the output block (the tool allocates them); word 0 = units | XCC << 32
+    unsigned long long *p3 = reinterpret_cast<unsigned long long *>(a.out + static_cast<unsigned long long>(a.batch) * a.n_filters * a.rows) +
+                             32ull * (blockIdx.x * kWavesM + wave);
+    unsigned p3n = 0;
+#define SS_P3(k) do { if ((threadIdx.x & 63) == 0 && p3n < 10) p3[1 + 3 * p3n + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SS_P3(k) do { } while (0)
+#endif
     unsigned item = u_lo + wave;
+#if SS_LAB && defined(SS_FAIR)
+    const int age = __builtin_amdgcn_readfirstlane(wave) >> 2;  // 0: dispatched first (the oldest wave of its SIMD) .. 2: last
+    unsigned nunit = 0;                                         // units this wave has started (uniform)
+    bool boost = age == 2;
+#endif
     SS_PRIOL(SS_P_TOP);
     while (item < u_hi) {
       // the claim of the next item is issued here and read at the end of the iteration
@@ -378,6 +440,13 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #pragma unroll 1
       for (int sub = 0; sub < (ROWS4 ? 2 : 1); ++sub) {
         const unsigned unit = ROWS4 ? 2 * item + sub : item;
+#if SS_LAB && defined(SS_FAIR)
+        {
+            const unsigned ph = nunit % 3u;
+            boost = age == 2 ? ph != 2u : (age == 1 ? ph == 1u : false);
+            ++nunit;
+        }
+#endif
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
         const int lane = lane_it & 63;     // (the mask tells the compiler the range again: 24-bit multiplies, no sign extensions)
@@ -391,6 +460,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         const unsigned clip = unit / pairs;
         const int r = static_cast<int>(unit - clip * pairs) * 2 + half;
         const bool in_rows = r < R;
+        SS_P3(0);
         // ---- the window of this half-wave's row (functions.rs:137-151: the last W samples ending at chunk r + n_pad) ----
         float2 v[32];
         {
@@ -414,7 +484,13 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 const unsigned clip_s = unit_s / pairs;
                 const long long start0 = static_cast<long long>((unit_s - clip_s * pairs) * 2 + a.n_pad + 1) * static_cast<long long>(a.hop) - 2048;
                 const char *sb = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>(clip_s) * a.ld) + start0 * 4;
+#if SS_LAB && defined(SS_ABL3B)
+                // (timing attribution, lab builds, results wrong by design: both half-waves load the first row's window -- half the
+                // lines per load instruction, no line asked for twice by one wave)
+                const unsigned so = static_cast<unsigned>(j) * 8u;
+#else
                 const unsigned so = static_cast<unsigned>(half) * a.hop * 4u + static_cast<unsigned>(j) * 8u;
+#endif
                 unsigned so2[2] = {so, so + 4096u};  // (a 32-bit lane offset per 4096 bytes, pinned: left alone the second half's addresses become 64-bit VALU sums)
                 asm volatile("" : "+v"(so2[1]));
 #pragma unroll
@@ -443,6 +519,10 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 }
             }
         }
+#if SS_LAB && defined(SS_PROF3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SS_P3(1);
+#endif
         // Vorbis window (config.rs:151-160): two batches of eight reads, each in front of its products
 #pragma unroll
         for (int eb = 0; eb < 16; eb += 8) {
@@ -612,18 +692,36 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                     buf_store(make_float4(a0, b0, c0, d0), ors, f0 >= 0 ? f0 * R * 4 + r4 : kOobOffset);
                     buf_store(make_float4(a1, b1, c1, d1), ors, f1 >= 0 ? f1 * R * 4 + r4 : kOobOffset);
                 }
-            } else if (in_rows) {
+            } else {
                 float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+                if (in_rows) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = mv[s];
+                    for (int s = 0; s < 4; ++s)
+                        if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = mv[s];
+                }
+                // the clip's last working pair: the all-zero rows behind it (uniform branch: one pair per wave)
+                const unsigned unit_z = __builtin_amdgcn_readfirstlane(unit);
+                if (unit_z - (unit_z / pairs) * pairs == pairs - 1) {
+                    for (int rz = r + 2; rz < R; rz += 2) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R + (rz - r)] = 0.f;
+                    }
+                }
             }
         }
         wave_order();
         SS_PRIOL(SS_P_TOP);
+#if SS_LAB && defined(SS_PROF3)
+        SS_P3(2);
+        ++p3n;
+#endif
       }
       item = __builtin_amdgcn_readfirstlane(next_v);
     }
+#if SS_LAB && defined(SS_PROF3)
+    if ((threadIdx.x & 63) == 0) p3[0] = p3n | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20)) << 32);
+#endif
 }
 
 template <int kWavesM>
@@ -633,7 +731,7 @@ hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, L
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (a.batch == 0) return hipSuccess;
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
-    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * (a.out_stft ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows));
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
     unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
@@ -661,7 +759,9 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
     const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
-    const unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
+    // (the mel builds enumerate working pairs only: see the kernel)
+    const unsigned long long work = a.out_stft ? units : static_cast<unsigned long long>(a.batch) * mel_work_pairs(a.rows, a.real_rows);
+    const unsigned long long blocks = (work + kWavesM - 1) / kWavesM;
     const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
     auto go = [&](auto kern, const char *name) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -699,7 +799,7 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * (a.out_stft ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows));
     const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
 #if SS_LAB
     // lab library: ss_debug_mel_tile(2) asks for the eight-wave builds only -- the retired whole-line tile

@@ -97,9 +97,12 @@ def run(name, xs):
     p = [s[0] / 1e6 for s in samples[5:] if s[0]]
     f = [s[1] / 1e6 for s in samples[5:] if s[1]]
     mp = sum(p) / len(p) if p else None
-    print("%-6s %6.2f us per launch | power W: mean %s max %s | sclk MHz: mean %s min %s | energy per launch %s mJ | kernel %s" % (
+    # shader clock by the library's one-wave probe beside the same launches (s_memtime / s_memrealtime): cycles per launch
+    clk = bench.probe_clock(torch, lib, lambda i: launch(xs[i % len(xs)]), us * 1e-6, torch.device("cuda", 0), probe_us=4000)
+    print("%-6s %6.2f us per launch | power W: mean %s max %s | sclk MHz: mean %s min %s | energy per launch %s mJ | probe clock %s GHz -> %s k cycles per launch | kernel %s" % (
         name, us, round(mp) if p else None, round(max(p)) if p else None, round(sum(f) / len(f)) if f else None,
-        round(min(f)) if f else None, round(mp * us * 1e-3, 1) if p else None, lib.ss_last_kernel_name().decode()))
+        round(min(f)) if f else None, round(mp * us * 1e-3, 1) if p else None, round(clk, 3) if clk else None,
+        round(us * clk, 1) if clk else None, lib.ss_last_kernel_name().decode()))
 
 
 n_buf = max(2, -(-300 * 1024 * 1024 // (4 * clips * n_samples)))
