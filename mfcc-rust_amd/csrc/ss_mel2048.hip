@@ -361,6 +361,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         off += a.mel_q4[s];
                     }
                 }
+#if SS_LAB && defined(SS_ZSKIP)
                 if (unit - (unit / pairs) * pairs == pairs - 1) {  // the clip's last working pair: the all-zero rows behind it
                     float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
                     for (int rz = r + 2; rz < R; rz += 2) {
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                             if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R + (rz - r)] = 0.f;
                     }
                 }
+#endif
                 wave_order();
             }
         }
@@ -403,8 +405,29 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     const unsigned pairs = (STFT || ROWS4) ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows);
     // work items: units (row pairs), or pairs of units (ROWS4)
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs / (ROWS4 ? 2 : 1);
-    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
-    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    // Work distribution.  Without a pool: the workgroup owns a contiguous range of units, its waves pull them from an LDS counter.
+    // With one (mel output): seven eighths of a workgroup's even share stay such a static range (neighbouring units share three
+    // quarters of their samples: L1 / L2 locality); the remaining units of the launch form a POOL, in eight shards (workgroup b
+    // pulls from shard b % 8: one XCD under the round-robin placement -- for speed only), each shard one counter word in device
+    // memory.  A wave whose workgroup has run out of static units goes on with pool units, so workgroups that are ahead (CU end
+    // times within one launch spread by 2 - 3 us: profiles/r05/unit_timeline_cfg3.txt) take work from the ones that are behind
+    // instead of idling until the launch's last unit ends.  The claim of a pool unit is a returning device-scope atomic issued a
+    // whole unit ahead of its use (behind nothing the wave waits for), so its microsecond of latency is never exposed.
+    const bool pooled = !STFT && !ROWS4 && a.pool != nullptr;
+    unsigned u_lo, u_hi, p_lo = 0, p_hi = 0;
+    unsigned *g_next = nullptr;
+    if (pooled) {
+        const unsigned share = static_cast<unsigned>(units / gridDim.x) * 7u / 8u;
+        u_lo = blockIdx.x * share;
+        u_hi = u_lo + share;
+        const unsigned pool0 = gridDim.x * share, pn = static_cast<unsigned>(units) - pool0, shard = blockIdx.x & 7u;
+        p_lo = pool0 + static_cast<unsigned>(static_cast<unsigned long long>(pn) * shard / 8u);
+        p_hi = pool0 + static_cast<unsigned>(static_cast<unsigned long long>(pn) * (shard + 1u) / 8u);
+        g_next = a.pool + 32u * shard;  // (a 128-byte line per shard)
+    } else {
+        u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+        u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
+    }
     {
         const int n4 = (L::kMelW + 32 * a.mel_wpitch + 4) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
@@ -426,16 +449,28 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #define SS_P3(k) do { } while (0)
 #endif
     unsigned item = u_lo + wave;
+    bool in_pool = false;  // (uniform) this wave's claims go to the pool
+    if (pooled && item >= u_hi) {
+        // (a static share smaller than the wave count: this wave starts in the pool, with the one claim whose latency shows)
+        in_pool = true;
+        unsigned g = 0;
+        if ((threadIdx.x & 63) == 0) g = atomicAdd(g_next, 1u);
+        item = p_lo + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(g));
+    }
 #if SS_LAB && defined(SS_FAIR)
     const int age = __builtin_amdgcn_readfirstlane(wave) >> 2;  // 0: dispatched first (the oldest wave of its SIMD) .. 2: last
     unsigned nunit = 0;                                         // units this wave has started (uniform)
     bool boost = age == 2;
 #endif
     SS_PRIOL(SS_P_TOP);
-    while (item < u_hi) {
+    while (item < (in_pool ? p_hi : u_hi)) {
       // the claim of the next item is issued here and read at the end of the iteration
       unsigned next_v = 0;
-      if ((static_cast<int>(threadIdx.x) & 63) == 0) next_v = atomicAdd(s_next, 1u);
+      bool next_pool = in_pool;  // (uniform) next_v will hold an index into the pool shard
+      if ((static_cast<int>(threadIdx.x) & 63) == 0) {
+          if (in_pool) next_v = atomicAdd(g_next, 1u);
+          else next_v = atomicAdd(s_next, 1u);
+      }
       float mva[4] = {0.f, 0.f, 0.f, 0.f};  // ROWS4: the first unit's mel values
 #pragma unroll 1
       for (int sub = 0; sub < (ROWS4 ? 2 : 1); ++sub) {
@@ -535,6 +570,14 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 const int e = 2 * (eb + i);
                 v[e] = make_float2(v[e].x * w[i].x, v[e].y * w[i].y);
                 v[e + 1] = make_float2(v[e + 1].x * w[i].z, v[e + 1].y * w[i].w);
+            }
+        }
+        if (pooled && !in_pool) {
+            // the static range's claim has long returned (the window reads above waited behind it): when it is past the end,
+            // this wave's next unit comes from the pool -- asked for now, needed at the end of this unit
+            if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)) >= u_hi) {
+                in_pool = next_pool = true;
+                if ((threadIdx.x & 63) == 0) next_v = atomicAdd(g_next, 1u);
             }
         }
         // ---- 1024-point complex FFT: radix-32, transpose through LDS in two register halves, twiddle, radix-32 ----
@@ -699,6 +742,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                     for (int s = 0; s < 4; ++s)
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = mv[s];
                 }
+#if SS_LAB && defined(SS_ZSKIP)
                 // the clip's last working pair: the all-zero rows behind it (uniform branch: one pair per wave)
                 const unsigned unit_z = __builtin_amdgcn_readfirstlane(unit);
                 if (unit_z - (unit_z / pairs) * pairs == pairs - 1) {
@@ -708,6 +752,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                             if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R + (rz - r)] = 0.f;
                     }
                 }
+#endif
             }
         }
         wave_order();
@@ -717,7 +762,19 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         ++p3n;
 #endif
       }
-      item = __builtin_amdgcn_readfirstlane(next_v);
+      item = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)) + (next_pool ? p_lo : 0u);
+    }
+    if (pooled) {
+        // the launch's last workgroup leaves the pool words at zero for the next launch that is handed this slot (every claim of
+        // every workgroup has returned by the time its `done` increment is issued)
+        __syncthreads();
+        if (tid == 0) {
+            unsigned *done = a.pool + 32u * 8u;
+            if (atomicAdd(done, 1u) == gridDim.x - 1u) {
+                for (int x = 0; x < 8; ++x) atomicExch(a.pool + 32 * x, 0u);
+                atomicExch(done, 0u);
+            }
+        }
     }
 #if SS_LAB && defined(SS_PROF3)
     if ((threadIdx.x & 63) == 0) p3[0] = p3n | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20)) << 32);

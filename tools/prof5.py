@@ -21,3 +21,12 @@ print("waves", len(w), "frames/wave mean", it.mean(), "loop cycles/frame", (w[:,
 tot = w[:, 11].astype(float).sum()
 for k in range(1, 11):
     print(f"{names[k]:10s} share {w[:, k].astype(float).sum() / tot:6.3f}   cycles/frame {(w[:, k] / it).mean():8.0f}")
+# by wave index within the workgroup (12 waves; 0-3 dispatched first = the oldest wave of each SIMD): frames done, cycles per
+# frame, main-loop lifetime -- the three speed classes of profiles/r05/unit_timeline_cfg3*.txt, and what the tail looks like
+w12 = w[: (len(w) // 12) * 12].reshape(-1, 12, 16).astype(float)
+print("by wave index: frames        ", [round(w12[:, k, 0].mean(), 2) for k in range(12)])
+print("by wave index: cycles/frame  ", [int(round((w12[:, k, 11] / w12[:, k, 0]).mean())) for k in range(12)])
+print("by wave index: loop k cycles ", [round(w12[:, k, 11].mean() / 1e3, 1) for k in range(12)])
+print("slowest wave of a CU is index", np.bincount(w12[:, :, 11].argmax(axis=1), minlength=12).tolist(),
+      "| CU loop k cycles p10 p50 p90 max", [round(float(x) / 1e3, 1) for x in np.percentile(w12[:, :, 11].max(axis=1), [10, 50, 90, 100])],
+      "| sum of wave loops / 12:", round(w12[:, :, 11].sum(axis=1).mean() / 12e3, 1))
