@@ -24,7 +24,7 @@ cfg4 (the 100 h corpus, 360 000 clips) is the one strong-scaling workload: the c
 contiguous clip shards (speechsauce_amd.distributed.shard_bounds), one launch per shard per step.
 
 A default N = 1 run (headline workload, no measurement switches) also times, after the headline region and outside it, the other
-BASELINE configurations -- `secondary.cfg3`, `secondary.cfg5` (200 steps each) and `secondary.cfg4` (the whole 360 000-clip corpus
+BASELINE configurations -- `secondary.cfg3`, `secondary.cfg5` (1000 steps each) and `secondary.cfg4` (the whole 360 000-clip corpus
 in one launch, 5 steps) -- and the headline workload once more with successive steps alternating over two HIP streams
 (`value_pipelined`: one launch's tail under the next one's head; whole-job throughput, not a kernel duration and no part of `roofline`).
 
@@ -254,20 +254,36 @@ def load_pmc(workload):
         return None
 
 
-def probe_clock(torch, lib, step, avg_s, device, probe_us=2000):
-    """Shader clock (GHz) the device holds while `step` launches run: enough launches for ~3 probe lengths go out on the launch
-    stream, then the library's one-wave probe (ss_shader_clock_probe: s_memtime against the 100 MHz s_memrealtime, asleep in
-    between) runs on a side stream beside them.  Outside every timed region.  None when the probe fails."""
-    side = torch.cuda.Stream(device=device)
-    n = max(8, int(3 * probe_us * 1e-6 / max(avg_s, 1e-6)))
-    for i in range(n // 4):  # the probe starts once the load is established
-        step(i)
-    g = C.c_float(0.0)
-    for i in range(n - n // 4):
-        step(i)
-    rc = lib.ss_shader_clock_probe(C.c_void_p(side.cuda_stream), int(probe_us), C.byref(g))
-    torch.cuda.synchronize()
-    return float(g.value) if rc == 0 and g.value > 0 else None
+def probe_clock(torch, lib, step, avg_s, device, probe_us=2000, want=3):
+    """Shader clock (GHz) the device holds while `step` launches run: the median of `want` accepted readings of the library's
+    one-wave probe (ss_shader_clock_probe_async: s_memtime against the 100 MHz s_memrealtime, asleep in between, a lead-in not
+    counted).  Each probe is queued on a fresh side stream FIRST and enough launches to outlast it follow at once on the launch
+    stream: the probe wave is resident before they start and reads the clock under their load.  A reading is ACCEPTED only if
+    the launches took no longer than they do alone: HIP multiplexes streams onto a few hardware queues, and a side stream that
+    shares the launch stream's queue makes the launches wait behind the sleeping probe, which then reads the idle clock (2.4 GHz;
+    tools/probe_test.py, profiles/r05/clock_probe_check.txt).  Outside every timed region.  None if no reading was accepted."""
+    n = max(8, int(2.5 * probe_us * 1e-6 / max(avg_s, 1e-6)))
+    words = torch.zeros((3 * want, 2), dtype=torch.int64, device=device)
+    got = []
+    for t in range(3 * want):
+        if len(got) >= want:
+            break
+        side = torch.cuda.Stream(device=device)
+        for i in range(min(n, 200)):  # the load is established and the clock has settled before the probe goes out
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = lib.ss_shader_clock_probe_async(C.c_void_p(side.cuda_stream), int(probe_us), C.c_void_p(words[t].data_ptr()))
+        for i in range(n):
+            step(i)
+        torch.cuda.current_stream().synchronize()
+        alone = (time.perf_counter() - t0) <= 1.2 * n * avg_s + 100e-6
+        torch.cuda.synchronize()
+        w = words[t].tolist()
+        if rc == 0 and alone and w[1] > 0 and 0.3 < w[0] / (10.0 * w[1]) < 2.6:
+            got.append(w[0] / (10.0 * w[1]))
+    got.sort()
+    return got[len(got) // 2] if got else None
 
 
 def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=300.0, streams=1, probe_board=True, ring_mib=300):
@@ -700,6 +716,11 @@ def main():
         rc = lib.ss_mfcc_shader_clock(cfg.handle, xs[0].data_ptr(), clips, n_samples, n_samples, outs[0].data_ptr(), sptr, 30, C.byref(g))
         if rc == 0 and g.value > 0:
             clock_ghz = float(g.value)
+    clock_source = "in-kernel stamps of the same launches (ss_mfcc_shader_clock)"
+    if clock_ghz is None and world == 1 and args.streams == 1:
+        # every other kernel: the library's one-wave probe beside more launches of the same step (ss_shader_clock_probe)
+        clock_ghz = probe_clock(torch, lib, lambda i: Region(False).step(i), dev_ms * 1e-3 / args.steps, device)
+        clock_source = "one-wave probe beside the same launches (ss_shader_clock_probe)"
 
     if rank == 0:
         kernel = lib.ss_last_kernel_name().decode()
@@ -805,6 +826,7 @@ def main():
         if clock_ghz is not None:
             rf = res["roofline"]
             rf["clock_ghz_measured"] = clock_ghz
+            rf["clock_source"] = clock_source
             # shader cycles per launch: the figure to compare between boxes / rounds (boxes hold 1.9-2.25 GHz at the power cap)
             rf["cycles_per_launch"] = avg_launch_s * 1e9 * clock_ghz
             if rf.get("valu_insts_per_launch"):
@@ -823,7 +845,8 @@ def main():
                                 "note": "same workload, successive steps alternate over two HIP streams (independent batches): one launch's tail "
                                         "runs under the next one's head; wall time per step, not a kernel duration, not part of `roofline`"}
             res["secondary"] = {}
-            for wl, st, wu in (("cfg3", 200, 20), ("cfg5", 200, 20), ("cfg4", 5, 1)):
+            # (1000 steps, 50 - 60 ms each: regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
+            for wl, st, wu in (("cfg3", 1000, 100), ("cfg5", 1000, 100), ("cfg4", 5, 1)):
                 try:
                     res["secondary"][wl] = measure_simple(torch, ss, wl, device, steps=st, warmup=wu, prewarm_ms=300.0)
                 except Exception as e:  # a secondary line must never take the headline down with it

@@ -291,13 +291,20 @@ int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_
 int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_out,
                          void *stream, int launches, float *ghz);
 
-/* Shader clock (GHz) of the device while WHATEVER ELSE runs on it: one wave on `stream` reads the shader-cycle counter and the
- * constant 100 MHz counter, sleeps (no memory traffic, no LDS, a handful of registers) for about `micros` microseconds and reads
- * both again; *ghz = cycles / time.  Launch the kernels of interest on their own stream first and call this with a side stream:
- * the probe wave fits beside the persistent workgroups (they leave wave slots free) and sees the clock the part holds under that
- * load (the power cap).  Works for every kernel of the library (bench.py's secondary.*.clock_ghz_measured);
- * synchronises `stream` only.  10 <= micros <= 1 000 000. */
+/* Shader clock (GHz) of the device while WHATEVER ELSE runs on it: one wave on `stream` sleeps through a lead-in (a tenth of
+ * `micros`, at most 200 us), reads the shader-cycle counter and the constant 100 MHz counter, sleeps (no memory traffic, no LDS,
+ * a handful of registers) for about `micros` microseconds and reads both again; *ghz = cycles / time.  Call it on a side stream
+ * FIRST (from a thread of its own: the call blocks) and launch the kernels of interest on their stream right behind it: the
+ * probe wave is resident before they start, fits beside the persistent workgroups (they leave wave slots free) and sees the
+ * clock the part holds under that load (the power cap).  Enqueued BEHIND a backlog of launches it may only start
+ * when the backlog has drained and read the idle clock; the call may also return only once the other stream is idle.  Works
+ * for every kernel of the library (bench.py's clock_ghz_measured where a kernel has no stamps of its own; checked against the
+ * 512-point kernel's own stamps in profiles/r05/clock_probe_check.txt).  10 <= micros <= 1 000 000. */
 int ss_shader_clock_probe(void *stream, uint32_t micros, float *ghz);
+/* The same probe without the wait: queues the one-wave kernel on `stream` and returns; when the stream has run it,
+ * d_words[0] = shader cycles and d_words[1] = ticks of the 100 MHz counter over the counted interval (GHz = d_words[0] /
+ * (10 * d_words[1])).  `d_words`: two 64-bit words of device memory.  This is the form to queue AHEAD of the launches to watch. */
+int ss_shader_clock_probe_async(void *stream, uint32_t micros, unsigned long long *d_words);
 
 /* Process-wide test aids (LDS poisoning, kernel-selection overrides, fault injection, a stamp buffer) are NOT part of this
  * library: include/speechsauce_amd_debug.h, exported by the lab build libspeechsauce_amd_lab.so only. */

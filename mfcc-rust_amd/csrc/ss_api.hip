@@ -1663,13 +1663,22 @@ int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, s
 
 namespace {
 // One wave: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over about `ticks` of the latter,
-// asleep in between (s_sleep: no issue slots, no memory traffic -- the workload beside it is not disturbed).
+// asleep in between (s_sleep: no issue slots, no memory traffic -- the workload beside it is not disturbed).  A lead-in of a
+// tenth of the interval (at most 200 us) is slept through first and not counted: a probe launched just ahead of the load it is
+// meant to watch does not average the idle clock of those first microseconds in.
 static __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, unsigned ticks)
 {
     if (threadIdx.x != 0) return;
+    const unsigned lead = ticks / 10u < 20000u ? ticks / 10u : 20000u;
+    unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl = t;
+    while (t - tl < lead) {
+        __builtin_amdgcn_s_sleep(64);
+        t = __builtin_amdgcn_s_memrealtime();
+    }
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long t = t0;
+    t = t0;
     while (t - t0 < ticks) {
         __builtin_amdgcn_s_sleep(64);
         t = __builtin_amdgcn_s_memrealtime();
@@ -1680,6 +1689,14 @@ static __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long lo
     out[1] = t1 - t0;
 }
 }  // namespace
+
+int ss_shader_clock_probe_async(void *stream, uint32_t micros, unsigned long long *d_words)
+{
+    if (!d_words || micros < 10 || micros > 1000000) return ss::fail(SS_ERR_ARG, "bad clock probe request");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_words, micros * 100u);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
 
 int ss_shader_clock_probe(void *stream, uint32_t micros, float *ghz)
 {

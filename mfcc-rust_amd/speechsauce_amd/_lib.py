@@ -126,6 +126,7 @@ PROTOTYPES = {
     "ss_time_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_mfcc_shader_clock": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p, C.c_int, _P(C.c_float)]),
     "ss_shader_clock_probe": (C.c_int, [C.c_void_p, C.c_uint, _P(C.c_float)]),
+    "ss_shader_clock_probe_async": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p]),
     "ss_stack_frames_shape": (C.c_int, [C.c_size_t, C.c_uint32, C.c_float, C.c_float, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
     "ss_stack_frames_signal": (C.c_int, [_fp, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp]),
     "ss_stack_frames_signal_device": (C.c_int, [_fp, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _fp, C.c_int, _fp, C.c_void_p]),

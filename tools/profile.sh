@@ -7,10 +7,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline $@"
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary $@"
 # the kernel trace runs bench.py's default step counts, so its average matches the bench line's HIP-event average
 rm -rf $OUT/trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/trace.log 2>&1
 [ "$TRACE_ONLY" = 1 ] && { ls $OUT/trace/*/*kernel_stats.csv; exit 0; }
 i=0
 for set in \
