@@ -528,8 +528,18 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #endif
                 unsigned so2[2] = {so, so + 4096u};  // (a 32-bit lane offset per 4096 bytes, pinned: left alone the second half's addresses become 64-bit VALU sums)
                 asm volatile("" : "+v"(so2[1]));
+#if SS_LAB && defined(SS_NTLOAD)
+                // (A/B, lab builds: sample loads with the non-temporal hint)
+                typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(sb + so2[e / 16] + 256u * (e % 16)));
+                    v[e] = make_float2(t.x, t.y);
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 32; ++e) v[e] = *reinterpret_cast<const float2 *>(sb + so2[e / 16] + 256u * (e % 16));
+#endif
 #endif
             } else {
                 // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows: see ss_mel_c1024
@@ -740,7 +750,11 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 if (in_rows) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
+#if SS_LAB && defined(SS_NTSTORE)
+                        if (fi[s] >= 0) __builtin_nontemporal_store(mv[s], &dst[static_cast<unsigned long long>(fi[s]) * R]);  // (A/B, lab builds)
+#else
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = mv[s];
+#endif
                 }
 #if SS_LAB && defined(SS_ZSKIP)
                 // the clip's last working pair: the all-zero rows behind it (uniform branch: one pair per wave)

@@ -171,6 +171,10 @@ def test_bench_launches_its_own_ranks(mode):
     assert g and g["mode"] == mode and g["bucket_steps"] >= 1 and g["achieved_gbps_per_link"] > 0 and g["collectives_timed"] >= 1
     assert d["backend"] in ("nccl", "gloo")
     assert d["rccl_ranks"] == (2 if d["backend"] == "nccl" else 0)
+    # the N > 1 line says how to read itself: the path alone against N independent runs, and what one xGMI link per rank allows
+    m = d["scaling_model"]
+    assert m["gather_bound_frames_per_s"] == pytest.approx(2 * m["link_gbps_assumed_one_way"] * 1e9 / (4 * 13))
+    assert 0 < m["path_only_efficiency"] <= 1.5 and "unmeasured" in m["note"]
 
 
 def _chunk_worker(rank, world, port, shard_max, chunks, mode, result_dir):

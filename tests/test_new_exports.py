@@ -157,6 +157,35 @@ def test_shader_clock_diagnostic_is_per_call_and_leaves_results_alone(ss, sslib)
 
 
 @pytest.mark.gpu
+def test_shader_clock_probe_beside_a_workload(ss, sslib):
+    """ss_shader_clock_probe / _async (ABI 6): one sleeping wave that reads the shader clock beside whatever else runs.  Alone on
+    the device it reads a plausible clock; queued ahead of cfg5 launches (whose workgroups take all of a CU's LDS: the probe needs
+    none) it still runs beside them and the launches' results are untouched; argument checks."""
+    import ctypes as C
+
+    import torch
+
+    ghz = C.c_float(0.0)
+    side = torch.cuda.Stream()
+    assert sslib.ss_shader_clock_probe(C.c_void_p(side.cuda_stream), 300, C.byref(ghz)) == 0
+    assert 0.05 < ghz.value < 2.6, ghz.value   # (an idle part may sit far below its peak clock)
+    assert sslib.ss_shader_clock_probe(C.c_void_p(side.cuda_stream), 5, C.byref(ghz)) == 3       # SS_ERR_ARG: too short
+    assert sslib.ss_shader_clock_probe(C.c_void_p(side.cuda_stream), 300, None) == 3
+    assert sslib.ss_shader_clock_probe_async(C.c_void_p(side.cuda_stream), 300, None) == 3
+    kw = dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096, high_frequency=22050.0)
+    x = torch.randn((512, 44100), device="cuda") * 0.1
+    want = ss.mfcc_batch(x, 44100, **kw)
+    torch.cuda.synchronize()
+    words = torch.zeros(2, dtype=torch.int64, device="cuda")
+    assert sslib.ss_shader_clock_probe_async(C.c_void_p(side.cuda_stream), 1000, C.c_void_p(words.data_ptr())) == 0
+    outs = [ss.mfcc_batch(x, 44100, **kw) for _ in range(40)]   # ~2.4 ms of launches behind the probe
+    torch.cuda.synchronize()
+    cyc, ticks = words.tolist()
+    assert ticks >= 100000 and 0.3 < cyc / (10.0 * ticks) < 2.6, (cyc, ticks)   # >= 1000 us on the 100 MHz counter
+    assert all(torch.equal(o, want) for o in outs)
+
+
+@pytest.mark.gpu
 def test_lab_stamp_buffer_describes_a_sane_launch(ss, sslab):
     """ss_debug_stamp_buffer (LAB library; tools/prof2.py, tools/dbg_times.py): while set, launches of the 512-point MFCC kernel
     write per-wave stamps; the features must not change, and the stamps must describe a sane launch."""
