@@ -413,7 +413,11 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     // times within one launch spread by 2 - 3 us: profiles/r05/unit_timeline_cfg3.txt) take work from the ones that are behind
     // instead of idling until the launch's last unit ends.  The claim of a pool unit is a returning device-scope atomic issued a
     // whole unit ahead of its use (behind nothing the wave waits for), so its microsecond of latency is never exposed.
+#if SS_LAB
     const bool pooled = !STFT && !ROWS4 && a.pool != nullptr;
+#else
+    constexpr bool pooled = false;  // (measured and not kept: the product build carries none of it -- DESIGN_LAB.md 9)
+#endif
     unsigned u_lo, u_hi, p_lo = 0, p_hi = 0;
     unsigned *g_next = nullptr;
     if (pooled) {
