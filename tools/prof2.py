@@ -27,3 +27,13 @@ print("waves", len(w), "quads/wave mean", it.mean(), "loop cycles/quad", (w[:, 1
 tot = w[:, 11].astype(float).sum()
 for k in range(1, 10):
     print(f"{names[k]:12s} share {w[:, k].astype(float).sum() / tot:6.3f}   cycles/quad {(w[:, k] / it).mean():8.0f}")
+# by wave index within the workgroup (16 stamp rows per workgroup, 12 waves used; waves 0-3 are dispatched first = the oldest wave
+# of each SIMD): quads done, cycles per quad, main-loop lifetime -- the three speed classes of profiles/r05/unit_timeline_cfg3*.txt
+full = st.cpu().numpy().reshape(ncu, 16, 16).astype(float)
+full = full[full[:, :12, 0].min(axis=1) > 0][:, :12, :]
+print("by wave index: quads         ", [round(float(full[:, k, 0].mean()), 2) for k in range(12)])
+print("by wave index: cycles/quad   ", [int(round(float((full[:, k, 11] / full[:, k, 0]).mean()))) for k in range(12)])
+print("by wave index: loop k cycles ", [round(float(full[:, k, 11].mean()) / 1e3, 1) for k in range(12)])
+print("slowest wave of a CU is index", np.bincount(full[:, :, 11].argmax(axis=1), minlength=12).tolist(),
+      "| CU loop k cycles p10 p50 p90 max", [round(float(x) / 1e3, 1) for x in np.percentile(full[:, :, 11].max(axis=1), [10, 50, 90, 100])],
+      "| sum of wave loops / 12:", round(float(full[:, :, 11].sum(axis=1).mean()) / 12e3, 1))
