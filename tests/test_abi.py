@@ -74,7 +74,7 @@ def test_the_product_library_exports_only_the_documented_abi():
     assert not [n for n in exported if n.startswith("ss_debug")], "a process-wide test aid is exported by the product library"
     blob = open(_lib.LIB_PATH, "rb").read()
     for knob in (b"SS_FORCE_GENERIC", b"SS_RES", b"SS_WAVES", b"SS_MEL_WAVES", b"SS_STFT_WAVES", b"SS_MEL_TILE", b"SS_HOST_CHUNK_MB", b"SS_HOST_SMALL_KB",
-                 b"SS_DEBUG_TIMES", b"SS_DEBUG_ROWS"):
+                 b"SS_DEBUG_TIMES", b"SS_DEBUG_ROWS", b"SS_POOL", b"SS_MEL_ROWS4"):
         assert knob + b"\0" not in blob, f"the product build still reads {knob.decode()}"
 
 
