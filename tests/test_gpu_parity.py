@@ -930,6 +930,46 @@ def test_cfg4_corpus_properties(ss, oracle):
         assert _rel(first[b].cpu().numpy(), oracle.mfcc(p, base[b])) <= RTOL
 
 
+def test_bench_default_line_carries_the_contract_and_the_secondary_configs():
+    """The driver's command (`python bench.py --steps 20 --warmup 5`, here with a short CPU leg): ONE JSON line with the contract's
+    keys, `roofline` and `cpu_baseline` (the port built on this host, its flags named), and -- round 5 -- the other BASELINE
+    configurations (`secondary`: the kernels of BENCH_KERNELS, the ones the parity tests above compare with the oracle), the
+    two-stream figure and shader cycles beside the times."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "cfg2" in d["config"]["workload"] and d["value"] > 1e9
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["kernel"].encode() == BENCH_KERNELS["cfg2"]
+    assert r["algorithmic_bytes_per_launch"] == 70754304 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert abs(r["achieved"] - 70754304 / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.9 < r["traffic"] / 70754304 < 1.1 and 1.0 < r["clock_ghz_measured"] < 2.6
+    assert abs(r["cycles_per_launch"] - r["avg_launch_us"] * 1e3 * r["clock_ghz_measured"]) < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e4 and ("-O3 -march=native" in c["sample"] or "portable" in c["sample"])
+    assert d["value_pipelined"] > 0.9 * d["value"] and d["pipelined"]["streams"] == 2
+    sec = d["secondary"]
+    for wl, bytes_ in (("cfg3", 82313216), ("cfg5", 93511680), ("cfg4", 24874560000)):
+        e = sec[wl]
+        assert "error" not in e, e
+        assert e["kernel"].encode() == BENCH_KERNELS["cfg2" if wl == "cfg4" else wl]
+        assert e["algorithmic_bytes_per_launch"] == bytes_ and abs(e["frac"] - bytes_ / (e["avg_launch_us"] * 1e-6) / 8e12) < 1e-9
+        assert 0.05 < e["frac"] < 0.6
+        if e.get("clock_ghz_measured"):
+            assert 1.0 < e["clock_ghz_measured"] < 2.6 and abs(e["cycles_per_launch"] - e["avg_launch_us"] * 1e3 * e["clock_ghz_measured"]) < 1.0
+
+
 def test_cpp_mirror_parity(tmp_path, oracle):
     """The header-only C++ mirror of the crate's API (include/speechsauce_amd.hpp), built with plain g++ against the
     library: mfcc -> cmvn on a seeded clip, compared with the oracle."""
