@@ -186,3 +186,28 @@ def test_bad_configs(oracle):
         oracle.mfcc(oracle.make_params(num_cepstral=41), np.zeros(16000, np.float32))
     with pytest.raises(oracle.OracleError):  # frame longer than fft_points (processing.rs:146-164)
         oracle.mfcc(oracle.make_params(frame_length=0.04), np.zeros(16000, np.float32))
+
+
+def test_the_timed_cpu_port_is_built_for_this_host_and_checked_first(oracle):
+    """bench.py's cpu_baseline leg: the reference-shaped f32 port is compiled ON the host that times it (`make -C oracle native`:
+    -O3 -march=native, no fast-math, no FMA contraction; oracle/_native/ is git- and gpurun-ignored so it never travels), compared
+    with the f64 checker on one clip before any timing, and the flags are named in the line."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    res = bench.cpu_baseline("mfcc", dict(sample_rate=16000), 16000, budget_s=0.3)
+    assert res["kind"] == "port" and res["cores"] == 1 and res["value"] > 1e3
+    assert ("-O3 -march=native" in res["sample"] and "-ffp-contract=off" in res["sample"]) or "portable" in res["sample"]
+    nat, flags = oracle.native_port()
+    if nat is not None:
+        x = (np.random.default_rng(2).standard_normal(16000) * 0.1).astype(np.float32)
+        p = oracle.make_params()
+        np.testing.assert_array_equal(oracle.port_mfcc(p, x, from_lib=nat).shape, (98, 13))
+        want = oracle.mfcc(p, x)
+        assert np.abs(oracle.port_mfcc(p, x, from_lib=nat) - want).max() <= 1e-4 * np.abs(want).max()
+    ign = open(os.path.join(root, ".gpurunignore")).read()
+    assert "oracle/_native/" in ign and "oracle/_native/" in open(os.path.join(root, ".gitignore")).read()
