@@ -375,6 +375,10 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         res["traffic"] = None
     if board:
         res["board"] = board
+        if board.get("power_w_mean") and streams == 1:
+            # socket energy per launch (mean power of the pre-roll of these same launches x this region's time per launch): at the
+            # power cap, time = energy / cap -- the figure a kernel change has to move
+            res["energy_mj_per_launch"] = board["power_w_mean"] * avg * 1e3
     if clock_ghz:
         # shader cycles per launch at the clock a probe wave read beside these same launches right after the timed ones (the hwmon
         # figure in `board` reads up to 10 % higher): the figure to compare across boxes that hold different clocks at the power cap
@@ -823,6 +827,8 @@ def main():
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(kind, pkw, n_samples, args.cpu_seconds / 2)
         if board:
             res["roofline"]["board"] = board
+            if board.get("power_w_mean") and args.streams == 1:
+                res["roofline"]["energy_mj_per_launch"] = board["power_w_mean"] * avg_launch_s * 1e3  # (see measure_simple)
         if clock_ghz is not None:
             rf = res["roofline"]
             rf["clock_ghz_measured"] = clock_ghz
