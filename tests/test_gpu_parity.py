@@ -481,6 +481,32 @@ def test_edge_signals(ss, oracle):
     assert _rel(ss.mfcc(imp, 16000), oracle.mfcc(p, imp)) <= RTOL
 
 
+@pytest.mark.parametrize("amp", [1e-6, 1e-3, 1.0, 32768.0])
+def test_amplitude_range_on_the_bench_kernels(ss, oracle, amp):
+    """The amplitudes a front end meets -- a near-silent recording (1e-6), quiet speech, full scale, and floats that still carry the
+    int16 scale (32768) -- through the three bench configurations against the oracle.  The kernels take `ln` of values pre-scaled
+    by 2^32 and `v_sqrt_f32` / `v_log_f32` without denormal handling: both are exact in this range (|X|^2 leaves the normal f32
+    range only below ~1e-19 / above ~1e19 of amplitude, where the reference's own f32 arithmetic underflows / overflows too)."""
+    import torch
+
+    x1 = (_signal(91, (3, 16000)) * (amp / 0.1)).astype(np.float32)
+    got = ss.mfcc_batch(torch.from_numpy(x1).cuda(), 16000).cpu().numpy()
+    p = oracle.make_params(**CFG1)
+    for b in range(3):
+        assert _rel(got[b], oracle.mfcc(p, x1[b])) <= RTOL, ("cfg1", amp, b)
+    kw3 = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+    mel = ss.mel_spectrogram(torch.from_numpy(x1).cuda(), 16000, **kw3).cpu().numpy()
+    want = oracle.mel_spectrogram(oracle.make_params(**CFG3), x1)
+    for b in range(3):
+        assert _rel(mel[b], want[b]) <= RTOL, ("cfg3", amp, b)
+    x5 = (_signal(92, (2, 44100)) * (amp / 0.1)).astype(np.float32)
+    kw5 = dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096, high_frequency=22050.0)
+    got5 = ss.mfcc_batch(torch.from_numpy(x5).cuda(), 44100, **kw5).cpu().numpy()
+    p5 = oracle.make_params(**CFG5)
+    for b in range(2):
+        assert _rel(got5[b], oracle.mfcc(p5, x5[b])) <= RTOL, ("cfg5", amp, b)
+
+
 @pytest.mark.parametrize("sr,nfft,flen,hop,M,C", [(8000, 256, 160, 80, 40, 13), (16000, 512, 400, 160, 80, 13), (22050, 1024, 1024, 256, 64, 20),
                                                   (44100, 2048, 2048, 512, 128, 20), (44100, 4096, 4096, 1024, 256, 40)])
 def test_edge_signals_every_frame_kernel(ss, oracle, sslib, sr, nfft, flen, hop, M, C):
