@@ -481,6 +481,47 @@ def test_edge_signals(ss, oracle):
     assert _rel(ss.mfcc(imp, 16000), oracle.mfcc(p, imp)) <= RTOL
 
 
+def test_a_nan_sample_stays_in_its_own_frames(ss):
+    """One NaN (and one +inf) sample in one clip of a batch: exactly the frames / rows whose window covers it come out non-finite
+    (as in the reference, whose arithmetic propagates them), every other frame of that clip and every other clip keeps its bits --
+    frames share a wave, an exchange region and a reduction tree, and none of that may leak."""
+    import torch
+
+    for bad in (float("nan"), float("inf")):
+        x = torch.from_numpy(_signal(93, (6, 16000))).cuda()
+        clean = ss.mfcc_batch(x, 16000)
+        xb = x.clone()
+        xb[2, 5000] = bad
+        got = ss.mfcc_batch(xb, 16000)
+        t = torch.arange(98, device="cuda")
+        hit = (t * 160 <= 5000) & (5000 < t * 160 + 320)      # frames whose 320 samples cover sample 5000
+        assert int(hit.sum()) == 2
+        assert not torch.isfinite(got[2, hit]).all(dim=1).any()
+        keep = torch.ones((6, 98), dtype=torch.bool, device="cuda")
+        keep[2, hit] = False
+        assert torch.equal(got[keep], clean[keep])
+        # mel spectrogram, 2048-point windows with hop 512: row r covers samples [512 r, 512 r + 2048)
+        kw3 = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+        mclean, mgot = ss.mel_spectrogram(x, 16000, **kw3), ss.mel_spectrogram(xb, 16000, **kw3)
+        r = torch.arange(32, device="cuda")
+        mhit = (r * 512 <= 5000) & (5000 < r * 512 + 2048) & (r < 29)
+        mkeep = torch.ones((6, 32), dtype=torch.bool, device="cuda")
+        mkeep[2, mhit] = False
+        assert torch.equal(mgot.permute(0, 2, 1)[mkeep], mclean.permute(0, 2, 1)[mkeep])
+        assert not torch.isfinite(mgot.permute(0, 2, 1)[2, mhit]).all(dim=1).any()
+        x5 = torch.from_numpy(_signal(94, (3, 44100))).cuda()
+        kw5 = dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096, high_frequency=22050.0)
+        c5 = ss.mfcc_batch(x5, 44100, **kw5)
+        x5b = x5.clone()
+        x5b[1, 20000] = bad
+        g5 = ss.mfcc_batch(x5b, 44100, **kw5)
+        t5 = torch.arange(39, device="cuda")
+        h5 = (t5 * 1024 <= 20000) & (20000 < t5 * 1024 + 4096)
+        k5 = torch.ones((3, 39), dtype=torch.bool, device="cuda")
+        k5[1, h5] = False
+        assert int(h5.sum()) == 4 and torch.equal(g5[k5], c5[k5]) and not torch.isfinite(g5[1, h5]).all(dim=1).any()
+
+
 @pytest.mark.parametrize("amp", [1e-6, 1e-3, 1.0, 32768.0])
 def test_amplitude_range_on_the_bench_kernels(ss, oracle, amp):
     """The amplitudes a front end meets -- a near-silent recording (1e-6), quiet speech, full scale, and floats that still carry the
