@@ -25,8 +25,8 @@ contiguous clip shards (speechsauce_amd.distributed.shard_bounds), one launch pe
 
 A default N = 1 run (headline workload, no measurement switches) also times, after the headline region and outside it, the other
 BASELINE configurations -- `secondary.cfg3`, `secondary.cfg5` (1000 steps each) and `secondary.cfg4` (the whole 360 000-clip corpus
-in one launch, 5 steps) -- and the headline workload once more with successive steps alternating over two HIP streams
-(`value_pipelined`: one launch's tail under the next one's head; whole-job throughput, not a kernel duration and no part of `roofline`).
+in one launch, 5 steps) -- and the headline workload once more with successive steps going round four HIP streams
+(`value_pipelined`: one launch's tail under the next ones' heads; whole-job throughput, not a kernel duration and no part of `roofline`).
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (4 B per input
 sample + 4 B per output element) / average launch duration measured with HIP events
@@ -845,11 +845,14 @@ def main():
             # the other BASELINE configurations and the pipelined headline, after and outside the headline's timed region
             del xs[:], outs[:]
             torch.cuda.empty_cache()
-            pl = measure_simple(torch, ss, "cfg2", device, steps=max(args.steps, 400), warmup=50, prewarm_ms=100.0, streams=2, probe_board=False)
+            # (four streams reach the one-launch corpus rate: 2 / 3 / 4 streams +3 / +8 / +12 % over one on a 2000-step run,
+            # profiles/r05/streams.txt)
+            pl = measure_simple(torch, ss, "cfg2", device, steps=max(args.steps, 800), warmup=100, prewarm_ms=100.0, streams=4, probe_board=False)
             res["value_pipelined"] = pl["value"]
-            res["pipelined"] = {"streams": 2, "steps": pl["steps"], "ms_per_step": pl["ms_per_step"], "kernel": pl["kernel"],
-                                "note": "same workload, successive steps alternate over two HIP streams (independent batches): one launch's tail "
-                                        "runs under the next one's head; wall time per step, not a kernel duration, not part of `roofline`"}
+            res["pipelined"] = {"streams": 4, "steps": pl["steps"], "ms_per_step": pl["ms_per_step"], "kernel": pl["kernel"],
+                                "note": "same workload, successive steps go round four HIP streams (independent batches): a launch's one-unit tail "
+                                        "and the next ones' wait for their first samples overlap; wall time per step, not a kernel duration, "
+                                        "not part of `roofline`"}
             res["secondary"] = {}
             # (1000 steps, 50 - 60 ms each: regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
             for wl, st, wu in (("cfg3", 1000, 100), ("cfg5", 1000, 100), ("cfg4", 5, 1)):

@@ -1025,7 +1025,7 @@ def test_bench_default_line_carries_the_contract_and_the_secondary_configs():
     assert abs(r["cycles_per_launch"] - r["avg_launch_us"] * 1e3 * r["clock_ghz_measured"]) < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e4 and ("-O3 -march=native" in c["sample"] or "portable" in c["sample"])
-    assert d["value_pipelined"] > 0.9 * d["value"] and d["pipelined"]["streams"] == 2
+    assert d["value_pipelined"] > 0.9 * d["value"] and d["pipelined"]["streams"] == 4
     sec = d["secondary"]
     for wl, bytes_ in (("cfg3", 82313216), ("cfg5", 93511680), ("cfg4", 24874560000)):
         e = sec[wl]
