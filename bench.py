@@ -261,7 +261,7 @@ def probe_clock(torch, lib, step, avg_s, device, probe_us=2000, want=3):
     stream: the probe wave is resident before they start and reads the clock under their load.  A reading is ACCEPTED only if
     the launches took no longer than they do alone: HIP multiplexes streams onto a few hardware queues, and a side stream that
     shares the launch stream's queue makes the launches wait behind the sleeping probe, which then reads the idle clock (2.4 GHz;
-    tools/probe_test.py, profiles/r05/clock_probe_check.txt).  Outside every timed region.  None if no reading was accepted."""
+    tools/clock_probe_ab.py, profiles/r05/clock_probe_check.txt).  Outside every timed region.  None if no reading was accepted."""
     n = max(8, int(2.5 * probe_us * 1e-6 / max(avg_s, 1e-6)))
     words = torch.zeros((3 * want, 2), dtype=torch.int64, device=device)
     got = []

@@ -14,6 +14,12 @@ CONFIGS = {
                  num_cepstral=40, num_filters=256, high_frequency=22050.0),
 }
 N_SAMPLES = {"cfg1": 16000, "cfg3": 16000, "cfg5": 44100}
+# the kernel builds bench.py's BASELINE workloads run on (asserted by name wherever a test means "what the bench times")
+BENCH_KERNELS = {
+    "cfg2": b"ss_mfcc_c256<10,exact,bank421,sym>",
+    "cfg3": b"ss_mel_c1024<w12,mel6321>",
+    "cfg5": b"ss_mfcc_c2048<exact,mel8321,w12>",
+}
 RTOL = 1e-4  # BASELINE.json north_star: outputs within 1e-4 (relative to the per-clip max)
 
 

@@ -111,11 +111,7 @@ def test_mfe_batch_fast_path(ss, oracle, sslib):
 
 # kernel builds that `bench.py --workload cfgN` launches (the names ss_last_kernel_name() reports; the rocprofv3 traces under
 # profiles/ carry the same builds under their template spelling, profiles/pmc_traffic.json "kernel_full")
-BENCH_KERNELS = {
-    "cfg2": b"ss_mfcc_c256<10,exact,bank421,sym>",
-    "cfg3": b"ss_mel_c1024<w12,mel6321>",
-    "cfg5": b"ss_mfcc_c2048<exact,mel8321,w12>",
-}
+from common import BENCH_KERNELS  # noqa: E402  (the builds bench.py's workloads run on)
 
 
 def test_cfg2_batch_1024(ss, oracle):
