@@ -23,10 +23,13 @@ own time and the per-link rate it reached, so the line says how much of the step
 cfg4 (the 100 h corpus, 360 000 clips) is the one strong-scaling workload: the corpus is split into
 contiguous clip shards (speechsauce_amd.distributed.shard_bounds), one launch per shard per step.
 
-A default N = 1 run (headline workload, no measurement switches) also times, after the headline region and outside it, the other
-BASELINE configurations -- `secondary.cfg3`, `secondary.cfg5` (1000 steps each) and `secondary.cfg4` (the whole 360 000-clip corpus
-in one launch, 5 steps) -- and the headline workload once more with successive steps going round four HIP streams
-(`value_pipelined`: one launch's tail under the next ones' heads; whole-job throughput, not a kernel duration and no part of `roofline`).
+A default N = 1 run (headline workload, no measurement switches) also times, after the headline region and outside it: the headline
+workload over 1000 single-stream steps with time AND shader clock taken from those same launches (`secondary.cfg2`: the stable figure
+rounds are compared on; its `cycles_per_launch` is the only one whose factors share launches), four independent batches per launch
+(`secondary.cfg2_x4`, ss_mfcc_batches_device), the other BASELINE configurations -- `secondary.cfg3`, `secondary.cfg5` (1000 steps
+each) and `secondary.cfg4` (the whole 360 000-clip corpus in one launch, 5 steps) -- and the headline workload once more with successive
+steps going round four HIP streams (`value_pipelined`, with `pipelined.value_one_stream` = secondary.cfg2's value beside it: one launch's
+tail under the next ones' heads; whole-job throughput, not a kernel duration and no part of `roofline`).
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (4 B per input
 sample + 4 B per output element) / average launch duration measured with HIP events
@@ -145,7 +148,8 @@ def timed_port(kind, p, probe_clip):
     got = fn(p, probe_clip)
     err = float(np.abs(got - want).max() / np.abs(want).max())
     if not err <= 1e-4:
-        raise SystemExit(f"bench.py: the native CPU port disagrees with the checker (rel err {err}): not timing it")
+        # never take the measured GPU line down with it: time the portable build instead and say so
+        return base, f"portable build (gcc -O2 -ffp-contract=off; the native build [{flags}] disagreed with the f64 checker: rel err {err:.1e})"
     return fn, flags + f"; checked against the f64 oracle on one clip first (rel err {err:.1e})"
 
 
@@ -286,11 +290,17 @@ def probe_clock(torch, lib, step, avg_s, device, probe_us=2000, want=3):
     return got[len(got) // 2] if got else None
 
 
-def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=300.0, streams=1, probe_board=True, ring_mib=300):
+def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=300.0, streams=1, probe_board=True, ring_mib=300,
+                   group=1, stamped=0):
     """One N = 1 measurement of a BASELINE configuration outside the headline region: `steps` launches of the hot path over batches
     resident in HBM (rotated over > 256 MiB of distinct inputs, like the headline), HIP events on the launch stream around them,
     wall clock between synchronize pairs.  streams > 1: successive steps alternate over that many streams (independent batches in
-    flight), so the per-step figure is wall time, not a kernel duration."""
+    flight), so the per-step figure is wall time, not a kernel duration.
+    group > 1: each launch takes `group` independent batches of the workload at once (ss_mfcc_batches_device: one persistent launch
+    over all of them); a step is still ONE batch, so `steps` must be a multiple of `group` and the per-step figures are launch / group.
+    stamped > 0 (512-point MFCC kernel, one stream): the timed region runs inside the library (ss_mfcc_timed_region: the same
+    launches, HIP events on the launch stream around them) and the shader clock comes from the in-kernel stamps of the last
+    `stamped` of THOSE launches -- time and clock of `cycles_per_launch` share launches."""
     from speechsauce_amd import SpeechConfig, _lib, make_params
 
     lib = _lib.lib()
@@ -312,11 +322,29 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
     sptrs = [C.c_void_p(st.cuda_stream) for st in sts]
     outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(1 if big else max(2, 2 * streams))]
     fn = lib.ss_mfcc_batch_device if kind == "mfcc" else lib.ss_mel_spectrogram_device
+    if group > 1:
+        # launch k takes batches k*group .. k*group + group - 1 of the ring (distinct inputs, distinct output blocks)
+        assert kind == "mfcc" and steps % group == 0 and warmup % group == 0 and streams == 1
+        outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(2 * group)]
+        nb = (C.c_size_t * group)(*([clips] * group))
+        tabs = []
+        for k in range(max(n_buf, 2) * 2):
+            px = (C.c_void_p * group)(*[xs[(k * group + g) % n_buf].data_ptr() for g in range(group)])
+            po = (C.c_void_p * group)(*[outs[((k % 2) * group + g)].data_ptr() for g in range(group)])
+            tabs.append((px, po))
 
-    def step(i):
-        rc = fn(cfg.handle, xs[i % n_buf].data_ptr(), clips, n_samples, n_samples, outs[i % len(outs)].data_ptr(), sptrs[i % len(sptrs)])
-        if rc:
-            _lib.check(rc)
+        def step(i):  # one call = `group` steps; called for i = 0, group, 2 group, ...
+            if i % group:
+                return
+            px, po = tabs[(i // group) % len(tabs)]
+            rc = lib.ss_mfcc_batches_device(cfg.handle, group, px, nb, n_samples, n_samples, po, sptrs[0])
+            if rc:
+                _lib.check(rc)
+    else:
+        def step(i):
+            rc = fn(cfg.handle, xs[i % n_buf].data_ptr(), clips, n_samples, n_samples, outs[i % len(outs)].data_ptr(), sptrs[i % len(sptrs)])
+            if rc:
+                _lib.check(rc)
 
     board = None
     if prewarm_ms > 0:
@@ -324,7 +352,7 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         t_end = time.perf_counter() + prewarm_ms * 1e-3
         k = 0
         while True:
-            for _ in range(1 if big else 50):
+            for _ in range(1 if big else 50 * group):
                 step(k)
                 k += 1
             torch.cuda.synchronize()
@@ -335,26 +363,47 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(main)
-    for st in sts[1:]:  # the other streams start behind the start event
-        st.wait_event(e0)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    for st in sts[1:]:
-        ev = torch.cuda.Event()
-        ev.record(st)
-        main.wait_event(ev)
-    e1.record(main)
-    while not e1.query():
-        pass
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dev_s = e0.elapsed_time(e1) * 1e-3
+    clock_ghz = clock_source = None
+    if stamped and kind == "mfcc" and streams == 1 and group == 1:
+        # the library runs the region: the same launches (input ring, output blocks), events on the launch stream, per-wave stamps
+        # of the last `stamped` of them
+        px = (C.c_void_p * n_buf)(*[x.data_ptr() for x in xs])
+        po = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        ms, ghz, wall = C.c_float(0.0), C.c_float(0.0), C.c_float(0.0)
+        rc = lib.ss_mfcc_timed_region(cfg.handle, px, n_buf, clips, n_samples, n_samples, po, len(outs), sptrs[0], steps, stamped,
+                                      C.byref(ms), C.byref(ghz), C.byref(wall))
+        torch.cuda.synchronize()
+        if rc:
+            _lib.check(rc)
+        elapsed = wall.value * 1e-3  # host clock inside the call: first launch .. last launch done (not the stamps' read-back)
+        dev_s = ms.value * 1e-3 * steps
+        if ghz.value > 0:
+            clock_ghz = float(ghz.value)
+            clock_source = (f"in-kernel stamps of {'all' if stamped >= steps else 'the last ' + str(stamped) + ' of'} the {steps} timed launches themselves "
+                            "(ss_mfcc_timed_region)")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        for st in sts[1:]:  # the other streams start behind the start event
+            st.wait_event(e0)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        for st in sts[1:]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            main.wait_event(ev)
+        e1.record(main)
+        while not e1.query():
+            pass
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        dev_s = e0.elapsed_time(e1) * 1e-3
     kernel = lib.ss_last_kernel_name().decode()
     avg = dev_s / steps
-    clock_ghz = probe_clock(torch, lib, step, avg, device) if streams == 1 else None
+    if clock_ghz is None and streams == 1 and group == 1:
+        clock_ghz = probe_clock(torch, lib, step, avg, device)
+        clock_source = "a one-wave probe beside FURTHER launches of the same step right after the timed ones (ss_shader_clock_probe)"
     del xs, outs
     torch.cuda.empty_cache()
     res = {
@@ -365,6 +414,13 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         "achieved": bytes_per_launch / avg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch / avg / 1e9 / HBM_PEAK_GBS,
         "frames_per_launch": clips * rows,
     }
+    if group > 1:
+        # a launch covers `group` batches: the per-launch figures above are per BATCH (region / steps); the launch itself is group x
+        res["batches_per_launch"] = group
+        res["launch_us"] = avg * 1e6 * group
+        res["note"] = (f"{group} independent batches of the workload per ss_mfcc_batches_device call = one persistent launch; avg_launch_us, "
+                       "bytes and frac are per 1024-clip batch (launch / group): the start-up and the one-unit tail of a launch are paid once per "
+                       f"{group} batches")
     e = load_pmc(workload)
     if e and kernel.split("<")[0] in e.get("kernel_full", ""):
         res["traffic"] = e.get("hbm_bytes_per_launch")
@@ -383,6 +439,7 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         # shader cycles per launch at the clock a probe wave read beside these same launches right after the timed ones (the hwmon
         # figure in `board` reads up to 10 % higher): the figure to compare across boxes that hold different clocks at the power cap
         res["clock_ghz_measured"] = clock_ghz
+        res["clock_source"] = clock_source
         res["cycles_per_launch"] = avg * 1e9 * clock_ghz
         if res.get("valu_insts_per_launch"):
             res["valu_floor_frac"] = res["valu_insts_per_launch"] / 1024.0 * 2.14 / res["cycles_per_launch"]
@@ -435,7 +492,7 @@ def main():
     ap.add_argument("--kind", default="", choices=["", "mfcc", "mel"], help="run the workload's clips through the other path (mfcc / mel_spectrogram); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="single-thread CPU baseline budget (the all-cores run takes half of it)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 / cfg5 / cfg4 lines and value_pipelined that a default N = 1 run appends")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (cfg2 over 1000 steps, cfg2_x4, cfg3, cfg5, cfg4) and value_pipelined that a default N = 1 run appends")
     ap.add_argument("--corpus-clips", type=int, default=0, help="cfg4: size of the corpus that is split over the ranks (default 360 000); keeps strong scaling, unlike --clips")
     ap.add_argument("--gather-chunks", type=int, default=8, help="cfg4 with a gather: a rank's shard is computed and gathered in this many chunks, "
                     "chunk i's collective under chunk i+1's kernel")
@@ -819,6 +876,11 @@ def main():
                 "gather_bound_frames_per_s": world * args.link_gbps * 1e9 / out_bytes_per_frame,
                 "gather_bound_efficiency": min(1.0, args.link_gbps * 1e9 / out_bytes_per_frame / kernel_only),
                 "value_over_gather_bound": value / (world * args.link_gbps * 1e9 / out_bytes_per_frame),
+                # one word for whoever reads the first SCALE record: is `value` held by the links into the root, or by the path?
+                # ("interconnect": the gather bound lies below what the ranks' kernels produce, or `value` sits within 15 % of it)
+                "bound": (("interconnect" if (world * args.link_gbps * 1e9 / out_bytes_per_frame < (corpus * rows / avg_launch_s if strong else world * kernel_only)
+                                              or value >= 0.85 * world * args.link_gbps * 1e9 / out_bytes_per_frame) else "path")
+                          if do_gather else "path"),
                 "note": "root mode: (N-1) peers each fill one direct link into rank 0; the bound counts N producers at one link's rate each "
                         "(rank 0's own block needs no link, so it is slightly pessimistic); unmeasured on hardware",
             }
@@ -829,37 +891,70 @@ def main():
             res["roofline"]["board"] = board
             if board.get("power_w_mean") and args.streams == 1:
                 res["roofline"]["energy_mj_per_launch"] = board["power_w_mean"] * avg_launch_s * 1e3  # (see measure_simple)
+        headline = world == 1 and args.workload == "cfg2" and args.streams == 1 and not (
+            args.params or args.kind or args.clips or args.force_generic or args.no_secondary or args.ring_mib != 300)
         if clock_ghz is not None:
             rf = res["roofline"]
             rf["clock_ghz_measured"] = clock_ghz
             rf["clock_source"] = clock_source
-            # shader cycles per launch: the figure to compare between boxes / rounds (boxes hold 1.9-2.25 GHz at the power cap)
-            rf["cycles_per_launch"] = avg_launch_s * 1e9 * clock_ghz
-            if rf.get("valu_insts_per_launch"):
-                # ONE VALU-issue-floor fraction: the kernel's instruction count (2.14 cycles per instruction per SIMD, 1024 SIMDs;
-                # tools/ubench/valu_issue.hip) over THIS run's launch duration at the clock THIS device held in THIS run
-                rf["valu_floor_frac"] = rf["valu_insts_per_launch"] / 1024.0 * 2.14 / (avg_launch_s * 1e9 * clock_ghz)
-        headline = world == 1 and args.workload == "cfg2" and args.streams == 1 and not (
-            args.params or args.kind or args.clips or args.force_generic or args.no_secondary or args.ring_mib != 300)
+            if headline:
+                # The clock above was read on LATER launches than the ones `avg_launch_us` times (and a 20-step region is 0.6 ms): their
+                # product is not a cycle count of anything.  The coherent figure -- time and clock from the same 1000 launches -- is
+                # secondary.cfg2.cycles_per_launch below.
+                rf["cycles_per_launch"] = None
+                rf["cycles_per_launch_see"] = "secondary.cfg2 (time and clock from the same launches)"
+            else:
+                # shader cycles per launch: the figure to compare between boxes / rounds (boxes hold 1.9-2.25 GHz at the power cap).
+                # Long regions only (--steps >= a few hundred): the clock is read on further launches right behind the timed ones
+                rf["cycles_per_launch"] = avg_launch_s * 1e9 * clock_ghz
+                if rf.get("valu_insts_per_launch"):
+                    # ONE VALU-issue-floor fraction: the kernel's instruction count (2.14 cycles per instruction per SIMD, 1024 SIMDs;
+                    # tools/ubench/valu_issue.hip) over THIS run's launch duration at the clock THIS device held in THIS run
+                    rf["valu_floor_frac"] = rf["valu_insts_per_launch"] / 1024.0 * 2.14 / (avg_launch_s * 1e9 * clock_ghz)
         if headline:
             # the other BASELINE configurations and the pipelined headline, after and outside the headline's timed region
             del xs[:], outs[:]
             torch.cuda.empty_cache()
             # (four streams reach the one-launch corpus rate: 2 / 3 / 4 streams +3 / +8 / +12 % over one on a 2000-step run,
             # profiles/r05/streams.txt)
-            pl = measure_simple(torch, ss, "cfg2", device, steps=max(args.steps, 800), warmup=100, prewarm_ms=100.0, streams=4, probe_board=False)
-            res["value_pipelined"] = pl["value"]
-            res["pipelined"] = {"streams": 4, "steps": pl["steps"], "ms_per_step": pl["ms_per_step"], "kernel": pl["kernel"],
-                                "note": "same workload, successive steps go round four HIP streams (independent batches): a launch's one-unit tail "
-                                        "and the next ones' wait for their first samples overlap; wall time per step, not a kernel duration, "
-                                        "not part of `roofline`"}
+            # Everything below is extra: none of it may take the measured headline down with it (each leg reports {"error": ...}).
             res["secondary"] = {}
-            # (1000 steps, 50 - 60 ms each: regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
-            for wl, st, wu in (("cfg3", 1000, 100), ("cfg5", 1000, 100), ("cfg4", 5, 1)):
+            # secondary.cfg2: the headline workload and kernel over 1000 single-stream steps, run inside the library -- HIP events
+            # around the launches AND the in-kernel stamps of ALL of those same launches (every wave's cycles / lifetime, summed on the
+            # device): the one cycles_per_launch whose time and clock share launches -- stamping only the region's last quarter spreads
+            # 1.2 % between regions on one box, stamping all of it 0.3 % (profiles/r06/stamp_cost.txt) --, and the figure rounds are compared on (a 20-step headline region is 0.6 ms: the same binary
+            # reads 26 - 30 us there, profiles/r05/box_spread.txt).
+            # secondary.cfg2_x4: four independent 1024-clip batches per ss_mfcc_batches_device call (ONE persistent launch): what the
+            # start-up + tail of a launch cost, recovered without streams.  Per-batch figures; never `value`.
+            # (cfg3 / cfg5: 1000 steps, 50 - 60 ms each: regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
+            legs = (("cfg2", "cfg2", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
+                    ("cfg2_x4", "cfg2", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
+                    ("cfg3", "cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+                    ("cfg5", "cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+                    ("cfg4", "cfg4", dict(steps=5, warmup=1, prewarm_ms=300.0)))
+            for name, wl, kw in legs:
                 try:
-                    res["secondary"][wl] = measure_simple(torch, ss, wl, device, steps=st, warmup=wu, prewarm_ms=300.0)
-                except Exception as e:  # a secondary line must never take the headline down with it
-                    res["secondary"][wl] = {"error": repr(e)}
+                    res["secondary"][name] = measure_simple(torch, ss, wl, device, **kw)
+                except Exception as e:
+                    res["secondary"][name] = {"error": repr(e)}
+            # value_pipelined: the headline workload once more with successive steps going round four HIP streams, 1000 steps with the
+            # settings of secondary.cfg2 -- `value_one_stream` beside it is that leg's value (same steps, same ring, one stream), so the
+            # ratio of the two is streams and nothing else.  (four streams reach the one-launch corpus rate: 2 / 3 / 4 streams +3 / +8 /
+            # +12 % over one on a 2000-step run, profiles/r05/streams.txt)
+            try:
+                pl = measure_simple(torch, ss, "cfg2", device, steps=1000, warmup=100, prewarm_ms=100.0, streams=4, probe_board=False)
+                res["value_pipelined"] = pl["value"]
+                one = res["secondary"]["cfg2"].get("value")
+                res["pipelined"] = {"streams": 4, "steps": pl["steps"], "ms_per_step": pl["ms_per_step"], "kernel": pl["kernel"],
+                                    "value_one_stream": one, "over_one_stream": (pl["value"] / one) if one else None,
+                                    "note": "same workload, successive steps go round four HIP streams (independent batches): a launch's one-unit tail "
+                                            "and the next ones' wait for their first samples overlap; wall time per step over 1000 steps, not a kernel "
+                                            "duration, not part of `roofline`; value_one_stream = secondary.cfg2 (same step count and input ring, one "
+                                            "stream): compare with THAT, not with the 20-step headline; outputs of this concurrent use are checked bit for "
+                                            "bit against serial launches in tests/test_concurrency.py"}
+            except Exception as e:
+                res["value_pipelined"] = None
+                res["pipelined"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
 
     if world > 1:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 6 /* 6: ss_shader_clock_probe; 5: config-free stack_frames entry points, ss_mfcc_shader_clock; the ss_debug_* test aids left the product library */
+#define SS_ABI_VERSION 7 /* 7: ss_mfcc_batches_device, ss_mel_spectrogram_batches_device, ss_mfcc_timed_region; 6: ss_shader_clock_probe; 5: config-free stack_frames entry points, ss_mfcc_shader_clock; the ss_debug_* test aids left the product library */
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -191,6 +191,20 @@ int ss_power_spectrum_batch(const ss_config *cfg, const float *x, size_t batch, 
 
 int ss_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
                          float *d_out, void *stream);
+/* Several independent batches per call (a loop over speechsauce::feature::mfcc, feature.rs:99-148, per clip of every batch):
+ * d_x / batch / d_out are HOST arrays of n_batches entries -- device pointer of batch b's clips [batch[b] x n_samples] (row
+ * stride ld), its clip count, device pointer of its output block [batch[b] x n_frames x num_cepstral].  The arrays are read
+ * before the call returns (nothing keeps pointing at them); batches with batch[b] == 0 are skipped.  Where the configuration's
+ * kernel takes a batch table (fft_points = 512 with the default frame shape and bank: the headline kernel) up to 8 batches share
+ * ONE launch, whose persistent workgroups run over all the batches' frames -- a launch's start-up and its one-unit tail are paid
+ * once per call, not once per batch; other configurations are served batch by batch on `stream`.  Results are bit-identical to
+ * n_batches separate ss_mfcc_batch_device calls either way. */
+int ss_mfcc_batches_device(const ss_config *cfg, size_t n_batches, const float *const *d_x, const size_t *batch, size_t n_samples,
+                           size_t ld, float *const *d_out, void *stream);
+/* the mel_spectrogram2 form (feature.rs:163-174 per block): block b is [channels[b] x n_samples], its output
+ * [channels[b] x num_filters x rows]; served block by block on `stream` */
+int ss_mel_spectrogram_batches_device(const ss_config *cfg, size_t n_batches, const float *const *d_x, const size_t *channels,
+                                      size_t n_samples, size_t ld, float *const *d_out, void *stream);
 int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
                         float *d_feat, float *d_energy, void *stream);
 int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples,
@@ -263,7 +277,9 @@ int ss_power_to_db_device(const float *d_s, size_t n, float ref, float amin, flo
  * `nccl_comm` is the caller's ncclComm_t and MUST come from the RCCL library this one resolves: the copy already mapped
  * into the process (e.g. torch's bundled librccl.so) is preferred, then librccl.so.1 / librccl.so by name;
  * ss_rccl_library(path) names the library explicitly (before the first collective) -- passing a communicator created by a
- * different RCCL copy is undefined behaviour.  Nothing is linked at build time. */
+ * different RCCL copy is undefined behaviour.  Nothing is linked at build time.  The automatic search runs ONCE per process: if
+ * the first collective finds no RCCL (it ran before torch / librccl was mapped), every later collective fails with SS_ERR_HIP
+ * as well until ss_rccl_library(path) is called -- load RCCL first, or name it. */
 int ss_shard_bounds(size_t n_items, int world, int rank, size_t *lo, size_t *hi);
 int ss_rccl_library(const char *path);
 int ss_gather_features(void *nccl_comm, const float *d_block, size_t elems_per_rank, float *d_out, int root, int rank,
@@ -290,6 +306,18 @@ int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_
  * SS_ERR_UNSUPPORTED for configurations served by another kernel. */
 int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_out,
                          void *stream, int launches, float *ghz);
+
+/* A timed region whose duration and shader clock come from the SAME launches (bench.py's secondary.cfg2): `launches` launches of
+ * the MFCC batch kernel on `stream`, launch i reading d_x[i % n_x] and writing d_out[i % n_out] (host arrays of device pointers: a
+ * ring of inputs larger than the 256 MiB Infinity Cache keeps the samples coming from HBM), HIP events recorded on `stream` around
+ * all of them, and the per-wave stamps of the LAST min(stamped, launches, 4096) launches kept, each launch in a slot of its own of
+ * a buffer this call owns.  *avg_ms = region / launches; *ghz = (sum of the waves' shader cycles) / (sum of their lifetimes on
+ * the 100 MHz clock) over every stamped launch; stamped = 0 times only.  *wall_ms (may be NULL) = host time from the first launch
+ * call to the completion of the last launch (the region starts on a synchronised stream; reading the stamps back is not part of
+ * it).  SS_ERR_UNSUPPORTED (after timing) where the launches ran on a kernel without stamps.  Blocks until the region has run. */
+int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t batch, size_t n_samples, size_t ld,
+                         float *const *d_out, size_t n_out, void *stream, int launches, int stamped, float *avg_ms, float *ghz,
+                         float *wall_ms);
 
 /* Shader clock (GHz) of the device while WHATEVER ELSE runs on it: one wave on `stream` sleeps through a lead-in (a tenth of
  * `micros`, at most 200 us), reads the shader-cycle counter and the constant 100 MHz counter, sleeps (no memory traffic, no LDS,

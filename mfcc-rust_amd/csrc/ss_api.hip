@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -189,8 +190,19 @@ void fill_common(const ss_config *cfg, ss::FrontArgs &a)
 // MFCC-path launch (OUT_MFCC / OUT_MFE / OUT_POWER).
 // rows_are_frames: d_x is a frames matrix [batch x n] (row stride ld) -- every row is one frame of n <= fft_points samples,
 // no window, no pre-emphasis (processing::power_spectrum(frames, fft_points), processing.rs:179-181).
+// `multi` (ss_mfcc_batches_device): several independent batches of the same clip shape for ONE launch; d_x / batch / out0 then
+// describe the first of them.  Only the kernel builds that take a batch table serve it: for every other configuration NOTHING is
+// launched and kNoMultiBuild comes back (the caller then launches batch by batch).
+struct MultiBatches {
+    int n;
+    const float *const *x;
+    float *const *out;
+    const size_t *clips;
+};
+constexpr int kNoMultiBuild = -1;
+
 int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t batch, size_t n, size_t ld,
-                  float *out0, float *out1, hipStream_t stream, bool rows_are_frames = false)
+                  float *out0, float *out1, hipStream_t stream, bool rows_are_frames = false, const MultiBatches *multi = nullptr)
 {
     if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
     if (batch == 0) return SS_OK;  // an empty batch has no buffers (a zero-row tensor's data pointer is null)
@@ -305,7 +317,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.fullp = cfg->fast.fullp;
         f.paired = cfg->fast.paired ? (cfg->fast.tight ? 2 : 1) : 0;
 #if SS_LAB
-        if (dbg_path && !dbg_done && !f.out_mfe) {
+        if (dbg_path && !dbg_done && !f.out_mfe && !multi) {
             dbg_done = true;
             const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16;
             DeviceBuf db;
@@ -344,6 +356,13 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
 #if SS_LAB
         if (!f.dbg) f.dbg = g_stamp_buffer.load(std::memory_order_relaxed);
 #endif
+        if (multi) {
+            const hipError_t em = ss::launch_mfcc_c256_multi(f, multi->n, multi->x, multi->out, multi->clips, stream, cfg->num_cus, &info);
+            if (em == hipErrorInvalidValue) return kNoMultiBuild;  // (before the launch: this shape has no batch-table build)
+            if (em != hipSuccess) return hip_fail(em, "launch_mfcc_c256_multi");
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
         const hipError_t e = ss::launch_mfcc_c256(f, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
             g_last_kernel = info.kernel_name;
@@ -352,6 +371,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
         if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mfcc_c256");
     }
+    if (multi) return kNoMultiBuild;  // the other kernels take one batch per launch
     // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra, and the output / window / framing combinations the
     // headline kernel has no build for (ss_mfcc512w.hip): optional frame window, centred frames, fused pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
@@ -1032,6 +1052,52 @@ int ss_mfcc_batch_device(const ss_config *cfg, const float *d_x, size_t batch, s
     return launch_frames(cfg, ss::OUT_MFCC, d_x, batch, n_samples, ld, d_out, nullptr, static_cast<hipStream_t>(stream));
 }
 
+// Several independent batches of equal-length clips per call.  Where the configuration's kernel takes a batch table (the 512-point
+// MFCC kernel's default build: ss_mfcc512.hip, MULTI) up to ss::kMaxLaunchBatches batches share ONE launch -- the persistent
+// workgroups' work range is the concatenation of the batches' frame quads, so a launch's start-up and its one-unit tail are paid
+// once per call instead of once per batch; every other configuration is served batch by batch on the same stream.  Either way the
+// results are those of n_batches separate ss_mfcc_batch_device calls, bit for bit.
+int ss_mfcc_batches_device(const ss_config *cfg, size_t n_batches, const float *const *d_x, const size_t *batch, size_t n_samples,
+                           size_t ld, float *const *d_out, void *stream)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (n_batches == 0) return SS_OK;
+    if (!d_x || !batch || !d_out) return ss::fail(SS_ERR_ARG, "null batch table");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    {
+        size_t T = 0;  // the clip shape is checked before anything is launched (every batch has the same one)
+        const int rc = ss::num_frames(cfg->host.params, n_samples, T);
+        if (rc) return rc;
+    }
+    std::vector<const float *> xs;
+    std::vector<float *> outs;
+    std::vector<size_t> clips;
+    for (size_t b = 0; b < n_batches; ++b) {
+        if (batch[b] == 0) continue;  // an empty batch has no buffers
+        if (!d_x[b] || !d_out[b]) return ss::fail(SS_ERR_ARG, "null buffer in batch " + std::to_string(b));
+        if (batch[b] > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "batch too large");
+        xs.push_back(d_x[b]);
+        outs.push_back(d_out[b]);
+        clips.push_back(batch[b]);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t g0 = 0; g0 < xs.size(); g0 += ss::kMaxLaunchBatches) {
+        const size_t gn = std::min<size_t>(ss::kMaxLaunchBatches, xs.size() - g0);
+        int rc = kNoMultiBuild;
+        if (gn > 1) {
+            const MultiBatches mb{static_cast<int>(gn), xs.data() + g0, outs.data() + g0, clips.data() + g0};
+            rc = launch_frames(cfg, ss::OUT_MFCC, xs[g0], clips[g0], n_samples, ld, outs[g0], nullptr, st, false, &mb);
+        }
+        if (rc == kNoMultiBuild) {
+            rc = SS_OK;
+            for (size_t b = g0; b < g0 + gn && rc == SS_OK; ++b)
+                rc = launch_frames(cfg, ss::OUT_MFCC, xs[b], clips[b], n_samples, ld, outs[b], nullptr, st);
+        }
+        if (rc) return rc;
+    }
+    return SS_OK;
+}
+
 int ss_mfe_batch_device(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld,
                         float *d_feat, float *d_energy, void *stream)
 {
@@ -1484,6 +1550,24 @@ int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t cha
     return launch_stft(cfg, ss::OUT_MEL, d_x, channels, n_samples, ld, d_out, static_cast<hipStream_t>(stream));
 }
 
+// The mel-spectrogram form of ss_mfcc_batches_device: n_batches independent [channels[b] x n_samples] blocks, each with its own
+// output block; served block by block on `stream` (the STFT-path kernels take one block per launch).
+int ss_mel_spectrogram_batches_device(const ss_config *cfg, size_t n_batches, const float *const *d_x, const size_t *channels,
+                                      size_t n_samples, size_t ld, float *const *d_out, void *stream)
+{
+    if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
+    if (n_batches == 0) return SS_OK;
+    if (!d_x || !channels || !d_out) return ss::fail(SS_ERR_ARG, "null batch table");
+    if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
+    for (size_t b = 0; b < n_batches; ++b)
+        if (channels[b] && (!d_x[b] || !d_out[b])) return ss::fail(SS_ERR_ARG, "null buffer in batch " + std::to_string(b));
+    for (size_t b = 0; b < n_batches; ++b) {
+        const int rc = launch_stft(cfg, ss::OUT_MEL, d_x[b], channels[b], n_samples, ld, d_out[b], static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
+    return SS_OK;
+}
+
 int ss_stft_device(const ss_config *cfg, const float *d_x, size_t channels, size_t n_samples, size_t ld,
                    float *d_out, void *stream)
 {
@@ -1658,6 +1742,106 @@ int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, s
     }
     if (n == 0) return ss::fail(SS_ERR_DEVICE, "no wave reported its lifetime");
     *ghz = static_cast<float>(sum / static_cast<double>(n));
+    return SS_OK;
+}
+
+namespace {
+// Sums of the per-wave stamps of ss_mfcc_timed_region's launches: sums[0] += shader cycles lived, sums[1] += 100 MHz ticks lived,
+// sums[2] += waves counted, over the `n` six-word wave records that carry a lifetime (the two table waves of a workgroup report
+// something else in word 5 and are skipped, as are records of waves that never ran).
+static __global__ __launch_bounds__(256) void stamp_sums_kernel(const unsigned long long *w, unsigned long long n, unsigned long long *sums)
+{
+    unsigned long long cyc = 0, ticks = 0, cnt = 0;
+    for (unsigned long long k = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; k < n;
+         k += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        const unsigned long long t0 = w[6 * k], t1 = w[6 * k + 2], c = w[6 * k + 5];
+        if (t1 <= t0 || (c >> 40) != 1) continue;
+        cyc += c & ((1ull << 40) - 1);
+        ticks += t1 - t0;
+        ++cnt;
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+        cyc += __shfl_xor(cyc, m, 64);
+        ticks += __shfl_xor(ticks, m, 64);
+        cnt += __shfl_xor(cnt, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&sums[0], cyc);
+        atomicAdd(&sums[1], ticks);
+        atomicAdd(&sums[2], cnt);
+    }
+}
+}  // namespace
+
+// A timed region whose duration AND shader clock come from the same launches: `launches` launches of the MFCC batch kernel on
+// `stream`, launch i reading d_x[i % n_x] and writing d_out[i % n_out] (a ring of inputs larger than the Infinity Cache keeps the
+// samples coming from HBM), HIP events on `stream` around all of them, and the per-wave stamps of the LAST `stamped` launches kept,
+// each launch in a slot of its own of a buffer this call owns.  *avg_ms = region / launches; *ghz = sum of the waves' shader
+// cycles / sum of their lifetimes on the 100 MHz clock over every stamped launch.
+int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t batch, size_t n_samples, size_t ld,
+                         float *const *d_out, size_t n_out, void *stream, int launches, int stamped, float *avg_ms, float *ghz,
+                         float *wall_ms)
+{
+    if (!cfg || !d_x || !d_out || n_x == 0 || n_out == 0 || launches <= 0 || stamped < 0 || !avg_ms || !ghz)
+        return ss::fail(SS_ERR_ARG, "bad timed-region request");
+    *avg_ms = 0.f;
+    *ghz = 0.f;
+    if (wall_ms) *wall_ms = 0.f;
+    if (stamped > launches) stamped = launches;
+    if (stamped > 4096) stamped = 4096;  // 196 KB of wave records per stamped launch
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nwaves = static_cast<size_t>(cfg->num_cus) * 16, words = nwaves * 6;
+    DeviceBuf db;
+    int rc = db.alloc(std::max<size_t>(1, static_cast<size_t>(stamped)) * words * sizeof(unsigned long long));
+    if (rc) return rc;
+    if (stamped) SS_HIP(hipMemsetAsync(db.p, 0, static_cast<size_t>(stamped) * words * sizeof(unsigned long long), s));
+    hipEvent_t e0, e1;
+    SS_HIP(hipEventCreate(&e0));
+    {
+        const hipError_t ec = hipEventCreate(&e1);
+        if (ec != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return hip_fail(ec, "hipEventCreate");
+        }
+    }
+    SS_HIP(hipStreamSynchronize(s));  // the region starts on an idle stream (the memset above is not part of it)
+    const auto w0 = std::chrono::steady_clock::now();
+    (void)hipEventRecord(e0, s);
+    bool all_stamped = true;
+    for (int i = 0; i < launches && rc == SS_OK; ++i) {
+        const int slot = i - (launches - stamped);
+        g_call_stamps = slot >= 0 ? db.as<unsigned long long>() + static_cast<size_t>(slot) * words : nullptr;
+        rc = ss_mfcc_batch_device(cfg, d_x[static_cast<size_t>(i) % n_x], batch, n_samples, ld, d_out[static_cast<size_t>(i) % n_out], stream);
+        if (slot >= 0 && std::strncmp(g_last_kernel, "ss_mfcc_c256<", 13) != 0) all_stamped = false;
+    }
+    g_call_stamps = nullptr;
+    (void)hipEventRecord(e1, s);
+    hipError_t e = hipSuccess;
+    while ((e = hipEventQuery(e1)) == hipErrorNotReady) {  // polled: a blocking wait's wake-up latency is several launches long
+    }
+    if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "event timing");
+    *avg_ms = ms / static_cast<float>(launches);
+    if (stamped == 0) return SS_OK;
+    if (!all_stamped) return ss::fail(SS_ERR_UNSUPPORTED, "the shader-clock stamps exist in the 512-point MFCC kernel only");
+    // the records are summed on the device (1000 stamped launches are 196 MB of them): three words come back
+    DeviceBuf sums;
+    rc = sums.alloc(3 * sizeof(unsigned long long));
+    if (rc) return rc;
+    SS_HIP(hipMemsetAsync(sums.p, 0, 3 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(stamp_sums_kernel, dim3(1024), dim3(256), 0, s, db.as<unsigned long long>(),
+                       static_cast<unsigned long long>(stamped) * nwaves, sums.as<unsigned long long>());
+    SS_HIP(hipGetLastError());
+    unsigned long long hs[3] = {0, 0, 0};
+    SS_HIP(hipMemcpyAsync(hs, sums.p, sizeof hs, hipMemcpyDeviceToHost, s));
+    SS_HIP(hipStreamSynchronize(s));
+    if (hs[1] == 0 || hs[2] == 0) return ss::fail(SS_ERR_DEVICE, "no wave reported its lifetime");
+    *ghz = static_cast<float>(static_cast<double>(hs[0]) / (static_cast<double>(hs[1]) * 10.0));  // cycles per ns
     return SS_OK;
 }
 

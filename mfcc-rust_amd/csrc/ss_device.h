@@ -143,6 +143,21 @@ struct Fast512Args {
 };
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+
+// Several independent batches in ONE launch of that kernel (ss_mfcc_batches_device): the second kernel argument.  Batch b has its
+// own input block x[b] (clips of a.n_samples at row stride a.ld) and output block out[b]; its quads are [qend[b-1], qend[b]) of the
+// launch's quad range (entries past the last batch: 0xffffffff), total[b] = its clips * n_frames.  Filled by launch_mfcc_c256_multi.
+constexpr int kMaxLaunchBatches = 8;
+struct Fast512Multi {
+    const float *x[kMaxLaunchBatches];
+    float *out[kMaxLaunchBatches];
+    uint32_t qend[kMaxLaunchBatches];
+    uint32_t total[kMaxLaunchBatches];
+};
+// a: the argument block of one batch (x / out / batch are ignored); d_x / d_out / clips: n_batches <= kMaxLaunchBatches entries.
+// hipErrorInvalidValue before the launch: the configuration has no multi-batch build (the caller launches batch by batch).
+hipError_t launch_mfcc_c256_multi(const Fast512Args &a, int n_batches, const float *const *d_x, float *const *d_out, const size_t *clips,
+                                  hipStream_t stream, int num_cus, LaunchInfo *info);
 // whether the kernel has an mfe-output / windowed / pre-emphasised build for this shape (the default bank at flen 320)
 bool mfcc_c256_has_mfe(const Fast512Args &a);
 

@@ -53,6 +53,7 @@
 #include "ss_internal.h"
 #include "ss_wave.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 // Timing-attribution builds (lab build only: tools/ablate.sh passes -DSS_LAB=1 -DSS_ABLATE=<bits>): each bit removes one
@@ -316,9 +317,43 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
+// MULTI builds (MULTI = true; ss_mfcc_batches_device): the launch's quad range is the concatenation of up to kMaxLaunchBatches
+// independent batches' quad ranges, each batch with its own input and output block.  Which batch a quad belongs to is scalar work
+// (the quad index is uniform): a wave keeps the batch of its current quad (output block) and of the quad it prefetches (input
+// block) in SGPRs and looks the table up again only when a claimed quad lies past that batch's last one -- quads are claimed in
+// increasing order, so that is once per batch boundary a wave crosses.  Inside a batch everything is the single-batch arithmetic
+// on the batch-local quad index: results are bit-identical to one launch per batch.
+struct Seg {
+    const float *x;
+    float *out;
+    unsigned q0, q1, total;  // the batch's quads are [q0, q1) of the launch; total = its clips * n_frames
+};
+__device__ __forceinline__ Seg seg_of(const Fast512Multi &m, unsigned g)  // g: uniform
+{
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxLaunchBatches - 1; ++k) s += g >= m.qend[k] ? 1u : 0u;  // (entries past the last batch hold 0xffffffff)
+    Seg r;
+    r.x = m.x[s];
+    r.out = m.out[s];
+    r.q1 = m.qend[s];
+    r.q0 = s ? m.qend[s - 1] : 0u;
+    r.total = m.total[s];
+    return r;
+}
+
+// second kernel argument: the batch table of a MULTI build, nothing otherwise
+template <bool MULTI>
+struct MultiArg {
+};
+template <>
+struct MultiArg<true> {
+    Fast512Multi m;
+};
+
 template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, int OUTK = 0, int FRONT = 0, bool FULLP = false,
-          bool CENTER = false>
-__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_in)
+          bool CENTER = false, bool MULTI = false>
+__global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_in, const MultiArg<MULTI> mt)
 {
     // Everything in front of a wave's first sample loads is start-up latency of the launch (nothing can be computed before
     // the samples are here), so the kernel arguments that lead to those loads are fetched by ONE batch of scalar loads at the
@@ -394,7 +429,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
     float2 vin[NE];
     float2 pin[PRE ? NE : 1];
     unsigned t_next = 0;  // frame index within the clip of the quad whose samples are in vin
-    t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
+    Seg ns{};                // MULTI: the batch of the quad whose samples are being fetched ...
+    Fast512Args an = a_in;   // ... and the argument block with that batch's input
+    if constexpr (MULTI) {
+        an = a;
+        ns = seg_of(mt.m, min(quad, q_hi - 1));
+        an.x = ns.x;
+        t_next = load_quad<NE, EXACT, PRE, CENTER>(an, min(quad, q_hi - 1) - ns.q0, ns.total, f, j, vin, pin);
+    } else {
+        t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
+    }
     if (wave < kTabWaves) {
         // (pinned: the compiler otherwise sinks each load next to its store, one memory round trip per float4)
 #pragma unroll
@@ -498,6 +542,8 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
 
     SS_PRIOL(SS_P2_TOP);
     while (quad < q_hi) {
+        const Seg cs = ns;  // MULTI: the batch of this iteration's quad (its samples were fetched from it)
+        (void)cs;
         // claim the next quad now so that its samples can be prefetched during this one
         // (the claim is issued here and read behind the first butterfly, where the prefetch needs it: read at once, the LDS
         // atomic's round trip was exposed at the top of every iteration)
@@ -551,8 +597,18 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         // order: behind a burst of vector-memory instructions its own VALU work waits); no branch surrounds them -- the last
         // iteration of a wave fetches the block's last quad again and drops it
         constexpr bool SPREAD = PREFETCH && EXACT && !PRE && !CENTER && !(SS_ABLATE & 16);
+        static_assert(!MULTI || (SPREAD && OUTK == 0), "the multi-batch build exists for the spread-prefetch MFCC builds");
         QuadSrc nsrc{nullptr, 0u};
-        if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, j, t_next);
+        if constexpr (MULTI) {
+            const unsigned nq = min(next, q_hi - 1);
+            if (nq >= ns.q1) {  // (uniform, rare: the claimed quad starts the next batch)
+                ns = seg_of(mt.m, nq);
+                an.x = ns.x;
+            }
+            nsrc = quad_src(an, nq - ns.q0, ns.total, f, j, t_next);
+        } else {
+            if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, j, t_next);
+        }
         if (!SPREAD && PREFETCH && next < q_hi && !(SS_ABLATE & 16)) t_next = load_quad<NE, EXACT, PRE, CENTER>(a, next, total, f, j, vin, pin);
         float2 u[16];
 #pragma unroll
@@ -819,9 +875,16 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             // unconditional, counted store (ss_wave.h): the descriptor covers the quad's valid frames, lanes j >= n_ceps are
             // dropped by its range check -- the next quad's samples are waited for with this store still in flight
             (void)gf;
-            const unsigned quad_s = __builtin_amdgcn_readfirstlane(quad);  // uniform, but born from the wave number: a VGPR to the compiler
-            const unsigned nvalid = min(4u, total - quad_s * 4);
-            const __amdgpu_buffer_rsrc_t orow = out_rsrc(a.out + static_cast<unsigned long long>(quad_s) * 4ull * Cc, nvalid * Cc * 4u);
+            unsigned quad_s = __builtin_amdgcn_readfirstlane(quad);  // uniform, but born from the wave number: a VGPR to the compiler
+            unsigned q_total = total;
+            float *q_out = a.out;
+            if constexpr (MULTI) {  // this quad's batch: its own output block, the quad's index and the frame count within it
+                quad_s -= cs.q0;
+                q_total = cs.total;
+                q_out = cs.out;
+            }
+            const unsigned nvalid = min(4u, q_total - quad_s * 4);
+            const __amdgpu_buffer_rsrc_t orow = out_rsrc(q_out + static_cast<unsigned long long>(quad_s) * 4ull * Cc, nvalid * Cc * 4u);
             buf_store(o, orow, j < Cc ? (f * Cc + j) * 4 : kOobOffset);
         }
         wave_order();
@@ -896,7 +959,7 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
             if (e != hipSuccess) return e;
         }
         if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a, MultiArg<false>{});
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2;
@@ -983,6 +1046,66 @@ hipError_t launch_w(const Fast512Args &a_in, hipStream_t stream, int num_cus, La
 }
 
 }  // namespace
+
+hipError_t launch_mfcc_c256_multi(const Fast512Args &a_in, int n_batches, const float *const *d_x, float *const *d_out, const size_t *clips,
+                                  hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    constexpr int WAVES = 12;
+    Fast512Args a = a_in;
+    // the builds that exist: MFCC output of the default frame shape and bank (what launch_w's first branch serves without a
+    // window, pre-emphasis or another output), 40 filters in the paired tight-tap layout -- the headline build
+    const bool b421 = a.mel_q4[0] == 4 && a.mel_q4[1] == 2 && a.mel_q4[2] == 1;
+    if (n_batches < 1 || n_batches > kMaxLaunchBatches || a.fullp || a.center || a.out_mfe || a.win_floats > 0 || a.preemph != 0.0f ||
+        a.flen != 320 || a.spectrum_exponent == 2 || !b421 || a.n_filters != 40 || a.paired != 2 || a.n_frames < 4)
+        return hipErrorInvalidValue;
+    Fast512Multi m{};
+    unsigned long long quads = 0, max_total = 0;
+    for (int b = 0; b < kMaxLaunchBatches; ++b) {
+        m.qend[b] = 0xffffffffu;
+        if (b >= n_batches) continue;
+        const unsigned long long tot = static_cast<unsigned long long>(clips[b]) * a.n_frames;
+        if (tot == 0 || tot + 4 >= (1ull << 31)) return hipErrorInvalidValue;  // (empty batches are dropped by the caller)
+        quads += (tot + 3) / 4;
+        if (quads >= 0xffffffffull) return hipErrorInvalidValue;
+        max_total = std::max(max_total, tot);
+        m.x[b] = d_x[b];
+        m.out[b] = d_out[b];
+        m.qend[b] = static_cast<uint32_t>(quads);
+        m.total[b] = static_cast<uint32_t>(tot);
+    }
+    {
+        // the same reciprocal and address-range conditions as launch_w (every batch has the same clip shape)
+        const unsigned long long d = a.n_frames;
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l;
+        const unsigned __int128 num = static_cast<unsigned __int128>(1) << (31 + l);
+        a.nf_magic = static_cast<uint32_t>((num + d - 1) / d);
+        a.nf_shift = l - 1;
+        const unsigned long long span = static_cast<unsigned long long>(a.n_frames) * a.step;
+        if (a.ld < span || static_cast<unsigned long long>(a.step) * 4ull >= (1ull << 24) ||
+            3ull * a.step * 4ull + (a.ld - span) * 4ull + 16ull * 8ull + 16ull * 128ull >= (1ull << 32))
+            return hipErrorInvalidValue;
+    }
+    a.x = d_x[0];
+    a.out = d_out[0];
+    a.batch = static_cast<uint32_t>(clips[0]);
+    const size_t lds = (static_cast<size_t>(WAVES) * kWaveFloats + L::kMelW + 16 * a.mel_wpitch) * sizeof(float) + 16;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    unsigned long long blocks = (quads + WAVES - 1) / WAVES;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    if (blocks > cap) blocks = cap;
+    const unsigned grid = static_cast<unsigned>(blocks);
+    a.q_base = static_cast<uint32_t>(quads / grid);
+    a.q_rem = static_cast<uint32_t>(quads % grid);
+    auto kern = ss_mfcc_c256<10, true, false, WAVES, true, 10, 30, 0, 0, false, false, true>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    if (info) *info = LaunchInfo{"ss_mfcc_c256m<10,exact,bank421,sym>", grid, static_cast<unsigned>(WAVES * 64), lds};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a, MultiArg<true>{m});
+    return hipGetLastError();
+}
 
 bool mfcc_c256_has_mfe(const Fast512Args &a)
 {

@@ -231,9 +231,43 @@ def mfcc(signal, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_
     return _internal_mfcc_batch(sig[None, :], config)[0]
 
 
+def _internal_mfcc_batches(signals, config: SpeechConfig):
+    """Several [B_i, L] batches (same L) -> list of [B_i, T, num_cepstral]: ONE ss_mfcc_batches_device call for device tensors
+    (one launch for up to 8 batches where the kernel takes a batch table), one host call per batch for numpy arrays."""
+    if not all(_is_torch(x) and x.is_cuda for x in signals):
+        return [_internal_mfcc_batch(x, config) for x in signals]
+    import torch
+
+    lib = _lib.lib()
+    dev = signals[0].device
+    L = signals[0].shape[1]
+    if any(x.device != dev or x.shape[1] != L for x in signals):
+        raise ValueError("mfcc_batch: the batches of one call must live on one device and hold clips of one length")
+    T = config.num_frames(L)
+    Cc = config.params.num_cepstral
+    xs = [x if (x.stride(1) == 1 and (x.shape[0] <= 1 or x.stride(0) == L)) else x.contiguous() for x in signals]
+    outs = [torch.empty((x.shape[0], T, Cc), dtype=torch.float32, device=dev) for x in xs]
+    n = len(xs)
+    px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    po = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    nb = (C.c_size_t * n)(*[x.shape[0] for x in xs])
+    with torch.cuda.device(dev):
+        _lib.check(lib.ss_mfcc_batches_device(config.handle, n, px, nb, L, L, po, _stream_ptr()))
+    return outs
+
+
 def mfcc_batch(signals, sampling_frequency, frame_length=0.020, frame_stride=0.01, num_cepstral=13, num_filters=40,
                fft_length=512, low_frequency=0, high_frequency=None, dc_elimination=True, **switches):
-    """Batch form: [B, L] float32 -> [B, num_frames, num_cepstral] in one launch."""
+    """Batch form: [B, L] float32 -> [B, num_frames, num_cepstral] in one launch.  A list / tuple of such batches (same clip
+    length; e.g. the blocks a data loader hands over) -> the list of their feature blocks from ONE call: device tensors share one
+    kernel launch where the configuration's kernel takes a batch table (ss_mfcc_batches_device)."""
+    if isinstance(signals, (list, tuple)):
+        sigs = [_require_f32(x, (2,), "mfcc_batch") for x in signals]
+        if not sigs:
+            return []
+        config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                      low_frequency, high_frequency, dc_elimination, switches, sigs[0])
+        return _internal_mfcc_batches(sigs, config)
     sig = _require_f32(signals, (2,), "mfcc_batch")
     config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
                   low_frequency, high_frequency, dc_elimination, switches, sig)

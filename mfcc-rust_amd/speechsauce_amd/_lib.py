@@ -15,7 +15,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd.so")
 # the lab build (same sources, -DSS_LAB=1): the only library that exports the ss_debug_* test aids
 LAB_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libspeechsauce_amd_lab.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SS_OK, SS_ERR_SHORT_SIGNAL, SS_ERR_BAD_CONFIG, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_UNSUPPORTED, SS_ERR_DEVICE = range(7)
 FRAMING = {"contract": 0, "literal": 1, "center": 2, "padded": 3}
@@ -95,6 +95,10 @@ PROTOTYPES = {
     "ss_mfe_batch": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp]),
     "ss_mfcc_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_mfe_batch_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, _fp, C.c_void_p]),
+    "ss_mfcc_batches_device": (C.c_int, [_cfg, C.c_size_t, _P(C.c_void_p), _P(C.c_size_t), C.c_size_t, C.c_size_t, _P(C.c_void_p), C.c_void_p]),
+    "ss_mel_spectrogram_batches_device": (C.c_int, [_cfg, C.c_size_t, _P(C.c_void_p), _P(C.c_size_t), C.c_size_t, C.c_size_t, _P(C.c_void_p), C.c_void_p]),
+    "ss_mfcc_timed_region": (C.c_int, [_cfg, _P(C.c_void_p), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P(C.c_void_p), C.c_size_t, C.c_void_p,
+                                       C.c_int, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "ss_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_preemphasis_device": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp, C.c_void_p]),
     "ss_lmfe": (C.c_int, [_cfg, _fp, C.c_size_t, _fp]),

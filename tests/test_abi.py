@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported(sslib):
     for n in names:
         assert hasattr(sslib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in the Python front"
-    assert sslib.ss_abi_version() == 6
+    assert sslib.ss_abi_version() == 7
 
 
 def test_the_lab_library_carries_the_test_aids(sslab):
@@ -54,7 +54,7 @@ def test_the_lab_library_carries_the_test_aids(sslab):
     assert len(names) >= 5
     for n in names:
         assert hasattr(sslab, n) and n in _lib.LAB_PROTOTYPES, n
-    assert sslab.ss_abi_version() == 6
+    assert sslab.ss_abi_version() == 7
 
 
 def test_the_product_library_exports_only_the_documented_abi():

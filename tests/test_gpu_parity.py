@@ -995,9 +995,9 @@ def test_cfg4_corpus_properties(ss, oracle):
 
 def test_bench_default_line_carries_the_contract_and_the_secondary_configs():
     """The driver's command (`python bench.py --steps 20 --warmup 5`, here with a short CPU leg): ONE JSON line with the contract's
-    keys, `roofline` and `cpu_baseline` (the port built on this host, its flags named), and -- round 5 -- the other BASELINE
-    configurations (`secondary`: the kernels of BENCH_KERNELS, the ones the parity tests above compare with the oracle), the
-    two-stream figure and shader cycles beside the times."""
+    keys, `roofline` and `cpu_baseline` (the port built on this host, its flags named), the other BASELINE configurations
+    (`secondary`: the kernels of BENCH_KERNELS, the ones the parity tests above compare with the oracle), the four-stream figure with
+    its one-stream twin, and -- round 6 -- `secondary.cfg2` (time and clock from the same 1000 launches) and `secondary.cfg2_x4`."""
     import json
     import subprocess
     import sys
@@ -1018,11 +1018,24 @@ def test_bench_default_line_carries_the_contract_and_the_secondary_configs():
     assert r["algorithmic_bytes_per_launch"] == 70754304 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert abs(r["achieved"] - 70754304 / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert 0.9 < r["traffic"] / 70754304 < 1.1 and 1.0 < r["clock_ghz_measured"] < 2.6
-    assert abs(r["cycles_per_launch"] - r["avg_launch_us"] * 1e3 * r["clock_ghz_measured"]) < 1.0
+    # the 20-step headline prints no cycle count: its clock comes from later launches (round 6) -- secondary.cfg2 carries the coherent one
+    assert r["cycles_per_launch"] is None and "secondary.cfg2" in r["cycles_per_launch_see"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e4 and ("-O3 -march=native" in c["sample"] or "portable" in c["sample"])
-    assert d["value_pipelined"] > 0.9 * d["value"] and d["pipelined"]["streams"] == 4
     sec = d["secondary"]
+    s2 = sec["cfg2"]  # 1000 single-stream steps inside the library: events and in-kernel stamps over the same launches
+    assert "error" not in s2, s2
+    assert s2["kernel"].encode() == BENCH_KERNELS["cfg2"] and s2["steps"] == 1000 and s2["streams"] == 1
+    assert "timed launches themselves" in s2["clock_source"] and 1.0 < s2["clock_ghz_measured"] < 2.6
+    assert abs(s2["cycles_per_launch"] - s2["avg_launch_us"] * 1e3 * s2["clock_ghz_measured"]) < 1.0
+    assert 0.2 < s2["frac"] < 0.6 and 0.3 < s2["valu_floor_frac"] < 0.8
+    x4 = sec["cfg2_x4"]  # four batches per launch (ss_mfcc_batches_device): per-batch figures
+    assert "error" not in x4, x4
+    assert x4["kernel"] == "ss_mfcc_c256m<10,exact,bank421,sym>" and x4["batches_per_launch"] == 4
+    assert x4["algorithmic_bytes_per_launch"] == 70754304 and abs(x4["launch_us"] - 4 * x4["avg_launch_us"]) < 1e-6
+    assert 0.9 * s2["frac"] < x4["frac"] < 0.6
+    assert d["value_pipelined"] > 0.9 * d["value"] and d["pipelined"]["streams"] == 4
+    assert d["pipelined"]["value_one_stream"] == s2["value"] and d["pipelined"]["steps"] == 1000
     for wl, bytes_ in (("cfg3", 82313216), ("cfg5", 93511680), ("cfg4", 24874560000)):
         e = sec[wl]
         assert "error" not in e, e
