@@ -275,10 +275,13 @@ impl SpeechConfig {
     fn raw(&self) -> *const SsConfig { self.handle.0 }
 }
 
-fn contiguous(signal: ArrayView1<f32>) -> std::borrow::Cow<[f32]> {
-    match signal.as_slice() {
+/// The samples of a 1-D view as one contiguous run: borrowed when the view already is one, copied otherwise (the reference accepts
+/// any stride, `as_array()`).  `ArrayView::to_slice(&self) -> Option<&'a [A]>` hands out the VIEW's lifetime; `ArrayBase::as_slice`
+/// would borrow from the by-value parameter, a local (E0515).
+fn contiguous<'a>(signal: ArrayView1<'a, f32>) -> std::borrow::Cow<'a, [f32]> {
+    match signal.to_slice() {
         Some(s) => std::borrow::Cow::Borrowed(s),
-        None => std::borrow::Cow::Owned(signal.to_vec()),  // the reference accepts any stride (as_array())
+        None => std::borrow::Cow::Owned(signal.to_vec()),
     }
 }
 
@@ -321,8 +324,8 @@ pub fn lmfe(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> { try_lm
 pub fn try_mel_spectrogram2(signal: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<f32>, Error> {
     let owned = signal.as_standard_layout();
     let (ch, n) = owned.dim();
-    let (mut rows, mut real) = (0usize, 0usize);
-    check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut real) })?;
+    let (mut rows, mut _real) = (0usize, 0usize);
+    check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut _real) })?;
     let mut out = Array3::<f32>::zeros((ch, cfg.num_filters, rows));
     check(unsafe { ss_mel_spectrogram(cfg.raw(), owned.as_ptr(), ch, n, out.as_mut_ptr()) })?;
     Ok(out)
@@ -333,7 +336,7 @@ pub fn mel_spectrogram2(signal: ArrayView2<f32>, cfg: &SpeechConfig) -> Array3<f
 /// feature.rs:151-162 (one channel)
 pub fn mel_spectrogram1(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<f32> {
     let x = contiguous(signal);
-    let v = ArrayView2::from_shape((1, x.len()), &x).expect("shape");
+    let v = ArrayView2::from_shape((1, x.len()), &x[..]).expect("shape");  // (&x[..]: a plain &[f32], no deref coercion of &Cow needed)
     let out = mel_spectrogram2(v, cfg);
     let (_, m, r) = out.dim();
     out.into_shape((m, r)).expect("shape")
@@ -362,8 +365,8 @@ pub unsafe fn mfcc_batch_device(cfg: &SpeechConfig, d_x: *const f32, batch: usiz
 pub fn try_stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<Complex32>, Error> {
     let owned = input.as_standard_layout();
     let (ch, n) = owned.dim();
-    let (mut rows, mut real) = (0usize, 0usize);
-    check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut real) })?;
+    let (mut rows, mut _real) = (0usize, 0usize);
+    check(unsafe { ss_stft_rows(&cfg.params, n, &mut rows, &mut _real) })?;
     let mut out = Array3::<Complex32>::zeros((ch, rows, cfg.freq_size));
     // Complex32 is #[repr(C)] { re: f32, im: f32 }: the interleaved block the ABI writes
     check(unsafe { ss_stft(cfg.raw(), owned.as_ptr(), ch, n, out.as_mut_ptr() as *mut f32) })?;
@@ -374,7 +377,7 @@ pub fn stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Array3<Complex32> { 
 /// functions.rs:199-233 (one channel): `Array2<Complex32>` `[rows, freq_size]`
 pub fn stft1(input: ArrayView1<f32>, cfg: &SpeechConfig) -> Array2<Complex32> {
     let x = contiguous(input);
-    let v = ArrayView2::from_shape((1, x.len()), &x).expect("shape");
+    let v = ArrayView2::from_shape((1, x.len()), &x[..]).expect("shape");
     let out = stft2(v, cfg);
     let (_, r, f) = out.dim();
     out.into_shape((r, f)).expect("shape")
@@ -420,9 +423,9 @@ pub fn stack_frames(signal: ArrayView1<f32>, sample_rate: usize, frame_length: f
 /// centred framing exist only in this form).  An extra beside the reference's signature above.
 pub fn try_stack_frames_with(signal: ArrayView1<f32>, cfg: &SpeechConfig) -> Result<Array2<f32>, Error> {
     let x = contiguous(signal);
-    let (mut t, mut flen, mut step) = (0usize, 0usize, 0usize);
+    let (mut t, mut flen, mut _step) = (0usize, 0usize, 0usize);
     check(unsafe { ss_num_frames(&cfg.params, x.len(), &mut t) })?;
-    check(unsafe { ss_frame_sizes(&cfg.params, &mut flen, &mut step) })?;
+    check(unsafe { ss_frame_sizes(&cfg.params, &mut flen, &mut _step) })?;
     let mut out = Array2::<f32>::zeros((t, flen));
     check(unsafe { ss_stack_frames(cfg.raw(), x.as_ptr(), x.len(), out.as_mut_ptr()) })?;
     Ok(out)
@@ -570,13 +573,14 @@ pub fn triangle(arr: Array1<f32>, left: f32, middle: f32, right: f32) -> Array1<
 /// functions.rs:66-71: exact zeros become f32::EPSILON
 pub fn zero_handling<D: Dimension>(x: Array<f32, D>) -> Array<f32, D> { x.mapv(|v| if v == 0.0 { f32::EPSILON } else { v }) }
 
-/// util.rs:372-381: natural logarithm of every element, in place
-pub trait ArrayLog<D: Dimension> {
-    fn log(self) -> Array<f32, D>;
+/// util.rs:372-381: natural logarithm of every element, in place.  Two type parameters with the reference's bounds, so that caller
+/// code naming `ArrayLog<f32, Ix2>` (or bounding on it) resolves unchanged.
+pub trait ArrayLog<A: num_traits::real::Real, I: Dimension> {
+    fn log(self) -> Array<A, I>;
 }
-impl<D: Dimension> ArrayLog<D> for Array<f32, D> {
-    fn log(mut self) -> Array<f32, D> {
-        self.mapv_inplace(f32::ln);
+impl<A: num_traits::real::Real, I: Dimension> ArrayLog<A, I> for Array<A, I> {
+    fn log(mut self) -> Array<A, I> {
+        self.map_inplace(|n| *n = (*n).ln());
         self
     }
 }

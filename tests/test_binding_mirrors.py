@@ -193,6 +193,43 @@ def test_rust_shim_is_drop_in_by_module_path_on_paper():
     assert "assert" not in body and "SS_ERR_ARG" in body and "u32::MAX" in body
 
 
+def test_rust_shim_paper_compile_guards():
+    """Round 6: the shim was read line by line as rustc would.  One textual guard per defect found, plus the
+    mechanical conditions of that walk.  The shim is STILL NEVER COMPILED."""
+    rs = open(SHIM).read()
+    code = re.sub(r"//[^\n]*", "", rs)  # comments may name the wrong forms
+    flat = re.sub(r"\s+", " ", code)
+    # 1. contiguous(): the view's own lifetime (ArrayView::to_slice), written out -- not a borrow of the by-value parameter
+    assert "fn contiguous<'a>(signal: ArrayView1<'a, f32>) -> std::borrow::Cow<'a, [f32]>" in flat
+    assert "signal.to_slice()" in flat and ".as_slice()" not in code
+    # 2. ArrayLog carries the reference's two type parameters and bounds (util.rs:372-381)
+    assert "pub trait ArrayLog<A: num_traits::real::Real, I: Dimension> { fn log(self) -> Array<A, I>; }" in flat
+    assert "impl<A: num_traits::real::Real, I: Dimension> ArrayLog<A, I> for Array<A, I>" in flat
+    cargo = open(os.path.join(os.path.dirname(os.path.dirname(SHIM)), "Cargo.toml")).read()
+    assert re.search(r'^num-traits\s*=', cargo, flags=re.M) and re.search(r'^ndarray\s*=\s*"\^0\.15"', cargo, flags=re.M)
+    if os.path.exists("/root/reference"):
+        ref = re.sub(r"\s+", " ", open("/root/reference/speechsauce/src/util.rs").read())
+        assert "pub trait ArrayLog<A: num_traits::real::Real, I: ndarray::Dimension> { fn log(self) -> Array<A, I>; }" in ref
+    # 3. slices handed to ArrayView2::from_shape are plain &[f32]
+    assert flat.count("ArrayView2::from_shape((1, x.len()), &x[..])") == 2 and "from_shape((1, x.len()), &x)" not in flat
+    # 4. every extern declaration is called somewhere, and every call of an ss_ function has a declaration
+    declared = set(rust_externs())
+    body = code[code.index("\n}", code.index('extern "C" {')):]
+    called = set(re.findall(r"\b(ss_\w+)\(", body))
+    assert called == declared, (declared - called, called - declared)
+    # 5. everything re-exported through the module paths is `pub` at the crate root
+    for m in re.finditer(r"pub use super::\{(.*?)\};", code, flags=re.S):
+        for name in re.findall(r"\w+", m.group(1)):
+            assert re.search(r"^pub (unsafe )?(fn|struct|trait) %s\b" % name, code, flags=re.M), name
+    # 6. as_standard_layout() results are let-bound (never a temporary whose pointer outlives the statement)
+    assert not re.search(r"as_standard_layout\(\)\s*\.as_ptr\(\)", code)
+    assert len(re.findall(r"let (x|owned) = \w+\.as_standard_layout\(\);", code)) == code.count(".as_standard_layout()")
+    # 7. no private type in a public signature
+    for priv in ("Handle", "Kept"):
+        assert not re.search(r"pub (unsafe )?fn [^{;]*\b%s\b" % priv, flat)
+    assert "NEVER COMPILED" in rs
+
+
 def test_cpp_mirror_has_the_reference_fields_and_is_copyable():
     hpp = open(os.path.join(ROOT, "include", "speechsauce_amd.hpp")).read()
     for acc in ("window_size_half()", "frame_size()", "wnorm()", "window()", "freq_size()", "dc_elimination()"):
