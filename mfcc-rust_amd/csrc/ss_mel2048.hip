@@ -56,46 +56,22 @@ using namespace wv;
 #define SS_P_MEL 1
 #endif
 #define SS_P_FFT 0
-// Fair shares for the three waves of a SIMD -- measured in round 5 and NOT kept (lab builds: -DSS_FAIR=1 boosts among butterflies
-// only, =2 every phase).  Among waves of equal priority the arbiter takes the OLDEST first, and the unit timeline of cfg3
-// (tools/prof3.py, profiles/r05/unit_timeline_cfg3*.txt) shows three speed classes by dispatch order: waves 0-3 / 4-7 / 8-11 of a
-// workgroup take 5.3 / 5.8 / 6.3 us of compute and 1.55 / 1.8 / 2.2 us of waiting for samples per unit, so the oldest end 2 us
-// before the youngest.  Raising a wave's priority by one step in some of its units (youngest class in two of every three units,
-// middle class in one, oldest never: every wave first, second and third once) does equalise them when it applies to every phase
-// -- at 6.1 us of compute and 2.2 us of waiting for ALL classes: the boosted butterflies tie with the other waves' LDS phases,
-// which is what the phase priorities exist to prevent (cfg3 49.0 us against 45.0).  Among butterflies only it changes neither
-// the classes nor the time (45.8 against 45.4).
-#if SS_LAB && defined(SS_FAIR)
-#if SS_FAIR == 2
-#define SS_PRIOL(x) do { if (boost) __builtin_amdgcn_s_setprio((x) < 3 ? (x) + 1 : 3); else __builtin_amdgcn_s_setprio(x); } while (0)
-#else
-#define SS_PRIOL(x) do { if ((x) == 0) { if (boost) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } \
-                         else __builtin_amdgcn_s_setprio((x) >= 3 ? 3 : 2); } while (0)
-#endif
-#else
+// (Fair shares between the three waves of a SIMD -- one more priority step for the younger waves in some of their units -- were
+// measured in round 5 and lost: profiles/r05/ab_cfg3_fair.txt; the retired switch is in tools/experiments/ss_mel2048_lab_r05.diff.)
 #define SS_PRIOL(x) __builtin_amdgcn_s_setprio(x)
-#endif
 namespace L = mel2048_layout;
 constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
 
-// Row pairs of a clip a mel build spends a unit on.  Every pair, the trailing all-zero ones (functions.rs:121) included.
-// Round 5 measured the alternative (lab builds, -DSS_ZSKIP=1): only the pairs that hold a real row are units and the wave that
-// owns a clip's last one writes the zeros behind it -- cfg3: 15 units per clip instead of 16, 60 per CU instead of 64, 6.6 % fewer
-// VALU and LDS instructions (profiles/r05/pmc_cfg3_zskip.txt) -- and the launch takes 0.7 - 1.5 us LONGER on four boxes, on
-// zeros as on noise (profiles/r05/ab_cfg3_zskip.txt, power_cfg3_zskip.txt).  Why (unit timeline, tools/prof3.py): a CU's twelve
-// waves run in three speed classes and a unit is 7 - 8.5 us; with 64 units the four all-zero ones (no sample wait) are taken by
-// whichever waves finish first and run under the slow waves' last units, with 60 there is nothing to take and the launch still
-// waits for a young wave's fifth unit.  The zero units were free filler; the tail is one unit long either way.
+// Row pairs of a clip a mel build spends a unit on: every pair, the trailing all-zero ones (functions.rs:121) included.  Skipping
+// them (15 units per clip instead of 16 for cfg3, 6.6 % fewer instructions) made the launch 0.7 - 1.5 us LONGER on four boxes: the
+// zero units are free filler under the slow waves' last units, and the tail is one unit long either way (round 5:
+// profiles/r05/ab_cfg3_zskip.txt, pmc_cfg3_zskip.txt; the retired switch is in tools/experiments/ss_mel2048_lab_r05.diff).
 __host__ __device__ inline unsigned mel_work_pairs(unsigned rows, unsigned real_rows)
 {
-    const unsigned w = (real_rows + 1) / 2, all = (rows + 1) / 2;
-#if SS_LAB && defined(SS_ZSKIP)
-    return w == 0 ? (all ? 1u : 0u) : (w < all ? w : all);
-#endif
-    (void)w;
-    return all;
+    (void)real_rows;
+    return (rows + 1) / 2;
 }
 
 template <int kWavesM, bool STFT, bool FULLP = false>
@@ -279,20 +255,8 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                     const unsigned clip_s = unit_s / pairs;
                     const unsigned r0 = (unit_s - clip_s * pairs) * 2;
                     srs = out_rsrc(a.out + (static_cast<unsigned long long>(clip_s) * R + r0) * 2050ull, min(2u, static_cast<unsigned>(R) - r0) * 8200u);
-#if SS_LAB && defined(SS_XSTFT)
-                    // store-path probes (lab builds, results wrong by design): 1 = rows at a pitch of 65 whole lines (wrapped into the
-                    // buffer), 2 = every store dropped by the range check (what the launch costs without its output)
-                    if (SS_XSTFT == 1) srs = out_rsrc(a.out + ((static_cast<unsigned long long>(clip_s) * R + r0) % 32000ull) * 2080ull, 2u * 8320u);
-                    if (SS_XSTFT == 2) srs = out_rsrc(a.out, 0u);
-                    // 4 = every unit writes into the first 4 MB of the buffer (stays in L2: the path to L2 without the path to HBM)
-                    if (SS_XSTFT == 4) srs = out_rsrc(a.out + (static_cast<unsigned long long>(unit_s) % 256ull) * 4100ull, 2u * 8200u);
-#endif
                 }
-#if SS_LAB && defined(SS_XSTFT)
-                const int srow_off = half * (SS_XSTFT == 1 ? 8320 : 8200);
-#else
                 const int srow_off = half * 8200;
-#endif
                 const float cs = 0.5f * a.scale;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {  // two batches of 8: all partner fetches of a batch go out before its arithmetic
@@ -315,18 +279,9 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         const float xr = fmaf(w.y, d.x, fmaf(w.x, d.y, s.x));
                         const float xi = fmaf(w.y, d.y, fmaf(-w.x, d.x, s.y));
                         if (STFT) {
-#if SS_LAB && defined(SS_XAUX)
-                            // cache-policy probe (lab builds): the row stores with other policy bits
-                            buf_store<SS_XAUX>(make_float2(cs * xr, cs * xi), srs, srow_off + (j + 32 * q) * 8);
-                            buf_store<SS_XAUX>(make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi)), srs, srow_off + (1024 - j - 32 * q) * 8);
-#else
                             buf_store(make_float2(cs * xr, cs * xi), srs, srow_off + (j + 32 * q) * 8);
                             // 2 conj X[1024 - k] = 2 s - 2 X[k]
-#if SS_LAB && defined(SS_XSTFT)
-                            if (SS_XSTFT != 3)  // 3 = the mirrored half of every row is not stored (half the bytes)
-#endif
                             buf_store(make_float2(cs * fmaf(2.f, s.x, -xr), -cs * fmaf(2.f, s.y, -xi)), srs, srow_off + (1024 - j - 32 * q) * 8);
-#endif
                         } else {
                             prow[j + 32 * q] = hs * (xr * xr + xi * xi);   // (|X| wnorm)^2, functions.rs:166-169 + feature.rs:164
                             if (FULLP) {  // bins 513..1024 as well
@@ -361,16 +316,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
                         off += a.mel_q4[s];
                     }
                 }
-#if SS_LAB && defined(SS_ZSKIP)
-                if (unit - (unit / pairs) * pairs == pairs - 1) {  // the clip's last working pair: the all-zero rows behind it
-                    float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
-                    for (int rz = r + 2; rz < R; rz += 2) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R + (rz - r)] = 0.f;
-                    }
-                }
-#endif
                 wave_order();
             }
         }
@@ -387,14 +332,12 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 // phases of the exchange fill it (left half-defined, the "undefined" halves are carried around the loop and spilled).
 // Twelve exchange regions + the tables are 134 KB of LDS, so the CU-wide whole-line tile of the 8-wave build (55 KB) does not
 // fit beside them: the rows leave as 8-byte pieces of lines (HBM writes 1.4x the output, traffic 1.09x the algorithmic bytes).
-// ROWS4 (mel output, an even number of row pairs per clip): the work item is FOUR consecutive rows of a clip -- two units run back
-// to back by the same wave, the first one's four mel values kept in registers -- and the rows leave as 16-byte pieces
-// out[clip][m][4c .. 4c + 3] (two v_permlane32_swap per filter pair hand each half-wave both halves' values): half the pieces
-// per 128-byte line, a quarter of the store instructions, one claim per four rows.
-template <bool FIXMEL, bool STFT = false, bool ROWS4 = false>
+// (A work item of FOUR consecutive rows -- 16-byte output pieces, a quarter of the store instructions -- was measured in round 4 and
+// lost: cfg3 49.3 against 46.8 us, profiles/r04/ab_cfg3_rows4.txt: 32 four-row items per CU spread over twelve waves of different
+// speeds worse than 64 two-row units do.  The retired build is in tools/experiments/ss_mel2048_lab_r05.diff.)
+template <bool FIXMEL, bool STFT = false>
 __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a)
 {
-    static_assert(!(STFT && ROWS4), "the four-row item is a mel-output build");
     constexpr int kWavesM = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -402,36 +345,15 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     float *s_tab = reinterpret_cast<float *>(smem) + kWavesM * kWaveFloatsM;
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
     // Row pairs per clip that are units: all of them (see mel_work_pairs for the measured alternative)
-    const unsigned pairs = (STFT || ROWS4) ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows);
-    // work items: units (row pairs), or pairs of units (ROWS4)
-    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs / (ROWS4 ? 2 : 1);
-    // Work distribution.  Without a pool: the workgroup owns a contiguous range of units, its waves pull them from an LDS counter.
-    // With one (mel output): seven eighths of a workgroup's even share stay such a static range (neighbouring units share three
-    // quarters of their samples: L1 / L2 locality); the remaining units of the launch form a POOL, in eight shards (workgroup b
-    // pulls from shard b % 8: one XCD under the round-robin placement -- for speed only), each shard one counter word in device
-    // memory.  A wave whose workgroup has run out of static units goes on with pool units, so workgroups that are ahead (CU end
-    // times within one launch spread by 2 - 3 us: profiles/r05/unit_timeline_cfg3.txt) take work from the ones that are behind
-    // instead of idling until the launch's last unit ends.  The claim of a pool unit is a returning device-scope atomic issued a
-    // whole unit ahead of its use (behind nothing the wave waits for), so its microsecond of latency is never exposed.
-#if SS_LAB
-    const bool pooled = !STFT && !ROWS4 && a.pool != nullptr;
-#else
-    constexpr bool pooled = false;  // (measured and not kept: the product build carries none of it -- DESIGN_LAB.md 9)
-#endif
-    unsigned u_lo, u_hi, p_lo = 0, p_hi = 0;
-    unsigned *g_next = nullptr;
-    if (pooled) {
-        const unsigned share = static_cast<unsigned>(units / gridDim.x) * 7u / 8u;
-        u_lo = blockIdx.x * share;
-        u_hi = u_lo + share;
-        const unsigned pool0 = gridDim.x * share, pn = static_cast<unsigned>(units) - pool0, shard = blockIdx.x & 7u;
-        p_lo = pool0 + static_cast<unsigned>(static_cast<unsigned long long>(pn) * shard / 8u);
-        p_hi = pool0 + static_cast<unsigned>(static_cast<unsigned long long>(pn) * (shard + 1u) / 8u);
-        g_next = a.pool + 32u * shard;  // (a 128-byte line per shard)
-    } else {
-        u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
-        u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
-    }
+    const unsigned pairs = STFT ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    // Work distribution: the workgroup owns a contiguous range of units (neighbouring units share three quarters of their samples:
+    // L1 / L2 locality), its waves pull them from an LDS counter.  (A cross-workgroup pool for the launch's last eighth of units --
+    // workgroups that are ahead take work from the ones behind -- was measured in round 5 and lost: cfg3 44.2 us with it, 44.1
+    // without, profiles/r05/ab_cfg3_pool.txt; the end of a launch is one UNIT long, not one slow CU long.  The retired code is in
+    // tools/experiments/ss_mel2048_lab_r05.diff.)
+    const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
+    const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
     {
         const int n4 = (L::kMelW + 32 * a.mel_wpitch + 4) / 4;
         for (int i = tid; i < n4; i += kWavesM * 64) reinterpret_cast<float4 *>(s_tab)[i] = reinterpret_cast<const float4 *>(a.tab)[i];
@@ -453,39 +375,12 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #define SS_P3(k) do { } while (0)
 #endif
     unsigned item = u_lo + wave;
-    bool in_pool = false;  // (uniform) this wave's claims go to the pool
-    if (pooled && item >= u_hi) {
-        // (a static share smaller than the wave count: this wave starts in the pool, with the one claim whose latency shows)
-        in_pool = true;
-        unsigned g = 0;
-        if ((threadIdx.x & 63) == 0) g = atomicAdd(g_next, 1u);
-        item = p_lo + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(g));
-    }
-#if SS_LAB && defined(SS_FAIR)
-    const int age = __builtin_amdgcn_readfirstlane(wave) >> 2;  // 0: dispatched first (the oldest wave of its SIMD) .. 2: last
-    unsigned nunit = 0;                                         // units this wave has started (uniform)
-    bool boost = age == 2;
-#endif
     SS_PRIOL(SS_P_TOP);
-    while (item < (in_pool ? p_hi : u_hi)) {
-      // the claim of the next item is issued here and read at the end of the iteration
-      unsigned next_v = 0;
-      bool next_pool = in_pool;  // (uniform) next_v will hold an index into the pool shard
-      if ((static_cast<int>(threadIdx.x) & 63) == 0) {
-          if (in_pool) next_v = atomicAdd(g_next, 1u);
-          else next_v = atomicAdd(s_next, 1u);
-      }
-      float mva[4] = {0.f, 0.f, 0.f, 0.f};  // ROWS4: the first unit's mel values
-#pragma unroll 1
-      for (int sub = 0; sub < (ROWS4 ? 2 : 1); ++sub) {
-        const unsigned unit = ROWS4 ? 2 * item + sub : item;
-#if SS_LAB && defined(SS_FAIR)
-        {
-            const unsigned ph = nunit % 3u;
-            boost = age == 2 ? ph != 2u : (age == 1 ? ph == 1u : false);
-            ++nunit;
-        }
-#endif
+    while (item < u_hi) {
+        // the claim of the next item is issued here and read at the end of the iteration
+        unsigned next_v = 0;
+        if ((static_cast<int>(threadIdx.x) & 63) == 0) next_v = atomicAdd(s_next, 1u);
+        const unsigned unit = item;
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
         const int lane = lane_it & 63;     // (the mask tells the compiler the range again: 24-bit multiplies, no sign extensions)
@@ -509,42 +404,16 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
             const float2 *src = reinterpret_cast<const float2 *>(xc + start) + j;
             if (__all(inside)) {
-#if SS_LAB && defined(SS_ABL3)
-                // timing attribution only (lab builds, results wrong by design): bit 0 no sample loads at all, bit 1 every second one
-#pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    if (SS_ABL3 & 1) v[e] = make_float2(1e-3f * static_cast<float>(lane + e), 2e-3f * static_cast<float>(unit & 255u));
-                    else if ((SS_ABL3 & 2) && (e & 1)) v[e] = make_float2(v[e - 1].y, v[e - 1].x);
-                    else v[e] = src[32 * e];
-                }
-#else
                 // (uniform base -- the unit's first row -- + this lane's 32-bit byte offset: loads in the SGPR-base form)
                 const unsigned unit_s = __builtin_amdgcn_readfirstlane(unit);
                 const unsigned clip_s = unit_s / pairs;
                 const long long start0 = static_cast<long long>((unit_s - clip_s * pairs) * 2 + a.n_pad + 1) * static_cast<long long>(a.hop) - 2048;
                 const char *sb = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>(clip_s) * a.ld) + start0 * 4;
-#if SS_LAB && defined(SS_ABL3B)
-                // (timing attribution, lab builds, results wrong by design: both half-waves load the first row's window -- half the
-                // lines per load instruction, no line asked for twice by one wave)
-                const unsigned so = static_cast<unsigned>(j) * 8u;
-#else
                 const unsigned so = static_cast<unsigned>(half) * a.hop * 4u + static_cast<unsigned>(j) * 8u;
-#endif
                 unsigned so2[2] = {so, so + 4096u};  // (a 32-bit lane offset per 4096 bytes, pinned: left alone the second half's addresses become 64-bit VALU sums)
                 asm volatile("" : "+v"(so2[1]));
-#if SS_LAB && defined(SS_NTLOAD)
-                // (A/B, lab builds: sample loads with the non-temporal hint)
-                typedef float f2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(sb + so2[e / 16] + 256u * (e % 16)));
-                    v[e] = make_float2(t.x, t.y);
-                }
-#else
 #pragma unroll
                 for (int e = 0; e < 32; ++e) v[e] = *reinterpret_cast<const float2 *>(sb + so2[e / 16] + 256u * (e % 16));
-#endif
-#endif
             } else {
                 // clip edges (zero initial state, zero padding of the last chunk, D3) and inactive rows: see ss_mel_c1024
                 const int base = start + 2 * j;
@@ -584,14 +453,6 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 const int e = 2 * (eb + i);
                 v[e] = make_float2(v[e].x * w[i].x, v[e].y * w[i].y);
                 v[e + 1] = make_float2(v[e + 1].x * w[i].z, v[e + 1].y * w[i].w);
-            }
-        }
-        if (pooled && !in_pool) {
-            // the static range's claim has long returned (the window reads above waited behind it): when it is past the end,
-            // this wave's next unit comes from the pool -- asked for now, needed at the end of this unit
-            if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)) >= u_hi) {
-                in_pool = next_pool = true;
-                if ((threadIdx.x & 63) == 0) next_v = atomicAdd(g_next, 1u);
             }
         }
         // ---- 1024-point complex FFT: radix-32, transpose through LDS in two register halves, twiddle, radix-32 ----
@@ -703,96 +564,45 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
             buf_store(make_float2(a.scale * u[16].x, -a.scale * u[16].y), srs, j == 0 ? srow_off + 512 * 8 : kOobOffset);  // X[512] = conj Z[512]
             wave_order();
             SS_PRIOL(SS_P_TOP);
-            continue;  // (the one pass of the sub loop ends here)
-        }
-        if (j == 0) {
-            const float2 z = u[16];  // X[512] = conj Z[512]
-            prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
-        }
-        if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
-        wave_order();
-        SS_PRIOL(SS_P_MEL);
-        // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are adjacent words of
-        //      out[clip][m][.] ----
-        {
-            const float4 *w4 = reinterpret_cast<const float4 *>(s_tab + L::kMelW + j * a.mel_wpitch);
-            float mv[4];
-            if constexpr (FIXMEL) {
-                mel4_fixed<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
-                                       reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mv);
-            } else {
-                int off = 0;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    mv[s] = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
-                    off += a.mel_q4[s];
-                }
+        } else {
+            if (j == 0) {
+                const float2 z = u[16];  // X[512] = conj Z[512]
+                prow[512] = hs * 4.f * (z.x * z.x + z.y * z.y);
             }
-            if (ROWS4) {
-                if (sub == 0) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) mva[s] = mv[s];
+            if (j < 3) prow[513 + j] = 0.f;  // pad bins read (with zero weight) by the mel stage
+            wave_order();
+            SS_PRIOL(SS_P_MEL);
+            // ---- banded mel reduction (feature.rs:173), four filters per lane; the two rows of the wave are adjacent words of
+            //      out[clip][m][.] ----
+            {
+                const float4 *w4 = reinterpret_cast<const float4 *>(s_tab + L::kMelW + j * a.mel_wpitch);
+                float mv[4];
+                if constexpr (FIXMEL) {
+                    mel4_fixed<6, 3, 2, 1>(w4, reinterpret_cast<const float4 *>(prow + st[0]), reinterpret_cast<const float4 *>(prow + st[1]),
+                                           reinterpret_cast<const float4 *>(prow + st[2]), reinterpret_cast<const float4 *>(prow + st[3]), mv);
                 } else {
-                    // rows 4c + half (first unit, mva) and 4c + 2 + half (this one, mv).  After the swaps the lower half-wave
-                    // holds rows 4c .. 4c + 3 of its filters fi[0], fi[1], the upper one those of its filters fi[2], fi[3]
-                    // (fi depends on j only): one 16-byte piece per lane and filter, dropped by the range check where a slot has
-                    // no filter (counted stores, ss_wave.h)
-                    float a0 = mva[0], b0 = mva[2], a1 = mva[1], b1 = mva[3], c0 = mv[0], d0 = mv[2], c1 = mv[1], d1 = mv[3];
-                    swap_halves(a0, b0);
-                    swap_halves(a1, b1);
-                    swap_halves(c0, d0);
-                    swap_halves(c1, d1);
-                    const unsigned clip_s = __builtin_amdgcn_readfirstlane(clip);
-                    const __amdgpu_buffer_rsrc_t ors = out_rsrc(a.out + static_cast<unsigned long long>(clip_s) * M * R, static_cast<unsigned>(M * R) * 4u);
-                    const int r4 = (r - half - 2) * 4;  // byte offset of row 4c within a filter's line
-                    const int f0 = half ? fi[2] : fi[0], f1 = half ? fi[3] : fi[1];
-                    buf_store(make_float4(a0, b0, c0, d0), ors, f0 >= 0 ? f0 * R * 4 + r4 : kOobOffset);
-                    buf_store(make_float4(a1, b1, c1, d1), ors, f1 >= 0 ? f1 * R * 4 + r4 : kOobOffset);
+                    int off = 0;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        mv[s] = mel_slot4(w4 + off, reinterpret_cast<const float4 *>(prow + st[s]), a.mel_q4[s]);
+                        off += a.mel_q4[s];
+                    }
                 }
-            } else {
                 float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
                 if (in_rows) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-#if SS_LAB && defined(SS_NTSTORE)
-                        if (fi[s] >= 0) __builtin_nontemporal_store(mv[s], &dst[static_cast<unsigned long long>(fi[s]) * R]);  // (A/B, lab builds)
-#else
                         if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R] = mv[s];
-#endif
                 }
-#if SS_LAB && defined(SS_ZSKIP)
-                // the clip's last working pair: the all-zero rows behind it (uniform branch: one pair per wave)
-                const unsigned unit_z = __builtin_amdgcn_readfirstlane(unit);
-                if (unit_z - (unit_z / pairs) * pairs == pairs - 1) {
-                    for (int rz = r + 2; rz < R; rz += 2) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (fi[s] >= 0) dst[static_cast<unsigned long long>(fi[s]) * R + (rz - r)] = 0.f;
-                    }
-                }
-#endif
             }
+            wave_order();
+            SS_PRIOL(SS_P_TOP);
         }
-        wave_order();
-        SS_PRIOL(SS_P_TOP);
 #if SS_LAB && defined(SS_PROF3)
         SS_P3(2);
         ++p3n;
 #endif
-      }
-      item = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)) + (next_pool ? p_lo : 0u);
-    }
-    if (pooled) {
-        // the launch's last workgroup leaves the pool words at zero for the next launch that is handed this slot (every claim of
-        // every workgroup has returned by the time its `done` increment is issued)
-        __syncthreads();
-        if (tid == 0) {
-            unsigned *done = a.pool + 32u * 8u;
-            if (atomicAdd(done, 1u) == gridDim.x - 1u) {
-                for (int x = 0; x < 8; ++x) atomicExch(a.pool + 32 * x, 0u);
-                atomicExch(done, 0u);
-            }
-        }
+        item = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v));
     }
 #if SS_LAB && defined(SS_PROF3)
     if ((threadIdx.x & 63) == 0) p3[0] = p3n | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20)) << 32);
@@ -847,26 +657,6 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
     };
     if (a.out_stft) return go(ss_mel_c1024_w12<false, true>, "ss_mel_c1024<w12,stft>");
     const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
-#if SS_LAB
-    // Four consecutive rows per work item (16-byte output pieces; ROWS4 above): measured and not kept -- cfg3 49.3 against 46.8 us
-    // on one box (profiles/r04/ab_cfg3_rows4.txt).  A CU's 64 two-row units spread over twelve waves of different speeds better
-    // than 32 four-row items do; what the wider pieces save in L2 is far less than what the coarser items cost at the end of the
-    // launch.  SS_MEL_ROWS4=1 (lab build) selects it.
-    static const char *r4 = std::getenv("SS_MEL_ROWS4");
-    if (r4 && std::atoi(r4) == 1 && a.rows % 4 == 0 && static_cast<unsigned long long>(a.n_filters) * a.rows * 4ull < 0x7fffffffull) {
-        // (the grid is sized on four-row items)
-        const unsigned long long items = units / 2, blocks4 = (items + kWavesM - 1) / kWavesM;
-        const unsigned grid4 = static_cast<unsigned>(blocks4 < cap ? blocks4 : cap);
-        auto go4 = [&](auto kern, const char *name) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-            if (info) *info = LaunchInfo{name, grid4, static_cast<unsigned>(kWavesM * 64), lds};
-            hipLaunchKernelGGL(kern, dim3(grid4), dim3(kWavesM * 64), lds, stream, a);
-            return hipGetLastError();
-        };
-        return m6321 ? go4(ss_mel_c1024_w12<true, false, true>, "ss_mel_c1024<w12,mel6321,rows4>") : go4(ss_mel_c1024_w12<false, false, true>, "ss_mel_c1024<w12,rows4>");
-    }
-#endif
     return m6321 ? go(ss_mel_c1024_w12<true>, "ss_mel_c1024<w12,mel6321>") : go(ss_mel_c1024_w12<false>, "ss_mel_c1024<w12>");
 }
 
