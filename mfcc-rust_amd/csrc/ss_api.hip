@@ -82,11 +82,6 @@ struct ss_config {
     // result (today: a tile hand-off of ss_mel_c1024<tile> that never came).  The host reads it without a copy; a non-zero
     // word turns into SS_ERR_DEVICE at the next launch or synchronisation point on this config (pending_device_error).
     unsigned *h_err = nullptr, *d_err = nullptr;
-    // Work-pool words of the kernels that balance a launch's last units across workgroups (ss_device.h kPoolSlots slots of
-    // kPoolSlotWords words, all zero between launches): every launch takes the next slot, so launches of this config that run at
-    // the same time on different streams never share counters (a slot comes round again 256 launches later).
-    unsigned *d_pool = nullptr;
-    mutable std::atomic<unsigned> pool_seq{0};
     mutable unsigned tile_spin_limit = 1u << 24;  // what the word behind the 2048-point mel table block holds (test aid toggles it)
     mutable unsigned tile_spin_stage[4] = {0, 0, 0, 0};
 };
@@ -607,18 +602,6 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
         m.ctl = cfg->d_err;
-        // The cross-workgroup work pool of the twelve-wave mel build (ss_mel2048.hip): measured in round 5 and NOT used by the
-        // product -- cfg3 44.2 us with it, 44.1 without (profiles/r05/ab_cfg3_pool.txt): the end of a launch is one UNIT long
-        // (7 - 8 us: the last claims are spread over a unit's duration whoever makes them), not one slow CU long, and the pool
-        // only moves who makes them.  SS_POOL=1 (lab build) switches it on.
-        m.pool = nullptr;
-#if SS_LAB
-        {
-            static const char *np = std::getenv("SS_POOL");
-            if (np && std::atoi(np) == 1 && cfg->d_pool)
-                m.pool = cfg->d_pool + static_cast<size_t>(ss::kPoolSlotWords) * (cfg->pool_seq.fetch_add(1u, std::memory_order_relaxed) % ss::kPoolSlots);
-        }
-#endif
         {
             // the poll bound lives behind the table block in device memory; it changes only when the test aid is toggled
             const unsigned lim = ss::dbg_tile_spin_limit();
@@ -991,20 +974,6 @@ int ss_config_create(const ss_params *p, ss_config **out)
         c->h_err = static_cast<unsigned *>(hp);
         c->d_err = static_cast<unsigned *>(dp);
     }
-#if SS_LAB
-    {
-        void *pp = nullptr;
-        const size_t bytes = static_cast<size_t>(ss::kPoolSlots) * ss::kPoolSlotWords * sizeof(unsigned);
-        hipError_t e3 = hipMalloc(&pp, bytes);
-        if (e3 == hipSuccess) e3 = hipMemset(pp, 0, bytes);
-        if (e3 != hipSuccess) {
-            if (pp) (void)hipFree(pp);
-            ss_config_destroy(cfg.release());
-            return hip_fail(e3, "hipMalloc (work-pool words)");
-        }
-        c->d_pool = static_cast<unsigned *>(pp);
-    }
-#endif
     *out = cfg.release();
     return SS_OK;
 }
@@ -1027,7 +996,6 @@ void ss_config_destroy(ss_config *cfg)
     for (void *p : cfg->pipe.h_small)
         if (p) (void)hipHostFree(p);
     if (cfg->h_err) (void)hipHostFree(cfg->h_err);
-    if (cfg->d_pool) (void)hipFree(cfg->d_pool);
     delete cfg;
 }
 

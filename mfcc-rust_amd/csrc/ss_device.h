@@ -180,12 +180,7 @@ struct Mel2048Args {
     // when a tile hand-off never came (the host turns it into SS_ERR_DEVICE).  Touched on the cold path only; how long a wave
     // polls before it gives up is the word behind the table block.
     unsigned *ctl;
-    // twelve-wave mel build: this launch's slot of the config's work-pool words (kPoolSlotWords zero-initialised words: eight
-    // shard counters on lines of their own, then the workgroups' done count; the launch leaves them at zero), or null
-    unsigned *pool;
 };
-constexpr unsigned kPoolSlotWords = 32u * 9u;  // 9 lines of 128 bytes
-constexpr unsigned kPoolSlots = 256u;          // slots per config, handed out round-robin: a slot is reused 256 launches later
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 #if SS_LAB

@@ -114,7 +114,7 @@ def test_four_streams_on_one_handle_equal_the_serial_run_bit_for_bit(works, ssli
     for s in streams:
         s.synchronize()
     for w in works:
-        w.cfg.device_status()  # no kernel reported a protocol error (the 2048-point mel kernel's tile hand-off, its work pool slots)
+        w.cfg.device_status()  # no kernel reported a protocol error (the error word the handle shares between its launches)
         for i in range(STEPS):
             assert torch.equal(w.conc[i], w.serial[i]), (w.name, i)
         w.check_against_oracle(oracle, w.conc)
@@ -122,7 +122,7 @@ def test_four_streams_on_one_handle_equal_the_serial_run_bit_for_bit(works, ssli
 
 def test_four_streams_same_workload_back_to_back(works, sslib):
     """The pipelined bench loop itself: ONE workload, 64 launches round-robin over four streams, for each bench kernel in turn
-    (launches of the same kernel and the same handle overlap: shared tables, the handle's work-pool slots and error word)."""
+    (launches of the same kernel and the same handle overlap: shared tables and the handle's error word)."""
     import torch
 
     streams = [torch.cuda.Stream() for _ in range(STREAMS)]
