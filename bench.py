@@ -504,6 +504,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        # the CPU leg's port is compiled for this host NOW, before anything touches the GPU (a compiler run is a child process;
+        # none is started once the device is initialised), not in the middle of the run
+        import oracle_c
+
+        oracle_c.native_port()
+
     import torch
     import torch.distributed as dist
 

@@ -270,17 +270,38 @@ _native = None
 _native_flags = None
 
 
+def _host_cpu_id():
+    """What -march=native depends on: the CPU model and its feature flags (first processor of /proc/cpuinfo)."""
+    import hashlib
+
+    try:
+        first = open("/proc/cpuinfo").read().split("\n\n")[0]
+        keep = [ln for ln in first.splitlines() if ln.split(":")[0].strip() in ("vendor_id", "cpu family", "model", "model name", "stepping", "flags")]
+        return hashlib.sha256("\n".join(keep).encode()).hexdigest()[:16]
+    except Exception:
+        return "unknown"
+
+
 def native_port():
     """The port built for THIS host (`make native`: -O3 -march=native, no fast-math, no contraction) -- what bench.py's
-    cpu_baseline times.  Built on first use on the machine that runs it; (None, reason) when that fails (the caller then times
-    the portable -O2 build and says so).  Only port_* are taken from this library; the checker stays libss_oracle.so."""
+    cpu_baseline times.  Built on the machine that runs it, on first use: `make native` is incremental (nothing is rebuilt while the
+    source is older than the library), and a library built on ANOTHER CPU model (oracle/_native/host.txt differs) is rebuilt; the
+    Makefile writes the new library under a temporary name and moves it into place, so a concurrent process never maps a
+    half-written file.  (None, reason) when the build fails (the caller then times the portable -O2 build and says so).  Only
+    port_* are taken from this library; the checker stays libss_oracle.so."""
     global _native, _native_flags
     if _native is None:
-        so = os.path.join(_HERE, "_native", "libss_oracle_native.so")
+        nd = os.path.join(_HERE, "_native")
+        so, host_file, host = os.path.join(nd, "libss_oracle_native.so"), os.path.join(nd, "host.txt"), _host_cpu_id()
         try:
-            subprocess.run(["make", "-C", _HERE, "-s", "-B", "native"], check=True, capture_output=True, timeout=300)
+            stale = os.path.exists(so) and (not os.path.exists(host_file) or open(host_file).read().strip() != host)
+            subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if stale else []) + ["native"], check=True, capture_output=True, timeout=300)
+            tmp = host_file + f".tmp.{os.getpid()}"
+            with open(tmp, "w") as f:
+                f.write(host + "\n")
+            os.replace(tmp, host_file)
             _native = C.CDLL(so)
-            _native_flags = open(os.path.join(_HERE, "_native", "flags.txt")).read().strip()
+            _native_flags = open(os.path.join(nd, "flags.txt")).read().strip()
         except Exception as e:  # no compiler / read-only tree: fall back, loudly, in the caller's report
             _native, _native_flags = False, f"native build failed: {e!r}"
     return (_native or None), _native_flags
