@@ -324,7 +324,8 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
     fn = lib.ss_mfcc_batch_device if kind == "mfcc" else lib.ss_mel_spectrogram_device
     if group > 1:
         # launch k takes batches k*group .. k*group + group - 1 of the ring (distinct inputs, distinct output blocks)
-        assert kind == "mfcc" and steps % group == 0 and warmup % group == 0 and streams == 1
+        assert steps % group == 0 and warmup % group == 0 and streams == 1
+        batches_fn = lib.ss_mfcc_batches_device if kind == "mfcc" else lib.ss_mel_spectrogram_batches_device
         outs = [torch.empty(out_shape, dtype=torch.float32, device=device) for _ in range(2 * group)]
         nb = (C.c_size_t * group)(*([clips] * group))
         tabs = []
@@ -337,7 +338,7 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
             if i % group:
                 return
             px, po = tabs[(i // group) % len(tabs)]
-            rc = lib.ss_mfcc_batches_device(cfg.handle, group, px, nb, n_samples, n_samples, po, sptrs[0])
+            rc = batches_fn(cfg.handle, group, px, nb, n_samples, n_samples, po, sptrs[0])
             if rc:
                 _lib.check(rc)
     else:
@@ -418,9 +419,9 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         # a launch covers `group` batches: the per-launch figures above are per BATCH (region / steps); the launch itself is group x
         res["batches_per_launch"] = group
         res["launch_us"] = avg * 1e6 * group
-        res["note"] = (f"{group} independent batches of the workload per ss_mfcc_batches_device call = one persistent launch; avg_launch_us, "
-                       "bytes and frac are per 1024-clip batch (launch / group): the start-up and the one-unit tail of a launch are paid once per "
-                       f"{group} batches")
+        res["note"] = (f"{group} independent batches of the workload per ss_{'mfcc' if kind == 'mfcc' else 'mel_spectrogram'}_batches_device call = one "
+                       f"persistent launch; avg_launch_us, bytes and frac are per {clips}-clip batch (launch / group): the start-up and the one-unit "
+                       f"tail of a launch are paid once per {group} batches")
     e = load_pmc(workload)
     if e and kernel.split("<")[0] in e.get("kernel_full", ""):
         res["traffic"] = e.get("hbm_bytes_per_launch")
@@ -931,13 +932,16 @@ def main():
             # device): the one cycles_per_launch whose time and clock share launches -- stamping only the region's last quarter spreads
             # 1.2 % between regions on one box, stamping all of it 0.3 % (profiles/r06/stamp_cost.txt) --, and the figure rounds are compared on (a 20-step headline region is 0.6 ms: the same binary
             # reads 26 - 30 us there, profiles/r05/box_spread.txt).
-            # secondary.cfg2_x4: four independent 1024-clip batches per ss_mfcc_batches_device call (ONE persistent launch): what the
-            # start-up + tail of a launch cost, recovered without streams.  Per-batch figures; never `value`.
+            # secondary.cfg2_x4 / cfg3_x4 / cfg5_x4: four independent batches of the workload per ss_mfcc_batches_device /
+            # ss_mel_spectrogram_batches_device call (ONE persistent launch): what the start-up + tail of a launch cost, recovered without
+            # streams.  Per-batch figures; never `value`.
             # (cfg3 / cfg5: 1000 steps, 50 - 60 ms each: regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
             legs = (("cfg2", "cfg2", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
                     ("cfg2_x4", "cfg2", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
                     ("cfg3", "cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+                    ("cfg3_x4", "cfg3", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
                     ("cfg5", "cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+                    ("cfg5_x4", "cfg5", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
                     ("cfg4", "cfg4", dict(steps=5, warmup=1, prewarm_ms=300.0)))
             for name, wl, kw in legs:
                 try:

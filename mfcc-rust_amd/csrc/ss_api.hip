@@ -366,7 +366,48 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
         if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mfcc_c256");
     }
-    if (multi) return kNoMultiBuild;  // the other kernels take one batch per launch
+    // fft_points = 4096 MFCC: the twelve-wave default-shape build takes a batch table too
+    auto fill4096 = [&](ss::Mfcc4096Args &f) {
+        f.preemph = a.preemph;
+        f.preemph_shift = a.preemph_shift;
+        f.x = d_x;
+        f.ld = ld;
+        f.n_samples = a.n_samples;
+        f.batch = a.batch;
+        f.flen = a.flen;
+        f.step = a.step;
+        f.n_frames = a.n_frames;
+        f.scale = a.scale;
+        f.spectrum_exponent = a.spectrum_exponent;
+        f.tab = cfg->d_mfcc4096_tab;
+        f.mel_wpitch = cfg->mfcc4096.wpitch;
+        for (int s = 0; s < 4; ++s) f.mel_q4[s] = cfg->mfcc4096.q4[s];
+        f.cos_floats = cfg->mfcc4096.cos_floats;
+        f.dct_fold2 = cfg->mfcc4096.dct_fold2 ? 1 : 0;
+        f.n_filters = a.n_filters;
+        f.n_ceps = a.n_ceps;
+        f.dct_scale_k = a.dct_scale_k;
+        f.dct_scale_0 = a.dct_scale_0;
+        f.dct_scale_00 = a.dct_scale_00;
+        f.dc_elimination = a.dc_elimination;
+        f.out = out0;
+        f.out_energy = out1;
+        f.out_mfe = out_kind == ss::OUT_MFE;
+        f.window = a.window;
+    };
+    if (multi) {
+        if (!force_generic && cfg->mfcc4096.ok && out_kind == ss::OUT_MFCC && a.frame_mode == ss::FRAME_NORMAL) {
+            ss::Mfcc4096Args f{};
+            fill4096(f);
+            const hipError_t em = ss::launch_mfcc_c2048_multi(f, multi->n, multi->x, multi->out, multi->clips, stream, cfg->num_cus, &info);
+            if (em == hipSuccess) {
+                g_last_kernel = info.kernel_name;
+                return SS_OK;
+            }
+            if (em != hipErrorInvalidValue) return hip_fail(em, "launch_mfcc_c2048_multi");
+        }
+        return kNoMultiBuild;  // the other kernels take one batch per launch
+    }
     // fft_points = 512 MFCC / mfe with more than 48 filters or 16 cepstra, and the output / window / framing combinations the
     // headline kernel has no build for (ss_mfcc512w.hip): optional frame window, centred frames, fused pre-emphasis
     if (!force_generic && cfg->mfcc512w.ok && static_cast<unsigned long long>(batch) * T + 4 < 0x7fffffffull &&
@@ -486,32 +527,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
     // fft_points = 4096 MFCC / mfe (up to 256 filters): the one-frame-per-wave kernel
     if (!force_generic && cfg->mfcc4096.ok && fits32 && (out_kind == ss::OUT_MFCC || out_kind == ss::OUT_MFE) && a.frame_mode == ss::FRAME_NORMAL) {
         ss::Mfcc4096Args f{};
-        f.preemph = a.preemph;
-        f.preemph_shift = a.preemph_shift;
-        f.x = d_x;
-        f.ld = ld;
-        f.n_samples = a.n_samples;
-        f.batch = a.batch;
-        f.flen = a.flen;
-        f.step = a.step;
-        f.n_frames = a.n_frames;
-        f.scale = a.scale;
-        f.spectrum_exponent = a.spectrum_exponent;
-        f.tab = cfg->d_mfcc4096_tab;
-        f.mel_wpitch = cfg->mfcc4096.wpitch;
-        for (int s = 0; s < 4; ++s) f.mel_q4[s] = cfg->mfcc4096.q4[s];
-        f.cos_floats = cfg->mfcc4096.cos_floats;
-        f.dct_fold2 = cfg->mfcc4096.dct_fold2 ? 1 : 0;
-        f.n_filters = a.n_filters;
-        f.n_ceps = a.n_ceps;
-        f.dct_scale_k = a.dct_scale_k;
-        f.dct_scale_0 = a.dct_scale_0;
-        f.dct_scale_00 = a.dct_scale_00;
-        f.dc_elimination = a.dc_elimination;
-        f.out = out0;
-        f.out_energy = out1;
-        f.out_mfe = out_kind == ss::OUT_MFE;
-        f.window = a.window;
+        fill4096(f);
 #if SS_LAB
         static const char *rows_path = std::getenv("SS_DEBUG_ROWS");  // diagnostic only (lab build): frame 0's P row and ln(mel) row
 #else
@@ -547,7 +563,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
 
 // STFT-path launch (OUT_MEL / OUT_STFT).
 int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t channels, size_t n, size_t ld,
-                float *out0, hipStream_t stream)
+                float *out0, hipStream_t stream, const MultiBatches *multi = nullptr)
 {
     if (!cfg) return ss::fail(SS_ERR_ARG, "null config");
     if (channels == 0) return SS_OK;  // nothing to do, and no buffers to check
@@ -614,6 +630,14 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
                 cfg->tile_spin_limit = lim;
             }
         }
+        if (multi) {
+            // several blocks for one launch (ss_mel_spectrogram_batches_device): the twelve-wave mel build takes a batch table
+            const hipError_t em = ss::launch_mel_c1024_multi(m, multi->n, multi->x, multi->out, multi->clips, stream, cfg->num_cus, &info);
+            if (em == hipErrorInvalidValue) return kNoMultiBuild;
+            if (em != hipSuccess) return hip_fail(em, "launch_mel_c1024_multi");
+            g_last_kernel = info.kernel_name;
+            return SS_OK;
+        }
         const hipError_t e = ss::launch_mel_c1024(m, stream, cfg->num_cus, &info);
         if (e == hipSuccess) {
             g_last_kernel = info.kernel_name;
@@ -622,6 +646,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         // hipErrorInvalidValue before the launch: the configuration does not fit this kernel (LDS budget) -> next candidate
         if (e != hipErrorInvalidValue) return hip_fail(e, "launch_mel_c1024");
     }
+    if (multi) return kNoMultiBuild;  // the other STFT-path kernels take one block per launch
     // fft_points = 512 mel spectrogram: four rows per wave (ss_mel512.hip), same layout assumptions
     if (!force_generic && (out_kind == ss::OUT_MEL || want_stft) && (cfg->mel512.ok || (want_stft && cfg->mel512.stft_only)) &&
         static_cast<unsigned long long>(a.rows + a.n_pad + 1) * a.hop < 0x7fffffffull) {
@@ -1519,7 +1544,9 @@ int ss_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_t cha
 }
 
 // The mel-spectrogram form of ss_mfcc_batches_device: n_batches independent [channels[b] x n_samples] blocks, each with its own
-// output block; served block by block on `stream` (the STFT-path kernels take one block per launch).
+// output block.  Where the configuration runs on the twelve-wave 2048-point mel build and every block is large enough to select
+// that build on its own, up to ss::kMaxLaunchBatches blocks share ONE launch; otherwise block by block on `stream`.  The results
+// are those of separate ss_mel_spectrogram_device calls, bit for bit.
 int ss_mel_spectrogram_batches_device(const ss_config *cfg, size_t n_batches, const float *const *d_x, const size_t *channels,
                                       size_t n_samples, size_t ld, float *const *d_out, void *stream)
 {
@@ -1527,10 +1554,29 @@ int ss_mel_spectrogram_batches_device(const ss_config *cfg, size_t n_batches, co
     if (n_batches == 0) return SS_OK;
     if (!d_x || !channels || !d_out) return ss::fail(SS_ERR_ARG, "null batch table");
     if (ld < n_samples) return ss::fail(SS_ERR_ARG, "leading dimension smaller than n_samples");
-    for (size_t b = 0; b < n_batches; ++b)
-        if (channels[b] && (!d_x[b] || !d_out[b])) return ss::fail(SS_ERR_ARG, "null buffer in batch " + std::to_string(b));
+    std::vector<const float *> xs;
+    std::vector<float *> outs;
+    std::vector<size_t> chans;
     for (size_t b = 0; b < n_batches; ++b) {
-        const int rc = launch_stft(cfg, ss::OUT_MEL, d_x[b], channels[b], n_samples, ld, d_out[b], static_cast<hipStream_t>(stream));
+        if (channels[b] == 0) continue;  // an empty block has no buffers
+        if (!d_x[b] || !d_out[b]) return ss::fail(SS_ERR_ARG, "null buffer in batch " + std::to_string(b));
+        if (channels[b] > 0x7fffffffull) return ss::fail(SS_ERR_ARG, "bad clip length / channel count");
+        xs.push_back(d_x[b]);
+        outs.push_back(d_out[b]);
+        chans.push_back(channels[b]);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t g0 = 0; g0 < xs.size(); g0 += ss::kMaxLaunchBatches) {
+        const size_t gn = std::min<size_t>(ss::kMaxLaunchBatches, xs.size() - g0);
+        int rc = kNoMultiBuild;
+        if (gn > 1) {
+            const MultiBatches mb{static_cast<int>(gn), xs.data() + g0, outs.data() + g0, chans.data() + g0};
+            rc = launch_stft(cfg, ss::OUT_MEL, xs[g0], chans[g0], n_samples, ld, outs[g0], st, &mb);
+        }
+        if (rc == kNoMultiBuild) {
+            rc = SS_OK;
+            for (size_t b = g0; b < g0 + gn && rc == SS_OK; ++b) rc = launch_stft(cfg, ss::OUT_MEL, xs[b], chans[b], n_samples, ld, outs[b], st);
+        }
         if (rc) return rc;
     }
     return SS_OK;

@@ -144,15 +144,26 @@ struct Fast512Args {
 
 hipError_t launch_mfcc_c256(const Fast512Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
 
-// Several independent batches in ONE launch of that kernel (ss_mfcc_batches_device): the second kernel argument.  Batch b has its
-// own input block x[b] (clips of a.n_samples at row stride a.ld) and output block out[b]; its quads are [qend[b-1], qend[b]) of the
-// launch's quad range (entries past the last batch: 0xffffffff), total[b] = its clips * n_frames.  Filled by launch_mfcc_c256_multi.
+// Several independent batches in ONE launch (ss_mfcc_batches_device / ss_mel_spectrogram_batches_device): the second argument of
+// the kernel builds that take a batch table (MULTI).  Batch b has its own input block x[b] (clips of a.n_samples at row stride
+// a.ld) and output block out[b]; its work units -- frame quads (512-point MFCC), frames (4096-point MFCC), row pairs (2048-point
+// mel) -- are [uend[b-1], uend[b]) of the launch's unit range (entries past the last batch: 0xffffffff); total[b] = its clips *
+// n_frames (the 512-point kernel's last quad of a batch may be partly filled).  Filled by the launch_*_multi functions.
 constexpr int kMaxLaunchBatches = 8;
-struct Fast512Multi {
+struct BatchTable {
     const float *x[kMaxLaunchBatches];
     float *out[kMaxLaunchBatches];
-    uint32_t qend[kMaxLaunchBatches];
+    uint32_t uend[kMaxLaunchBatches];
     uint32_t total[kMaxLaunchBatches];
+};
+using Fast512Multi = BatchTable;
+// second kernel argument: the batch table of a MULTI build, nothing otherwise
+template <bool MULTI>
+struct MultiArg {
+};
+template <>
+struct MultiArg<true> {
+    BatchTable m;
 };
 // a: the argument block of one batch (x / out / batch are ignored); d_x / d_out / clips: n_batches <= kMaxLaunchBatches entries.
 // hipErrorInvalidValue before the launch: the configuration has no multi-batch build (the caller launches batch by batch).
@@ -183,6 +194,10 @@ struct Mel2048Args {
 };
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+// several blocks of channels in one launch of the twelve-wave mel build (a: one block's arguments; x / out / batch are ignored);
+// hipErrorInvalidValue before the launch where the shape has no batch-table build
+hipError_t launch_mel_c1024_multi(const Mel2048Args &a, int n_batches, const float *const *d_x, float *const *d_out, const size_t *channels,
+                                  hipStream_t stream, int num_cus, LaunchInfo *info);
 #if SS_LAB
 // the retired whole-line-tile build (tools/experiments/ss_mel2048_tile.hip, linked into the lab library only);
 // hipErrorInvalidValue where the shape has no tile build
@@ -295,5 +310,8 @@ struct Mfcc4096Args {
 };
 
 hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
+// several batches in one launch of the twelve-wave default-shape build (see launch_mfcc_c256_multi)
+hipError_t launch_mfcc_c2048_multi(const Mfcc4096Args &a, int n_batches, const float *const *d_x, float *const *d_out, const size_t *clips,
+                                   hipStream_t stream, int num_cus, LaunchInfo *info);
 
 }  // namespace ss

@@ -335,9 +335,12 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 // (A work item of FOUR consecutive rows -- 16-byte output pieces, a quarter of the store instructions -- was measured in round 4 and
 // lost: cfg3 49.3 against 46.8 us, profiles/r04/ab_cfg3_rows4.txt: 32 four-row items per CU spread over twelve waves of different
 // speeds worse than 64 two-row units do.  The retired build is in tools/experiments/ss_mel2048_lab_r05.diff.)
-template <bool FIXMEL, bool STFT = false>
-__global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a)
+// MULTI (ss_mel_spectrogram_batches_device): the launch's units are the concatenation of up to kMaxLaunchBatches blocks' row
+// pairs, each block with its own input and output (BatchTable, ss_device.h; Seg / seg_of, ss_wave.h).
+template <bool FIXMEL, bool STFT = false, bool MULTI = false>
+__global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a, const MultiArg<MULTI> mt)
 {
+    static_assert(!(MULTI && STFT), "the batch-table build is a mel-output build");
     constexpr int kWavesM = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -346,7 +349,8 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + L::kMelW + 32 * a.mel_wpitch + 4);
     // Row pairs per clip that are units: all of them (see mel_work_pairs for the measured alternative)
     const unsigned pairs = STFT ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows);
-    const unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
+    if constexpr (MULTI) units = a.batch;  // (the launcher hands over the launch's unit count: the sum over the blocks)
     // Work distribution: the workgroup owns a contiguous range of units (neighbouring units share three quarters of their samples:
     // L1 / L2 locality), its waves pull them from an LDS counter.  (A cross-workgroup pool for the launch's last eighth of units --
     // workgroups that are ahead take work from the ones behind -- was measured in round 5 and lost: cfg3 44.2 us with it, 44.1
@@ -375,12 +379,23 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #define SS_P3(k) do { } while (0)
 #endif
     unsigned item = u_lo + wave;
+    Seg cs{};  // MULTI: the block of the current unit
+    if constexpr (MULTI) cs = seg_of(mt.m, min(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(item)), u_hi - 1));
     SS_PRIOL(SS_P_TOP);
     while (item < u_hi) {
         // the claim of the next item is issued here and read at the end of the iteration
         unsigned next_v = 0;
         if ((static_cast<int>(threadIdx.x) & 63) == 0) next_v = atomicAdd(s_next, 1u);
-        const unsigned unit = item;
+        unsigned unit = item;
+        const float *x_b = a.x;  // the block this unit belongs to: its input, its output and the unit's index within it
+        float *out_b = a.out;
+        if constexpr (MULTI) {
+            const unsigned item_s = __builtin_amdgcn_readfirstlane(item);
+            if (item_s >= cs.u1) cs = seg_of(mt.m, item_s);  // (uniform, rare: the claimed unit starts the next block)
+            unit = item_s - cs.u0;
+            x_b = cs.x;
+            out_b = cs.out;
+        }
         int lane_it = static_cast<int>(threadIdx.x) & 63;
         asm volatile("" : "+v"(lane_it));  // see above: nothing derived from the lane number is hoisted out of the loop
         const int lane = lane_it & 63;     // (the mask tells the compiler the range again: 24-bit multiplies, no sign extensions)
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
         // ---- the window of this half-wave's row (functions.rs:137-151: the last W samples ending at chunk r + n_pad) ----
         float2 v[32];
         {
-            const float *xc = a.x + static_cast<unsigned long long>(clip) * a.ld;
+            const float *xc = x_b + static_cast<unsigned long long>(clip) * a.ld;
             const bool active = r < Rreal;
             const int start = static_cast<int>(r + a.n_pad + 1) * static_cast<int>(a.hop) - 2048;
             const bool inside = active && start >= 0 && start + 2048 <= static_cast<int>(a.n_samples);
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                 const unsigned unit_s = __builtin_amdgcn_readfirstlane(unit);
                 const unsigned clip_s = unit_s / pairs;
                 const long long start0 = static_cast<long long>((unit_s - clip_s * pairs) * 2 + a.n_pad + 1) * static_cast<long long>(a.hop) - 2048;
-                const char *sb = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>(clip_s) * a.ld) + start0 * 4;
+                const char *sb = reinterpret_cast<const char *>(x_b + static_cast<unsigned long long>(clip_s) * a.ld) + start0 * 4;
                 const unsigned so = static_cast<unsigned>(half) * a.hop * 4u + static_cast<unsigned>(j) * 8u;
                 unsigned so2[2] = {so, so + 4096u};  // (a 32-bit lane offset per 4096 bytes, pinned: left alone the second half's addresses become 64-bit VALU sums)
                 asm volatile("" : "+v"(so2[1]));
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
                         off += a.mel_q4[s];
                     }
                 }
-                float *dst = a.out + static_cast<unsigned long long>(clip) * M * R + r;
+                float *dst = out_b + static_cast<unsigned long long>(clip) * M * R + r;
                 if (in_rows) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
@@ -652,7 +667,7 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
         if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kWavesM * 64), lds};
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a, MultiArg<false>{});
         return hipGetLastError();
     };
     if (a.out_stft) return go(ss_mel_c1024_w12<false, true>, "ss_mel_c1024<w12,stft>");
@@ -661,6 +676,53 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
 }
 
 }  // namespace
+
+hipError_t launch_mel_c1024_multi(const Mel2048Args &a_in, int n_batches, const float *const *d_x, float *const *d_out, const size_t *channels,
+                                  hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    constexpr int kWavesM = 12;
+    Mel2048Args a = a_in;
+    // the build that exists: mel output, the reference bank shape (P rows of bins 0..512), compile-time tap counts 6 / 3 / 2 / 1
+    const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
+    if (n_batches < 1 || n_batches > kMaxLaunchBatches || a.out_stft || a.fullp || !m6321) return hipErrorInvalidValue;
+    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const unsigned pairs = mel_work_pairs(a.rows, a.real_rows);
+    const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    BatchTable m{};
+    unsigned long long units = 0;
+    for (int b = 0; b < kMaxLaunchBatches; ++b) {
+        m.uend[b] = 0xffffffffu;
+        if (b >= n_batches) continue;
+        if (channels[b] == 0 || channels[b] > 0x7fffffffull) return hipErrorInvalidValue;  // (empty blocks are dropped by the caller)
+        {
+            // Only blocks that launch_mel_c1024 would give the twelve-wave build on their own share a launch: the eight-wave build
+            // rounds a few FMAs differently in the last bit, and the results of a call must not depend on how its blocks were grouped
+            const unsigned long long per_cu = (static_cast<unsigned long long>(channels[b]) * pairs + cus - 1) / cus;
+            const double r8 = static_cast<double>((per_cu + 7) / 8), r12 = 1.29 * static_cast<double>((per_cu + 11) / 12);
+            if (!(r12 < r8)) return hipErrorInvalidValue;
+        }
+        units += static_cast<unsigned long long>(channels[b]) * pairs;
+        if (units >= 0xffffffffull) return hipErrorInvalidValue;
+        m.x[b] = d_x[b];
+        m.out[b] = d_out[b];
+        m.uend[b] = static_cast<uint32_t>(units);
+        m.total[b] = static_cast<uint32_t>(channels[b]);
+    }
+    if (units == 0) return hipErrorInvalidValue;
+    a.x = d_x[0];
+    a.out = d_out[0];
+    a.batch = static_cast<uint32_t>(units);  // MULTI: the launch's unit count (the kernel takes the blocks from the table)
+    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
+    const unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
+    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
+    auto kern = ss_mel_c1024_w12<true, false, true>;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    if (info) *info = LaunchInfo{"ss_mel_c1024m<w12,mel6321>", grid, static_cast<unsigned>(kWavesM * 64), lds};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a, MultiArg<true>{m});
+    return hipGetLastError();
+}
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {

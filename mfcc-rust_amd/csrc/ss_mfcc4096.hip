@@ -100,8 +100,10 @@ constexpr int kSegPitch = 68;
 constexpr int kMelPitch8321 = 60;  // floats per lane row of mel weights for the 8 / 3 / 2 / 1 bank (14 float4s + 1: odd pitch in 16-byte units)
 
 
-template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false, bool FIXMEL = false>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfcc4096Args a)
+// MULTI (ss_mfcc_batches_device): the launch's frames are the concatenation of up to kMaxLaunchBatches batches' frames, each batch
+// with its own input and output block (BatchTable, ss_device.h; Seg / seg_of, ss_wave.h); the default-shape MFCC build only.
+template <bool EXACT, bool POW2, int WAVES, bool MFE = false, bool WIN = false, bool PRE = false, bool FIXMEL = false, bool MULTI = false>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfcc4096Args a, const MultiArg<MULTI> mt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     const float2 *s_win = reinterpret_cast<const float2 *>(s_tab + melw0 + 64 * a.mel_wpitch);
     unsigned *s_next = reinterpret_cast<unsigned *>(s_tab + melw0 + 64 * a.mel_wpitch + (WIN ? 4096 : 0));
 
-    const unsigned total = a.batch * a.n_frames;
+    const unsigned total = MULTI ? a.batch : a.batch * a.n_frames;  // (MULTI: the launcher hands over the launch's frame count)
     const unsigned f_lo = static_cast<unsigned>(static_cast<unsigned long long>(total) * blockIdx.x / gridDim.x);
     const unsigned f_hi = static_cast<unsigned>(static_cast<unsigned long long>(total) * (blockIdx.x + 1) / gridDim.x);
     {
@@ -155,11 +157,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     // the round-4 phase profile).  The stage's one output store is a counted store (ss_wave.h): the samples are then waited for
     // with it still in flight.  Result: no change (three waves per SIMD already cover a wave's wait for its samples).
     constexpr bool PF = LEAN && FIXMEL && EXACT && !MFE && !WIN && !PRE && !SS_PROF5 && SS_ABL5 == 0 && !kNoPf;
+    static_assert(!MULTI || (LEAN && FIXMEL && EXACT && !MFE && !WIN && !PRE), "the batch-table build exists for the default-shape MFCC build");
     float2 vpf[PF ? 32 : 1];
+    Seg ns{};  // MULTI: the batch of the frame whose samples are being fetched (PF) / of the current frame
+    if constexpr (MULTI && !PF) ns = seg_of(mt.m, min(frame, f_hi - 1));
     if (PF) {
-        const unsigned fr0 = min(frame, f_hi - 1);  // (a wave without a frame loads the block's last one: no branch around the loads)
+        unsigned fr0 = min(frame, f_hi - 1);  // (a wave without a frame loads the block's last one: no branch around the loads)
+        const float *x0 = a.x;
+        if constexpr (MULTI) {
+            ns = seg_of(mt.m, fr0);
+            fr0 -= ns.u0;
+            x0 = ns.x;
+        }
         const unsigned clip0 = fr0 / a.n_frames;
-        const float2 *src0 = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(clip0) * a.ld + (fr0 - clip0 * a.n_frames) * a.step) + (threadIdx.x & 63);
+        const float2 *src0 = reinterpret_cast<const float2 *>(x0 + static_cast<unsigned long long>(clip0) * a.ld + (fr0 - clip0 * a.n_frames) * a.step) + (threadIdx.x & 63);
 #pragma unroll
         for (int e = 0; e < 32; ++e) vpf[e] = src0[64 * e];
         buf_store(0.f, out_rsrc(a.out, 0u), 0);  // both ways into the loop have one store behind the samples (see ss_mfcc512.hip)
@@ -195,12 +206,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
 #endif
         SS_PH(1);  // claim
 
-        const unsigned clip = frame / a.n_frames;
-        const unsigned t = frame - clip * a.n_frames;
+        if constexpr (MULTI && !PF) {
+            if (frame >= ns.u1) ns = seg_of(mt.m, frame);  // (uniform, rare: the claimed frame starts the next batch)
+        }
+        const Seg cs = ns;  // MULTI: the batch of this iteration's frame (PF: its samples were fetched from it)
+        (void)cs;
+        const unsigned frame_b = MULTI ? frame - cs.u0 : frame;  // the frame's index within its batch
+        const unsigned clip = frame_b / a.n_frames;
+        const unsigned t = frame_b - clip * a.n_frames;
         // stack_frames (processing.rs:65-129, contract framing): frame t starts at sample t*step
         // (SS_ABL5 & 16: every frame reads clip 0 -- L2-resident samples; & 32: no sample loads at all)
         // (uniform base + this lane's 32-bit byte offset: the loads take the SGPR-base form, no 64-bit address is formed on the VALU)
-        const char *src_b = reinterpret_cast<const char *>(a.x + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step);
+        const char *src_b = reinterpret_cast<const char *>((MULTI ? cs.x : a.x) + static_cast<unsigned long long>((SS_ABL5 & 16) ? 0u : clip) * a.ld + t * a.step);
         const unsigned src_o = static_cast<unsigned>(lane) * 8u;
         const float2 *src = reinterpret_cast<const float2 *>(src_b + src_o);
         unsigned src_o4[4] = {src_o, src_o + 4096u, src_o + 8192u, src_o + 12288u};
@@ -482,9 +499,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         // of the lane number removes the spills and measured 1.1 us slower, so they stay.)
         if (FIXMEL || a.dct_fold2) {  // (the FIXMEL build is only launched with the twice-folded table: no generic DCT code in it)
             if (PF) {
-                const unsigned nf = min(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)), f_hi - 1);  // past the end: the last frame again, dropped
+                unsigned nf = min(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v)), f_hi - 1);  // past the end: the last frame again, dropped
+                const float *xn = a.x;
+                if constexpr (MULTI) {
+                    if (nf >= ns.u1) ns = seg_of(mt.m, nf);  // (uniform, rare: the claimed frame starts the next batch)
+                    nf -= ns.u0;
+                    xn = ns.x;
+                }
                 const unsigned nclip = nf / a.n_frames;
-                const float2 *nsrc = reinterpret_cast<const float2 *>(a.x + static_cast<unsigned long long>(nclip) * a.ld + (nf - nclip * a.n_frames) * a.step) + lane;
+                const float2 *nsrc = reinterpret_cast<const float2 *>(xn + static_cast<unsigned long long>(nclip) * a.ld + (nf - nclip * a.n_frames) * a.step) + lane;
 #pragma unroll
                 for (int e = 0; e < 32; ++e) vpf[e] = nsrc[64 * e];
             }
@@ -532,14 +555,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
                 // scaling + column-0 replacement (feature.rs:126-146); an unconditional, counted store (ss_wave.h)
                 float o = acc * a.dct_scale_k;
                 if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-                const unsigned frame_s = __builtin_amdgcn_readfirstlane(frame);
-                buf_store(o, out_rsrc(a.out + static_cast<unsigned long long>(frame_s) * Cc, static_cast<unsigned>(Cc) * 4u),
+                const unsigned frame_s = __builtin_amdgcn_readfirstlane(frame_b);
+                buf_store(o, out_rsrc((MULTI ? cs.out : a.out) + static_cast<unsigned long long>(frame_s) * Cc, static_cast<unsigned>(Cc) * 4u),
                           whole ? (even ? 2 * lane : lp + 1) * 4 : kOobOffset);
             } else if (whole) {
                 // scaling + column-0 replacement (feature.rs:126-146)
                 float o = acc * a.dct_scale_k;
                 if (lane == 0) o = a.dc_elimination ? ln_scaled(energy) : acc * (t == 0 ? a.dct_scale_00 : a.dct_scale_0);
-                a.out[static_cast<unsigned long long>(frame) * Cc + (even ? 2 * lane : lp + 1)] = o;
+                (MULTI ? cs.out : a.out)[static_cast<unsigned long long>(frame_b) * Cc + (even ? 2 * lane : lp + 1)] = o;
             }
             wave_order();
             SS_PH(10);  // DCT + store
@@ -854,7 +877,7 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
                                            static_cast<int>(lds));
         if (e != hipSuccess) return e;
         if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(WAVES * 64), lds};
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a, MultiArg<false>{});
         return hipGetLastError();
     };
     const bool pow2 = a.spectrum_exponent == 2, exact = a.flen == 4096 && a.preemph == 0.f;
@@ -896,6 +919,46 @@ hipError_t launch_h(const Mfcc4096Args &a, hipStream_t stream, int num_cus, Laun
 }
 
 }  // namespace
+
+hipError_t launch_mfcc_c2048_multi(const Mfcc4096Args &a_in, int n_batches, const float *const *d_x, float *const *d_out, const size_t *clips,
+                                   hipStream_t stream, int num_cus, LaunchInfo *info)
+{
+    constexpr int WAVES = 12;
+    Mfcc4096Args a = a_in;
+    // the build that exists: the default cfg5 shape (see launch_h<12>)
+    const bool lean_ok = a.flen == 4096 && a.preemph == 0.f && a.spectrum_exponent != 2 && !a.window && !a.out_mfe && a.dct_fold2 && a.mel_q4[0] == 8 &&
+                         a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1 && a.mel_wpitch == kMelPitch8321 && a.n_filters == 256;
+    if (n_batches < 1 || n_batches > kMaxLaunchBatches || !lean_ok) return hipErrorInvalidValue;
+    const size_t lds = (static_cast<size_t>(WAVES) * kExFloats + L::kCos + static_cast<size_t>(a.cos_floats) + 64 * static_cast<size_t>(a.mel_wpitch) + 4) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    BatchTable m{};
+    unsigned long long total = 0;
+    for (int b = 0; b < kMaxLaunchBatches; ++b) {
+        m.uend[b] = 0xffffffffu;
+        if (b >= n_batches) continue;
+        const unsigned long long tot = static_cast<unsigned long long>(clips[b]) * a.n_frames;
+        if (tot == 0) return hipErrorInvalidValue;  // (empty batches are dropped by the caller)
+        total += tot;
+        if (total >= 0xffffffffull) return hipErrorInvalidValue;
+        m.x[b] = d_x[b];
+        m.out[b] = d_out[b];
+        m.uend[b] = static_cast<uint32_t>(total);
+        m.total[b] = static_cast<uint32_t>(tot);
+    }
+    a.x = d_x[0];
+    a.out = d_out[0];
+    a.batch = static_cast<uint32_t>(total);  // MULTI: the launch's frame count (the kernel takes the batches from the table)
+    unsigned long long blocks = (total + WAVES - 1) / WAVES;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
+    if (blocks > cap) blocks = cap;
+    const unsigned grid = static_cast<unsigned>(blocks);
+    auto kern = ss_mfcc_c2048<true, false, 12, false, false, false, true, true>;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    if (info) *info = LaunchInfo{"ss_mfcc_c2048m<exact,mel8321,w12>", grid, static_cast<unsigned>(WAVES * 64), lds};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, stream, a, MultiArg<true>{m});
+    return hipGetLastError();
+}
 
 hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {

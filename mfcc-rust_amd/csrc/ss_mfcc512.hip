@@ -317,40 +317,8 @@ __device__ __forceinline__ float mel_slot_loop(const float4 *w4, const float *p,
     return acc;
 }
 
-// MULTI builds (MULTI = true; ss_mfcc_batches_device): the launch's quad range is the concatenation of up to kMaxLaunchBatches
-// independent batches' quad ranges, each batch with its own input and output block.  Which batch a quad belongs to is scalar work
-// (the quad index is uniform): a wave keeps the batch of its current quad (output block) and of the quad it prefetches (input
-// block) in SGPRs and looks the table up again only when a claimed quad lies past that batch's last one -- quads are claimed in
-// increasing order, so that is once per batch boundary a wave crosses.  Inside a batch everything is the single-batch arithmetic
-// on the batch-local quad index: results are bit-identical to one launch per batch.
-struct Seg {
-    const float *x;
-    float *out;
-    unsigned q0, q1, total;  // the batch's quads are [q0, q1) of the launch; total = its clips * n_frames
-};
-__device__ __forceinline__ Seg seg_of(const Fast512Multi &m, unsigned g)  // g: uniform
-{
-    unsigned s = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxLaunchBatches - 1; ++k) s += g >= m.qend[k] ? 1u : 0u;  // (entries past the last batch hold 0xffffffff)
-    Seg r;
-    r.x = m.x[s];
-    r.out = m.out[s];
-    r.q1 = m.qend[s];
-    r.q0 = s ? m.qend[s - 1] : 0u;
-    r.total = m.total[s];
-    return r;
-}
-
-// second kernel argument: the batch table of a MULTI build, nothing otherwise
-template <bool MULTI>
-struct MultiArg {
-};
-template <>
-struct MultiArg<true> {
-    Fast512Multi m;
-};
-
+// MULTI builds (ss_mfcc_batches_device): the launch's quad range is the concatenation of up to kMaxLaunchBatches independent batches'
+// quad ranges, each batch with its own input and output block (BatchTable, ss_device.h; Seg / seg_of, ss_wave.h).
 template <int NE, bool EXACT, bool POW2, int WAVES, bool BANK421, int NQ, int RES = 0, int OUTK = 0, int FRONT = 0, bool FULLP = false,
           bool CENTER = false, bool MULTI = false>
 __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_in, const MultiArg<MULTI> mt)
@@ -435,7 +403,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         an = a;
         ns = seg_of(mt.m, min(quad, q_hi - 1));
         an.x = ns.x;
-        t_next = load_quad<NE, EXACT, PRE, CENTER>(an, min(quad, q_hi - 1) - ns.q0, ns.total, f, j, vin, pin);
+        t_next = load_quad<NE, EXACT, PRE, CENTER>(an, min(quad, q_hi - 1) - ns.u0, ns.total, f, j, vin, pin);
     } else {
         t_next = load_quad<NE, EXACT, PRE, CENTER>(a, min(quad, q_hi - 1), total, f, j, vin, pin);
     }
@@ -601,11 +569,11 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
         QuadSrc nsrc{nullptr, 0u};
         if constexpr (MULTI) {
             const unsigned nq = min(next, q_hi - 1);
-            if (nq >= ns.q1) {  // (uniform, rare: the claimed quad starts the next batch)
+            if (nq >= ns.u1) {  // (uniform, rare: the claimed quad starts the next batch)
                 ns = seg_of(mt.m, nq);
                 an.x = ns.x;
             }
-            nsrc = quad_src(an, nq - ns.q0, ns.total, f, j, t_next);
+            nsrc = quad_src(an, nq - ns.u0, ns.total, f, j, t_next);
         } else {
             if (SPREAD) nsrc = quad_src(a, min(next, q_hi - 1), total, f, j, t_next);
         }
@@ -879,7 +847,7 @@ __global__ __launch_bounds__(WAVES * 64) void ss_mfcc_c256(const Fast512Args a_i
             unsigned q_total = total;
             float *q_out = a.out;
             if constexpr (MULTI) {  // this quad's batch: its own output block, the quad's index and the frame count within it
-                quad_s -= cs.q0;
+                quad_s -= cs.u0;
                 q_total = cs.total;
                 q_out = cs.out;
             }
@@ -1061,7 +1029,7 @@ hipError_t launch_mfcc_c256_multi(const Fast512Args &a_in, int n_batches, const 
     Fast512Multi m{};
     unsigned long long quads = 0, max_total = 0;
     for (int b = 0; b < kMaxLaunchBatches; ++b) {
-        m.qend[b] = 0xffffffffu;
+        m.uend[b] = 0xffffffffu;
         if (b >= n_batches) continue;
         const unsigned long long tot = static_cast<unsigned long long>(clips[b]) * a.n_frames;
         if (tot == 0 || tot + 4 >= (1ull << 31)) return hipErrorInvalidValue;  // (empty batches are dropped by the caller)
@@ -1070,7 +1038,7 @@ hipError_t launch_mfcc_c256_multi(const Fast512Args &a_in, int n_batches, const 
         max_total = std::max(max_total, tot);
         m.x[b] = d_x[b];
         m.out[b] = d_out[b];
-        m.qend[b] = static_cast<uint32_t>(quads);
+        m.uend[b] = static_cast<uint32_t>(quads);
         m.total[b] = static_cast<uint32_t>(tot);
     }
     {

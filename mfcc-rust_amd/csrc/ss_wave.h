@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ss_device.h"
+
 namespace ss {
 namespace wv {
 
@@ -59,6 +61,30 @@ __device__ __forceinline__ void buf_store(float4 v, __amdgpu_buffer_rsrc_t r, in
     d.z = __builtin_bit_cast(unsigned, v.z);
     d.w = __builtin_bit_cast(unsigned, v.w);
     __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, 0);
+}
+
+// MULTI builds (a BatchTable as second kernel argument, ss_device.h): which batch a unit of the launch's concatenated unit range
+// belongs to.  Scalar work (the unit index is uniform): a wave keeps the batch of its current unit (and of the unit it prefetches)
+// in SGPRs and looks the table up again only when a claimed unit lies past that batch's last one -- units are claimed in increasing
+// order, so that is once per batch boundary a wave crosses.  Inside a batch everything is the single-batch arithmetic on the
+// batch-local unit index: results are bit-identical to one launch per batch.
+struct Seg {
+    const float *x;
+    float *out;
+    unsigned u0, u1, total;  // the batch's units are [u0, u1) of the launch; total = its clips * n_frames
+};
+__device__ __forceinline__ Seg seg_of(const BatchTable &m, unsigned g)  // g: uniform
+{
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxLaunchBatches - 1; ++k) s += g >= m.uend[k] ? 1u : 0u;  // (entries past the last batch hold 0xffffffff)
+    Seg r;
+    r.x = m.x[s];
+    r.out = m.out[s];
+    r.u1 = m.uend[s];
+    r.u0 = s ? m.uend[s - 1] : 0u;
+    r.total = m.total[s];
+    return r;
 }
 
 // ds_bpermute_b32: every lane reads `v` of the lane whose number is addr / 4 (LDS crossbar, no memory round trip)

@@ -208,6 +208,30 @@ def _internal_mel_spectrogram(signal, config: SpeechConfig):
     return out[0] if one_d else out
 
 
+def _internal_mel_spectrogram_batches(signals, config: SpeechConfig):
+    """Several [C_i, L] blocks (same L) -> list of [C_i, n_mels, rows]."""
+    if not all(_is_torch(x) and x.is_cuda for x in signals):
+        return [_internal_mel_spectrogram(x, config) for x in signals]
+    import torch
+
+    lib = _lib.lib()
+    dev = signals[0].device
+    L = signals[0].shape[1]
+    if any(x.device != dev or x.shape[1] != L for x in signals):
+        raise ValueError("mel_spectrogram: the blocks of one call must live on one device and hold clips of one length")
+    R, _ = config.stft_rows(L)
+    M = config.params.num_filters
+    xs = [x if (x.stride(1) == 1 and (x.shape[0] <= 1 or x.stride(0) == L)) else x.contiguous() for x in signals]
+    outs = [torch.empty((x.shape[0], M, R), dtype=torch.float32, device=dev) for x in xs]
+    n = len(xs)
+    px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    po = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    nb = (C.c_size_t * n)(*[x.shape[0] for x in xs])
+    with torch.cuda.device(dev):
+        _lib.check(lib.ss_mel_spectrogram_batches_device(config.handle, n, px, nb, L, L, po, _stream_ptr()))
+    return outs
+
+
 # ---- public API (py-speechsauce/speechsauce/__init__.py:37-132) ------------------------------------
 
 def _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length, low_frequency,
@@ -365,6 +389,15 @@ def mel_spectrogram(signal, sampling_frequency, frame_length=0.020, frame_stride
     window is ``fft_length`` samples (config.rs:154, functions.rs:96-101); the reference panics
     unless ``fft_length >= 2 * hop`` -- that raises SpeechSauceError here.
     """
+    if isinstance(signal, (list, tuple)):
+        # several [C_i, L] blocks (same L) -> the list of their [C_i, n_mels, time] spectrograms from ONE call (device tensors:
+        # ss_mel_spectrogram_batches_device -- one launch where the configuration's kernel takes a batch table)
+        sigs = [_require_f32(x, (2,), "mel_spectrogram") for x in signal]
+        if not sigs:
+            return []
+        config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
+                      low_frequency, high_frequency, dc_elimination, switches, sigs[0])
+        return _internal_mel_spectrogram_batches(sigs, config)
     sig = _require_f32(signal, (1, 2), "mel_spectrogram")
     config = _cfg(sampling_frequency, frame_length, frame_stride, num_cepstral, num_filters, fft_length,
                   low_frequency, high_frequency, dc_elimination, switches, sig)

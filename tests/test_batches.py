@@ -15,7 +15,9 @@ from common import BENCH_KERNELS
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
-MULTI_KERNEL = b"ss_mfcc_c256m<10,exact,bank421,sym>"
+MULTI_KERNEL = b"ss_mfcc_c256m<10,exact,bank421,sym>"      # 512-point MFCC, default shape (cfg2)
+MULTI_KERNEL_4096 = b"ss_mfcc_c2048m<exact,mel8321,w12>"    # 4096-point MFCC, default shape (cfg5)
+MULTI_KERNEL_MEL = b"ss_mel_c1024m<w12,mel6321>"            # 2048-point mel spectrogram, reference bank shape (cfg3)
 
 
 def _rel(got, want):
@@ -120,14 +122,15 @@ def test_ragged_batches_cross_quad_and_workgroup_boundaries(ss, sslib, oracle):
 
 
 def test_configurations_without_a_batch_table_are_served_batch_by_batch(ss, sslib, oracle):
-    """cfg5 (4096-point kernel), a windowed 512-point configuration, and clips of fewer than four frames: the same call, the same
-    results, one launch per batch of the kernel a single call would use."""
+    """A 4096-point configuration outside the default shape, a 1024-point one, a windowed 512-point one, clips of fewer than four
+    frames, another filter count: the same call, the same results, one launch per batch of the kernel a single call would use."""
     import torch
     from speechsauce_amd import SpeechConfig, make_params
 
     cases = [
-        (dict(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256,
+        (dict(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=20, num_filters=128,
               high_frequency=22050.0), 44100, [40, 3, 17], b"ss_mfcc_c2048<"),
+        (dict(sample_rate=16000, fft_points=1024, frame_length=0.05, frame_stride=0.02), 16000, [12, 7], b"ss_mfcc_c512"),
         (dict(sample_rate=16000, mfcc_window="hann"), 16000, [9, 130], b"ss_mfcc_c256<10,exact,bank421,win>"),
         (dict(sample_rate=16000), 800, [5, 2, 11], b"ss_mfcc_c256<"),  # 3 frames per clip: a quad spans clips, no batch-table build
         (dict(sample_rate=16000, num_filters=26), 16000, [6, 6], b"ss_mfcc_c256<"),
@@ -147,6 +150,34 @@ def test_configurations_without_a_batch_table_are_served_batch_by_batch(ss, ssli
         assert all(torch.equal(g, w) for g, w in zip(got, want)), pkw
         okw = {k: v for k, v in pkw.items()}
         assert _rel(got[0][0].cpu().numpy(), oracle.mfcc(oracle.make_params(**okw), xs[0][0].cpu().numpy())) <= RTOL, pkw
+
+
+def test_cfg5_batches_in_one_launch(ss, sslib, oracle):
+    """The 4096-point MFCC kernel's default shape (cfg5) takes a batch table too: 4 x 512 clips (bench.py's secondary.cfg5_x4) and a
+    ragged set with one-clip batches, bit-identical to separate launches of the bench kernel, sampled clips against the oracle."""
+    import torch
+    from speechsauce_amd import SpeechConfig, make_params
+
+    pkw = dict(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256,
+               high_frequency=22050.0)
+    cfg = SpeechConfig(make_params(**pkw))
+    p = oracle.make_params(**pkw)
+    for counts, seed in (([512] * 4, 350), ([1, 40, 3, 512, 0, 17, 1, 2, 130, 9, 5], 351)):
+        xs = _batches(torch, counts, 44100, seed)
+        want = _separate(torch, sslib, cfg, xs, (39, 40), 44100)
+        assert sslib.ss_last_kernel_name() == BENCH_KERNELS["cfg5"]
+        got = [torch.full((c, 39, 40), float("nan"), device="cuda") for c in counts]
+        px, nb, po = _tables(xs, got)
+        assert sslib.ss_mfcc_batches_device(cfg.handle, len(xs), px, nb, 44100, 44100, po, None) == 0, sslib.ss_last_error_string()
+        assert sslib.ss_last_kernel_name() == MULTI_KERNEL_4096, sslib.ss_last_kernel_name()
+        torch.cuda.synchronize()
+        for b, c in enumerate(counts):
+            assert torch.equal(got[b], want[b]), (b, c)
+            if c:
+                assert _rel(got[b][c - 1].cpu().numpy(), oracle.mfcc(p, xs[b][c - 1].cpu().numpy())) <= RTOL, b
+    outs = ss.mfcc_batch(xs, 44100, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096)
+    assert sslib.ss_last_kernel_name() == MULTI_KERNEL_4096
+    assert all(torch.equal(o, w) for o, w in zip(outs, want))
 
 
 def test_batches_argument_errors_launch_nothing(ss, sslib):
@@ -197,9 +228,37 @@ def test_mel_spectrogram_batches(ss, sslib, oracle):
     torch.cuda.synchronize()
     cfg.device_status()
     assert all(torch.equal(g, w) for g, w in zip(got, want))
+    # (the 5-channel block alone runs on the eight-wave build, which rounds a few FMAs differently: a group with such a block is served
+    # block by block, so that the results never depend on how the blocks were grouped)
+    assert sslib.ss_last_kernel_name().startswith(b"ss_mel_c1024<"), sslib.ss_last_kernel_name()
     p = oracle.make_params(**pkw)
     assert _rel(got[3][299].cpu().numpy(), oracle.mel_spectrogram(p, xs[3][299].cpu().numpy()[None, :])[0]) <= RTOL
     assert sslib.ss_mel_spectrogram_batches_device(cfg.handle, 4, px, nb, 16000, 100, po, None) == 3
+    # blocks that each select the twelve-wave build share ONE launch of its batch-table build (4 x 1024: bench.py's secondary.cfg3_x4)
+    for counts2, seed in (([1024] * 4, 331), ([1024, 300, 0, 512, 150, 129, 1000, 700, 400, 350, 333], 332)):
+        xs2 = _batches(torch, counts2, 16000, seed)
+        want2 = []
+        for x in xs2:
+            o = torch.empty((x.shape[0], 128, R), device="cuda")
+            if x.shape[0]:
+                assert sslib.ss_mel_spectrogram_device(cfg.handle, x.data_ptr(), x.shape[0], 16000, 16000, o.data_ptr(), None) == 0
+                assert sslib.ss_last_kernel_name() == BENCH_KERNELS["cfg3"], (x.shape[0], sslib.ss_last_kernel_name())
+            want2.append(o)
+        got2 = [torch.full((c, 128, R), float("nan"), device="cuda") for c in counts2]
+        px, nb, po = _tables(xs2, got2)
+        assert sslib.ss_mel_spectrogram_batches_device(cfg.handle, len(xs2), px, nb, 16000, 16000, po, None) == 0, sslib.ss_last_error_string()
+        assert sslib.ss_last_kernel_name() == MULTI_KERNEL_MEL, sslib.ss_last_kernel_name()
+        torch.cuda.synchronize()
+        cfg.device_status()
+        for b, c in enumerate(counts2):
+            assert torch.equal(got2[b], want2[b]), (b, c)
+        b, c = len(counts2) - 1, counts2[-1]
+        assert _rel(got2[b][c - 1].cpu().numpy(), oracle.mel_spectrogram(p, xs2[b][c - 1].cpu().numpy()[None, :])[0]) <= RTOL
+    # the Python front: a list in, a list out
+    kw = dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0)
+    outs = ss.mel_spectrogram([x for x in xs2 if x.shape[0]], 16000, **kw)
+    assert sslib.ss_last_kernel_name() == MULTI_KERNEL_MEL
+    assert all(torch.equal(o, w) for o, w in zip(outs, [w for w, c in zip(want2, counts2) if c]))
 
 
 def test_timed_region_times_and_clocks_the_same_launches(ss, sslib):
