@@ -402,8 +402,9 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         dev_s = e0.elapsed_time(e1) * 1e-3
     kernel = lib.ss_last_kernel_name().decode()
     avg = dev_s / steps
-    if clock_ghz is None and streams == 1 and group == 1:
-        clock_ghz = probe_clock(torch, lib, step, avg, device)
+    if clock_ghz is None and streams == 1:
+        # (group > 1: one call per `group` steps)
+        clock_ghz = probe_clock(torch, lib, (lambda i: step(i * group)) if group > 1 else step, avg * group, device)
         clock_source = "a one-wave probe beside FURTHER launches of the same step right after the timed ones (ss_shader_clock_probe)"
     del xs, outs
     torch.cuda.empty_cache()
@@ -422,12 +423,14 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         res["note"] = (f"{group} independent batches of the workload per ss_{'mfcc' if kind == 'mfcc' else 'mel_spectrogram'}_batches_device call = one "
                        f"persistent launch; avg_launch_us, bytes and frac are per {clips}-clip batch (launch / group): the start-up and the one-unit "
                        f"tail of a launch are paid once per {group} batches")
-    e = load_pmc(workload)
+    e = load_pmc(workload if group == 1 else f"{workload}_x{group}")
     if e and kernel.split("<")[0] in e.get("kernel_full", ""):
-        res["traffic"] = e.get("hbm_bytes_per_launch")
-        res["traffic_source"] = f"profiles/pmc_traffic.json (stored, {e.get('profiled', '?')}; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
+        # (a launch of `group` batches: the stored per-launch counters are divided down to one batch, like every figure of this leg)
+        res["traffic"] = e.get("hbm_bytes_per_launch") / group if e.get("hbm_bytes_per_launch") else None
+        res["traffic_source"] = (f"profiles/pmc_traffic.json (stored, {e.get('profiled', '?')}; 2 x FETCH_SIZE + WRITE_SIZE per launch"
+                                 + (f", / {group} batches" if group > 1 else "") + ")")
         if e.get("valu_insts_per_launch"):
-            res["valu_insts_per_launch"] = e["valu_insts_per_launch"]
+            res["valu_insts_per_launch"] = e["valu_insts_per_launch"] / group
     else:
         res["traffic"] = None
     if board:

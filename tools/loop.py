@@ -1,5 +1,6 @@
 """Runs one device entry point in a loop (for rocprofv3 passes on stages bench.py has no workload for).
-usage: python3 tools/loop.py <stft|power|power_frames|stack|cfg2|cfg3|cfg5> [iterations]"""
+usage: python3 tools/loop.py <stft|power|power_frames|stack|cfg2|cfg3|cfg5|cfg2x4|cfg3x4|cfg5x4> [iterations]
+(cfgNx4: four independent batches per call = one launch of the batch-table build, rotating over eight distinct batches)"""
 import os
 import sys
 
@@ -30,6 +31,17 @@ elif what == "cfg3":
 elif what == "cfg5":
     x5 = torch.randn(512, 44100, device="cuda") * 0.1
     fn = lambda: ss.mfcc_batch(x5, 44100, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096)
+elif what in ("cfg2x4", "cfg3x4", "cfg5x4"):
+    n_s, clips = (44100, 512) if what == "cfg5x4" else (16000, 1024)
+    xs = [torch.randn(clips, n_s, device="cuda") * 0.1 for _ in range(8)]
+    kw = {"cfg2x4": {}, "cfg3x4": dict(frame_length=0.032, frame_stride=0.032, num_filters=128, fft_length=2048, high_frequency=8000.0),
+          "cfg5x4": dict(frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40, num_filters=256, fft_length=4096)}[what]
+    call = ss.mel_spectrogram if what == "cfg3x4" else ss.mfcc_batch
+    state = [0]
+
+    def fn():
+        state[0] ^= 1
+        return call(xs[4 * state[0]: 4 * state[0] + 4], n_s, **kw)
 else:
     raise SystemExit(__doc__)
 for _ in range(20):

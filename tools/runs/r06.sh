@@ -37,8 +37,34 @@ done 2>&1 | tee gpurun_out/r06/box_spread.txt
 stampcost)  # do the stamps cost launch time?
 python tools/stamp_cost.py 5 2>&1 | grep -v "$FILT" | tee gpurun_out/r06/stamp_cost.txt
 ;;
+profile)  # bench lines first (un-profiled), then traces + PMC passes of the same commands, all on this ONE box
+O=gpurun_out/r06
+python bench.py --no-cpu-baseline > $O/bench_cfg2.json 2>/dev/null
+( time python bench.py --steps 20 --warmup 5 ) > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --no-cpu-baseline --workload cfg3 --steps 1000 --warmup 100 > $O/bench_cfg3.json 2>/dev/null
+python bench.py --no-cpu-baseline --workload cfg5 --steps 1000 --warmup 100 > $O/bench_cfg5.json 2>/dev/null
+python bench.py --no-cpu-baseline --workload cfg4 --steps 10 --warmup 2 > $O/bench_cfg4.json 2>/dev/null
+tools/profile.sh r06_cfg2 > $O/cfg2_pmc_summary.txt 2>&1
+tools/profile.sh r06_cfg3 --workload cfg3 --steps 1000 --warmup 100 > $O/cfg3_pmc_summary.txt 2>&1
+tools/profile.sh r06_cfg5 --workload cfg5 --steps 1000 --warmup 100 > $O/cfg5_pmc_summary.txt 2>&1
+for w in cfg2 cfg3 cfg5; do cp gpurun_out/prof_r06_$w/trace/*/*kernel_stats.csv $O/${w}_kernel_stats.csv; cp gpurun_out/prof_r06_$w/summary.json $O/${w}_pmc_summary.json; done
+# the batch-table builds: four batches per launch (tools/loop.py cfgNx4)
+for w in cfg2 cfg3 cfg5; do
+  tools/prof_loop.sh ${w}x4 r06_${w}_x4 > $O/${w}_x4_pmc_summary.txt 2>&1
+  cp gpurun_out/prof_r06_${w}_x4/trace/*/*kernel_stats.csv $O/${w}_x4_kernel_stats.csv; cp gpurun_out/prof_r06_${w}_x4/summary.json $O/${w}_x4_pmc_summary.json
+done
+rm -rf gpurun_out/prof_r06_*  # raw traces: more than gpurun copies back; the summaries above are what is kept
+for f in $O/bench_cfg*.json; do python -c "
+import json,sys;d=json.load(open('$f'));r=d['roofline'];print('$f', r['kernel'], round(r['avg_launch_us'],2), 'us frac', round(r['frac'],4), 'clk', r.get('clock_ghz_measured'), 'valu', r.get('valu_floor_frac'))"; done
+grep real $O/bench_default.err; summ $O/bench_default.json
+for w in cfg2 cfg3 cfg5; do head -2 $O/${w}_kernel_stats.csv | cut -c1-220; head -2 $O/${w}_x4_kernel_stats.csv | cut -c1-220; done
+for w in cfg2 cfg3 cfg5; do python tools/power_probe.py --workload $w --inputs ring,zeros --seconds 1.5 2>&1 | grep -v "$FILT"; done > $O/power_probe.txt
+SS_PROFILE_TAG="round 6 (final code)" SS_PROFILE_CLOCK_GHZ=$(python -c "import json;print(json.load(open('$O/bench_cfg2.json'))['roofline']['clock_ghz_measured'])") python tools/make_traffic_json.py cfg2=$O/cfg2_pmc_summary.json cfg3=$O/cfg3_pmc_summary.json cfg5=$O/cfg5_pmc_summary.json cfg2_x4=$O/cfg2_x4_pmc_summary.json cfg3_x4=$O/cfg3_x4_pmc_summary.json cfg5_x4=$O/cfg5_x4_pmc_summary.json > /dev/null
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python tools/stage_rate.py 2>&1 | grep -v "$FILT" > $O/stage_rate.txt
+;;
 *)
-echo "usage: $0 {first|tests|spread|stampcost}" >&2
+echo "usage: $0 {first|tests|spread|stampcost|profile}" >&2
 exit 2
 ;;
 esac
