@@ -70,6 +70,29 @@ WORKLOADS = {
 }
 
 
+# The legs a default N = 1 run appends behind the headline (`secondary.<name>`): name -> (workload, measure_simple arguments).
+# `python bench.py --leg <name>` runs one of them alone (what tools/profile.sh wraps in rocprofv3 for the batch-table builds).
+#   cfg2: the headline workload and kernel over 1000 single-stream steps, run inside the library -- HIP events around the launches AND
+#     the in-kernel stamps of ALL of those same launches (every wave's cycles / lifetime, summed on the device): the one
+#     cycles_per_launch whose time and clock share launches -- stamping only the region's last quarter spreads 1.2 % between regions
+#     on one box, stamping all of it 0.3 % (profiles/r06/stamp_cost.txt) --, and the figure rounds are compared on (a 20-step headline
+#     region is 0.6 ms: the same binary reads 26 - 30 us there, profiles/r05/box_spread.txt).
+#   cfg2_x4 / cfg3_x4 / cfg5_x4: four independent batches of the workload per ss_mfcc_batches_device /
+#     ss_mel_spectrogram_batches_device call (ONE persistent launch): what the start-up + tail of a launch cost, recovered without
+#     streams.  Per-batch figures; never `value`.
+#   cfg3 / cfg5: 1000 steps, 50 - 60 ms each (regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
+#   cfg4: the whole 360 000-clip corpus in one launch, 5 steps
+LEGS = {
+    "cfg2": ("cfg2", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
+    "cfg2_x4": ("cfg2", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
+    "cfg3": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+    "cfg3_x4": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
+    "cfg5": ("cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+    "cfg5_x4": ("cfg5", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
+    "cfg4": ("cfg4", dict(steps=5, warmup=1, prewarm_ms=300.0)),
+}
+
+
 def synth_batch(torch, batch, n, seed, device):
     """N(0, 0.1) clips (the distribution of the reference's own tests, lib.rs:18-22), generated on device."""
     g = torch.Generator(device=device)
@@ -424,7 +447,11 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
                        f"persistent launch; avg_launch_us, bytes and frac are per {clips}-clip batch (launch / group): the start-up and the one-unit "
                        f"tail of a launch are paid once per {group} batches")
     e = load_pmc(workload if group == 1 else f"{workload}_x{group}")
-    if e and kernel.split("<")[0] in e.get("kernel_full", ""):
+    # (the batch-table builds report themselves as <kernel>m<...>; rocprofv3 lists them as one more instantiation of <kernel><...>)
+    kbase = kernel.split("<")[0]
+    if group > 1 and kbase.endswith("m"):
+        kbase = kbase[:-1]
+    if e and kbase in e.get("kernel_full", ""):
         # (a launch of `group` batches: the stored per-launch counters are divided down to one batch, like every figure of this leg)
         res["traffic"] = e.get("hbm_bytes_per_launch") / group if e.get("hbm_bytes_per_launch") else None
         res["traffic_source"] = (f"profiles/pmc_traffic.json (stored, {e.get('profiled', '?')}; 2 x FETCH_SIZE + WRITE_SIZE per launch"
@@ -503,6 +530,8 @@ def main():
     ap.add_argument("--ring-mib", type=int, default=300, help="size of the rotated input ring (measurement aid: below 256 MiB the Infinity Cache serves the input)")
     ap.add_argument("--one-device", action="store_true", help="test aid: every rank uses device 0 (gloo instead of RCCL; control flow only)")
     ap.add_argument("--link-gbps", type=float, default=64.0, help="one-way xGMI rate per link assumed by scaling_model (unmeasured here)")
+    ap.add_argument("--leg", default="", choices=[""] + sorted(LEGS), help="run ONE of the default run's secondary legs alone and print its JSON "
+                    "(an explicit --steps / --warmup replaces the leg's own; measurement aid: rocprofv3 passes of the batch-table builds)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -573,6 +602,19 @@ def main():
         shard_max = max(shard_sizes(corpus, world))
         if clips == 0:
             raise SystemExit("bench.py: --corpus-clips is smaller than the number of ranks")
+    if args.leg:
+        wl, kw = LEGS[args.leg]
+        kw = dict(kw)
+        if "--steps" in sys.argv:
+            g = kw.get("group", 1)
+            kw["steps"] = max(g, args.steps // g * g)
+            if kw.get("stamped"):
+                kw["stamped"] = kw["steps"]
+        if "--warmup" in sys.argv:
+            g = kw.get("group", 1)
+            kw["warmup"] = args.warmup // g * g
+        print(json.dumps(dict(measure_simple(torch, ss, wl, device, **kw), leg=args.leg)), flush=True)
+        return
     if args.force_generic:
         # a process-wide kernel-selection override: a test aid of the LAB library (include/speechsauce_amd_debug.h), so this
         # measurement aid runs the whole bench on that build
@@ -930,23 +972,7 @@ def main():
             # profiles/r05/streams.txt)
             # Everything below is extra: none of it may take the measured headline down with it (each leg reports {"error": ...}).
             res["secondary"] = {}
-            # secondary.cfg2: the headline workload and kernel over 1000 single-stream steps, run inside the library -- HIP events
-            # around the launches AND the in-kernel stamps of ALL of those same launches (every wave's cycles / lifetime, summed on the
-            # device): the one cycles_per_launch whose time and clock share launches -- stamping only the region's last quarter spreads
-            # 1.2 % between regions on one box, stamping all of it 0.3 % (profiles/r06/stamp_cost.txt) --, and the figure rounds are compared on (a 20-step headline region is 0.6 ms: the same binary
-            # reads 26 - 30 us there, profiles/r05/box_spread.txt).
-            # secondary.cfg2_x4 / cfg3_x4 / cfg5_x4: four independent batches of the workload per ss_mfcc_batches_device /
-            # ss_mel_spectrogram_batches_device call (ONE persistent launch): what the start-up + tail of a launch cost, recovered without
-            # streams.  Per-batch figures; never `value`.
-            # (cfg3 / cfg5: 1000 steps, 50 - 60 ms each: regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
-            legs = (("cfg2", "cfg2", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
-                    ("cfg2_x4", "cfg2", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
-                    ("cfg3", "cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
-                    ("cfg3_x4", "cfg3", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
-                    ("cfg5", "cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
-                    ("cfg5_x4", "cfg5", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
-                    ("cfg4", "cfg4", dict(steps=5, warmup=1, prewarm_ms=300.0)))
-            for name, wl, kw in legs:
+            for name, (wl, kw) in LEGS.items():
                 try:
                     res["secondary"][name] = measure_simple(torch, ss, wl, device, **kw)
                 except Exception as e:

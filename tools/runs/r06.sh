@@ -48,9 +48,10 @@ tools/profile.sh r06_cfg2 > $O/cfg2_pmc_summary.txt 2>&1
 tools/profile.sh r06_cfg3 --workload cfg3 --steps 1000 --warmup 100 > $O/cfg3_pmc_summary.txt 2>&1
 tools/profile.sh r06_cfg5 --workload cfg5 --steps 1000 --warmup 100 > $O/cfg5_pmc_summary.txt 2>&1
 for w in cfg2 cfg3 cfg5; do cp gpurun_out/prof_r06_$w/trace/*/*kernel_stats.csv $O/${w}_kernel_stats.csv; cp gpurun_out/prof_r06_$w/summary.json $O/${w}_pmc_summary.json; done
-# the batch-table builds: four batches per launch (tools/loop.py cfgNx4)
+# the batch-table builds: four batches per launch (bench.py --leg cfgN_x4: the default run's secondary legs, alone)
 for w in cfg2 cfg3 cfg5; do
-  tools/prof_loop.sh ${w}x4 r06_${w}_x4 > $O/${w}_x4_pmc_summary.txt 2>&1
+  python bench.py --leg ${w}_x4 > $O/bench_${w}_x4.json 2>/dev/null
+  tools/profile.sh r06_${w}_x4 --leg ${w}_x4 > $O/${w}_x4_pmc_summary.txt 2>&1
   cp gpurun_out/prof_r06_${w}_x4/trace/*/*kernel_stats.csv $O/${w}_x4_kernel_stats.csv; cp gpurun_out/prof_r06_${w}_x4/summary.json $O/${w}_x4_pmc_summary.json
 done
 rm -rf gpurun_out/prof_r06_*  # raw traces: more than gpurun copies back; the summaries above are what is kept
@@ -63,8 +64,22 @@ SS_PROFILE_TAG="round 6 (final code)" SS_PROFILE_CLOCK_GHZ=$(python -c "import j
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 python tools/stage_rate.py 2>&1 | grep -v "$FILT" > $O/stage_rate.txt
 ;;
+profile_x4)  # the batch-table part of `profile` alone
+O=gpurun_out/r06
+for w in cfg2 cfg3 cfg5; do
+  python bench.py --leg ${w}_x4 > $O/bench_${w}_x4.json 2>/dev/null
+  tools/profile.sh r06_${w}_x4 --leg ${w}_x4 > $O/${w}_x4_pmc_summary.txt 2>&1
+  cp gpurun_out/prof_r06_${w}_x4/trace/*/*kernel_stats.csv $O/${w}_x4_kernel_stats.csv; cp gpurun_out/prof_r06_${w}_x4/summary.json $O/${w}_x4_pmc_summary.json
+  python -c "
+import json;d=json.load(open('$O/bench_${w}_x4.json'));print('${w}_x4', d['kernel'], round(d['avg_launch_us'],2), 'us per batch,', round(d['launch_us'],1), 'us per launch, frac', round(d['frac'],4))"
+  head -2 $O/${w}_x4_kernel_stats.csv | tail -1 | cut -c1-200
+done
+rm -rf gpurun_out/prof_r06_*
+SS_PROFILE_TAG="round 6 (final code)" SS_PROFILE_CLOCK_GHZ=2.0 python tools/make_traffic_json.py cfg2_x4=$O/cfg2_x4_pmc_summary.json cfg3_x4=$O/cfg3_x4_pmc_summary.json cfg5_x4=$O/cfg5_x4_pmc_summary.json > /dev/null
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+;;
 *)
-echo "usage: $0 {first|tests|spread|stampcost|profile}" >&2
+echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4}" >&2
 exit 2
 ;;
 esac
