@@ -175,6 +175,8 @@ def test_bench_launches_its_own_ranks(mode):
     m = d["scaling_model"]
     assert m["gather_bound_frames_per_s"] == pytest.approx(2 * m["link_gbps_assumed_one_way"] * 1e9 / (4 * 13))
     assert 0 < m["path_only_efficiency"] <= 1.5 and "unmeasured" in m["note"]
+    # one word for whoever reads the first SCALE record: what holds `value` (round 6)
+    assert m["bound"] in ("interconnect", "path")
 
 
 def _chunk_worker(rank, world, port, shard_max, chunks, mode, result_dir):
@@ -241,6 +243,7 @@ def test_bench_cfg4_strong_sharding_two_ranks(mode, corpus):
     assert g["mode"] == mode and g["chunks_per_step"] == 8 and g["collectives_timed"] == 4 * 8
     m = d["scaling_model"]
     assert 0 < m["path_only_efficiency"] <= 1.5 and m["gather_bound_frames_per_s"] > 0 and "unmeasured" in m["note"]
+    assert m["bound"] in ("interconnect", "path")
     # frames per step = the whole corpus, whatever the shard sizes
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - corpus * d["config"]["frames_per_clip"]) < 1e-6 * corpus * 98
 
