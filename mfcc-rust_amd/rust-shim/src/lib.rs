@@ -79,6 +79,8 @@ extern "C" {
     fn ss_mfcc_batch(cfg: *const SsConfig, x: *const f32, batch: usize, n: usize, ld: usize, out: *mut f32) -> c_int;
     fn ss_mfcc_batch_device(cfg: *const SsConfig, d_x: *const f32, batch: usize, n: usize, ld: usize, d_out: *mut f32,
                             stream: *mut c_void) -> c_int;
+    fn ss_mfcc_batches_device(cfg: *const SsConfig, n_batches: usize, d_x: *const *const f32, batch: *const usize, n: usize, ld: usize,
+                              d_out: *const *mut f32, stream: *mut c_void) -> c_int;
     fn ss_preemphasis(x: *const f32, n: usize, shift: c_long, cof: f32, y: *mut f32) -> c_int;
     fn ss_frame_sizes(p: *const SsParams, frame_len: *mut usize, frame_step: *mut usize) -> c_int;
     fn ss_stft(cfg: *const SsConfig, x: *const f32, channels: usize, n: usize, out: *mut f32) -> c_int;
@@ -361,6 +363,19 @@ pub unsafe fn mfcc_batch_device(cfg: &SpeechConfig, d_x: *const f32, batch: usiz
     check(ss_mfcc_batch_device(cfg.raw(), d_x, batch, n, ld, d_out, stream))
 }
 
+/// Several device-resident batches per call (ABI 7): batch `b` is `batch[b]` clips of `n` samples at `d_x[b]` (row stride `ld`), its
+/// features go to `d_out[b]`.  One persistent launch for up to 8 batches where the configuration's kernel takes a batch table;
+/// bit-identical to `batch.len()` calls of `mfcc_batch_device`.
+/// # Safety
+/// As `mfcc_batch_device`, for every batch.
+pub unsafe fn mfcc_batches_device(cfg: &SpeechConfig, d_x: &[*const f32], batch: &[usize], n: usize, ld: usize, d_out: &[*mut f32],
+                                  stream: *mut c_void) -> Result<(), Error> {
+    if d_x.len() != batch.len() || d_out.len() != batch.len() {
+        return Err(Error { status: SS_ERR_ARG, detail: "d_x, batch and d_out must have one entry per batch".to_string() });
+    }
+    check(ss_mfcc_batches_device(cfg.raw(), batch.len(), d_x.as_ptr(), batch.as_ptr(), n, ld, d_out.as_ptr(), stream))
+}
+
 /// functions.rs:86-123: `[channels, samples]` -> `Array3<Complex32>` `[channels, rows, freq_size]`
 pub fn try_stft2(input: ArrayView2<f32>, cfg: &SpeechConfig) -> Result<Array3<Complex32>, Error> {
     let owned = input.as_standard_layout();
@@ -596,7 +611,7 @@ pub mod config {
 /// speechsauce::feature (feature.rs): mfcc, mfe, mel_spectrogram1 / 2 (+ the private lmfe / extract_derivative_feature, public here)
 pub mod feature {
     pub use super::{extract_derivative_feature, lmfe, mel_spectrogram1, mel_spectrogram2, mfcc, mfe};
-    pub use super::{try_lmfe, try_mel_spectrogram2, try_mfcc, try_mfcc_batch, try_mfe};
+    pub use super::{mfcc_batch_device, mfcc_batches_device, try_lmfe, try_mel_spectrogram2, try_mfcc, try_mfcc_batch, try_mfe};
 }
 /// speechsauce::processing (processing.rs)
 pub mod processing {
