@@ -180,6 +180,53 @@ def test_cfg5_batches_in_one_launch(ss, sslib, oracle):
     assert all(torch.equal(o, w) for o, w in zip(outs, want))
 
 
+def test_random_batch_sets_through_the_three_batch_table_builds(ss, sslib):
+    """Seeded random sets of 2..8 batches -- mostly tiny ones, so that a workgroup's contiguous unit range crosses several batch
+    boundaries, a boundary falls on a workgroup's last unit, and launches run with fewer workgroups than CUs -- through each of the
+    three batch-table builds: every block bit-identical to a launch of its own."""
+    import torch
+    from speechsauce_amd import SpeechConfig, make_params
+
+    rng = np.random.default_rng(6)
+    cfg2 = SpeechConfig(make_params(sample_rate=16000))
+    cfg5 = SpeechConfig(make_params(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40,
+                                    num_filters=256, high_frequency=22050.0))
+    cfg3 = SpeechConfig(make_params(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=128, high_frequency=8000.0))
+    R = cfg3.stft_rows(16000)[0]
+    mel_ok = [129, 150, 192, 257, 300, 333, 384, 400, 512]  # block sizes that select the twelve-wave build on their own
+    for trial in range(10):
+        nb = int(rng.integers(2, 9))
+        small = [int(c) for c in rng.integers(1, 30, nb)]
+        if trial % 3 == 0:
+            small[int(rng.integers(0, nb))] = int(rng.integers(200, 700))
+        for cfg, n, counts, tail, kernel in ((cfg2, 16000, small, (98, 13), MULTI_KERNEL), (cfg5, 44100, [max(1, c // 2) for c in small], (39, 40), MULTI_KERNEL_4096)):
+            xs = _batches(torch, counts, n, 400 + trial)
+            want = _separate(torch, sslib, cfg, xs, tail, n)
+            got = [torch.full((c,) + tail, float("nan"), device="cuda") for c in counts]
+            px, nbt, po = _tables(xs, got)
+            assert sslib.ss_mfcc_batches_device(cfg.handle, len(xs), px, nbt, n, n, po, None) == 0, sslib.ss_last_error_string()
+            assert sslib.ss_last_kernel_name() == kernel, (counts, sslib.ss_last_kernel_name())
+            torch.cuda.synchronize()
+            for b, c in enumerate(counts):
+                assert torch.equal(got[b], want[b]), (trial, counts, b)
+        counts = [mel_ok[int(i)] for i in rng.integers(0, len(mel_ok), nb)]
+        xs = _batches(torch, counts, 16000, 500 + trial)
+        want = []
+        for x in xs:
+            o = torch.empty((x.shape[0], 128, R), device="cuda")
+            assert sslib.ss_mel_spectrogram_device(cfg3.handle, x.data_ptr(), x.shape[0], 16000, 16000, o.data_ptr(), None) == 0
+            want.append(o)
+        got = [torch.full((c, 128, R), float("nan"), device="cuda") for c in counts]
+        px, nbt, po = _tables(xs, got)
+        assert sslib.ss_mel_spectrogram_batches_device(cfg3.handle, len(xs), px, nbt, 16000, 16000, po, None) == 0, sslib.ss_last_error_string()
+        assert sslib.ss_last_kernel_name() == MULTI_KERNEL_MEL, (counts, sslib.ss_last_kernel_name())
+        torch.cuda.synchronize()
+        for b, c in enumerate(counts):
+            assert torch.equal(got[b], want[b]), (trial, counts, b)
+    for c in (cfg2, cfg3, cfg5):
+        c.device_status()
+
+
 def test_batches_argument_errors_launch_nothing(ss, sslib):
     import torch
     from speechsauce_amd import SpeechConfig, make_params

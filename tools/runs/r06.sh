@@ -78,8 +78,12 @@ rm -rf gpurun_out/prof_r06_*
 SS_PROFILE_TAG="round 6 (final code)" SS_PROFILE_CLOCK_GHZ=2.0 python tools/make_traffic_json.py cfg2_x4=$O/cfg2_x4_pmc_summary.json cfg3_x4=$O/cfg3_x4_pmc_summary.json cfg5_x4=$O/cfg5_x4_pmc_summary.json > /dev/null
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 ;;
+sweeps)  # robustness: random configurations against the oracle (every third on poisoned LDS)
+SS_SWEEP_SEED=10000 timeout 1500 python tools/bigsweep.py 2>&1 | grep -v "$FILT" | tail -6 | tee gpurun_out/r06/bigsweep.txt
+SS_SWEEP_SEED=10000 timeout 1500 python tools/melsweep.py 2>&1 | grep -v "$FILT" | tail -6 | tee gpurun_out/r06/melsweep.txt
+;;
 *)
-echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4}" >&2
+echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4|sweeps}" >&2
 exit 2
 ;;
 esac
