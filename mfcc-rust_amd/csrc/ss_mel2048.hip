@@ -56,18 +56,18 @@ using namespace wv;
 #define SS_P_MEL 1
 #endif
 #define SS_P_FFT 0
-// (Fair shares between the three waves of a SIMD -- one more priority step for the younger waves in some of their units -- were
-// measured in round 5 and lost: profiles/r05/ab_cfg3_fair.txt; the retired switch is in tools/experiments/ss_mel2048_lab_r05.diff.)
 #define SS_PRIOL(x) __builtin_amdgcn_s_setprio(x)
+// Measured and retired (rounds 4 / 5; records profiles/r04, profiles/r05, code tools/experiments/ss_mel2048_lab_r05.diff): fair shares
+// between the three waves of a SIMD by rotating a priority step (equal shares at the slowest wave's speed, +9 %); no unit for the
+// all-zero row pairs (6.6 % fewer instructions, +0.7 - 1.5 us: those units were free filler under the slow waves' last ones); a
+// cross-workgroup pool for the launch's last eighth of units (44.2 against 44.1 us: the end of a launch is one UNIT long, not one
+// slow CU long); work items of four rows with 16-byte output pieces (49.3 against 46.8 us: coarser items spread worse over twelve
+// waves of different speeds); non-temporal sample loads / output stores.
 namespace L = mel2048_layout;
 constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange region: two frames x half the columns (8704 B)
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
-
-// Row pairs of a clip a mel build spends a unit on: every pair, the trailing all-zero ones (functions.rs:121) included.  Skipping
-// them (15 units per clip instead of 16 for cfg3, 6.6 % fewer instructions) made the launch 0.7 - 1.5 us LONGER on four boxes: the
-// zero units are free filler under the slow waves' last units, and the tail is one unit long either way (round 5:
-// profiles/r05/ab_cfg3_zskip.txt, pmc_cfg3_zskip.txt; the retired switch is in tools/experiments/ss_mel2048_lab_r05.diff).
+// Row pairs of a clip a mel build spends a unit on: every pair, the trailing all-zero ones (functions.rs:121) included.
 __host__ __device__ inline unsigned mel_work_pairs(unsigned rows, unsigned real_rows)
 {
     (void)real_rows;
@@ -332,9 +332,6 @@ __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a
 // phases of the exchange fill it (left half-defined, the "undefined" halves are carried around the loop and spilled).
 // Twelve exchange regions + the tables are 134 KB of LDS, so the CU-wide whole-line tile of the 8-wave build (55 KB) does not
 // fit beside them: the rows leave as 8-byte pieces of lines (HBM writes 1.4x the output, traffic 1.09x the algorithmic bytes).
-// (A work item of FOUR consecutive rows -- 16-byte output pieces, a quarter of the store instructions -- was measured in round 4 and
-// lost: cfg3 49.3 against 46.8 us, profiles/r04/ab_cfg3_rows4.txt: 32 four-row items per CU spread over twelve waves of different
-// speeds worse than 64 two-row units do.  The retired build is in tools/experiments/ss_mel2048_lab_r05.diff.)
 // MULTI (ss_mel_spectrogram_batches_device): the launch's units are the concatenation of up to kMaxLaunchBatches blocks' row
 // pairs, each block with its own input and output (BatchTable, ss_device.h; Seg / seg_of, ss_wave.h).
 template <bool FIXMEL, bool STFT = false, bool MULTI = false>
@@ -352,10 +349,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
     unsigned long long units = static_cast<unsigned long long>(a.batch) * pairs;
     if constexpr (MULTI) units = a.batch;  // (the launcher hands over the launch's unit count: the sum over the blocks)
     // Work distribution: the workgroup owns a contiguous range of units (neighbouring units share three quarters of their samples:
-    // L1 / L2 locality), its waves pull them from an LDS counter.  (A cross-workgroup pool for the launch's last eighth of units --
-    // workgroups that are ahead take work from the ones behind -- was measured in round 5 and lost: cfg3 44.2 us with it, 44.1
-    // without, profiles/r05/ab_cfg3_pool.txt; the end of a launch is one UNIT long, not one slow CU long.  The retired code is in
-    // tools/experiments/ss_mel2048_lab_r05.diff.)
+    // L1 / L2 locality), its waves pull them from an LDS counter.
     const unsigned u_lo = static_cast<unsigned>(units * blockIdx.x / gridDim.x);
     const unsigned u_hi = static_cast<unsigned>(units * (blockIdx.x + 1) / gridDim.x);
     {
@@ -624,55 +618,64 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #endif
 }
 
+// ---- launchers: LDS budget, grid (one persistent workgroup per CU, fewer when there is not a unit per wave), the launch itself ----
+size_t mel_lds_bytes(int waves, int wpitch)
+{
+    return (static_cast<size_t>(waves) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(wpitch)) * sizeof(float);
+}
+unsigned mel_grid(unsigned long long units, int waves, int num_cus)
+{
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256), blocks = (units + waves - 1) / waves;
+    return static_cast<unsigned>(blocks < cap ? blocks : cap);
+}
+// Eight waves per CU or twelve?  A unit (two rows) takes a wave 1.29 x as long with three waves on its SIMD as with two (cfg3, one
+// box: 8.0 us against 6.2), and a CU's units go round in ceil(units / waves) rounds: twelve waves win unless the CU's share of
+// units fits eight waves much better (cfg3: 64 units per CU, 8 rounds of 8 against 5.3 -> 6 of 12: 46.5 us against 49.7).
+bool twelve_waves_win(unsigned long long units, int num_cus)
+{
+    const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256), per_cu = (units + cus - 1) / cus;
+    return 1.29 * static_cast<double>((per_cu + 11) / 12) < static_cast<double>((per_cu + 7) / 8);
+}
+template <typename Kern, typename... Args>
+hipError_t mel_go(Kern kern, const char *name, unsigned grid, int waves, size_t lds, hipStream_t stream, LaunchInfo *info, const Args &...args)
+{
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(waves * 64), lds};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, stream, args...);
+    return hipGetLastError();
+}
+
 template <int kWavesM>
 hipError_t launch_mel_w(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    const size_t lds = mel_lds_bytes(kWavesM, a.mel_wpitch);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (a.batch == 0) return hipSuccess;
-    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * (a.out_stft ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows));
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
-    unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
-    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    auto go = [&](auto kern, const char *name) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kWavesM * 64), lds};
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a);
-        return hipGetLastError();
-    };
+    const unsigned grid = mel_grid(units, kWavesM, num_cus);
     // (a fixed-shape mel stage costs this kernel 84 bytes of scratch per lane beside the prefetched unit: measured 77 us against
     // 50; the run-time loops stay, with their remainders fetched in one batch)
-    if (a.out_stft) return go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>");
-    if (a.fullp) return go(ss_mel_c1024<kWavesM, false, true>, "ss_mel_c1024<fullp>");
-    return go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024");
+    if (a.out_stft) return mel_go(ss_mel_c1024<kWavesM, true>, "ss_mel_c1024<stft>", grid, kWavesM, lds, stream, info, a);
+    if (a.fullp) return mel_go(ss_mel_c1024<kWavesM, false, true>, "ss_mel_c1024<fullp>", grid, kWavesM, lds, stream, info, a);
+    return mel_go(ss_mel_c1024<kWavesM, false>, "ss_mel_c1024", grid, kWavesM, lds, stream, info, a);
 }
 
-// three waves per SIMD, direct stores (see ss_mel_c1024_w12): mel output with the reference bank shape
+// three waves per SIMD, direct stores (see ss_mel_c1024_w12): mel output with the reference bank shape, and stft
 hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    constexpr int kWavesM = 12;
     if (a.fullp || a.batch == 0) return hipErrorInvalidValue;
-    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    const size_t lds = mel_lds_bytes(12, a.mel_wpitch);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
-    const unsigned long long units = static_cast<unsigned long long>(a.batch) * ((a.rows + 1) / 2);
+    const unsigned long long units = static_cast<unsigned long long>(a.batch) * (a.out_stft ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows));
     if (units >= 0xffffffffull) return hipErrorInvalidValue;
-    // (the mel builds enumerate working pairs only: see the kernel)
-    const unsigned long long work = a.out_stft ? units : static_cast<unsigned long long>(a.batch) * mel_work_pairs(a.rows, a.real_rows);
-    const unsigned long long blocks = (work + kWavesM - 1) / kWavesM;
-    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    auto go = [&](auto kern, const char *name) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-        if (info) *info = LaunchInfo{name, grid, static_cast<unsigned>(kWavesM * 64), lds};
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a, MultiArg<false>{});
-        return hipGetLastError();
-    };
-    if (a.out_stft) return go(ss_mel_c1024_w12<false, true>, "ss_mel_c1024<w12,stft>");
+    const unsigned grid = mel_grid(units, 12, num_cus);
+    const MultiArg<false> none{};
+    if (a.out_stft) return mel_go(ss_mel_c1024_w12<false, true>, "ss_mel_c1024<w12,stft>", grid, 12, lds, stream, info, a, none);
     const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
-    return m6321 ? go(ss_mel_c1024_w12<true>, "ss_mel_c1024<w12,mel6321>") : go(ss_mel_c1024_w12<false>, "ss_mel_c1024<w12>");
+    return m6321 ? mel_go(ss_mel_c1024_w12<true>, "ss_mel_c1024<w12,mel6321>", grid, 12, lds, stream, info, a, none)
+                 : mel_go(ss_mel_c1024_w12<false>, "ss_mel_c1024<w12>", grid, 12, lds, stream, info, a, none);
 }
 
 }  // namespace
@@ -680,54 +683,39 @@ hipError_t launch_mel_w12(const Mel2048Args &a, hipStream_t stream, int num_cus,
 hipError_t launch_mel_c1024_multi(const Mel2048Args &a_in, int n_batches, const float *const *d_x, float *const *d_out, const size_t *channels,
                                   hipStream_t stream, int num_cus, LaunchInfo *info)
 {
-    constexpr int kWavesM = 12;
     Mel2048Args a = a_in;
     // the build that exists: mel output, the reference bank shape (P rows of bins 0..512), compile-time tap counts 6 / 3 / 2 / 1
     const bool m6321 = a.mel_q4[0] == 6 && a.mel_q4[1] == 3 && a.mel_q4[2] == 2 && a.mel_q4[3] == 1;
     if (n_batches < 1 || n_batches > kMaxLaunchBatches || a.out_stft || a.fullp || !m6321) return hipErrorInvalidValue;
-    const size_t lds = (static_cast<size_t>(kWavesM) * kWaveFloatsM + L::kMelW + 8 + 32 * static_cast<size_t>(a.mel_wpitch)) * sizeof(float);
+    const size_t lds = mel_lds_bytes(12, a.mel_wpitch);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const unsigned pairs = mel_work_pairs(a.rows, a.real_rows);
-    const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
-    BatchTable m{};
+    MultiArg<true> mt{};
     unsigned long long units = 0;
     for (int b = 0; b < kMaxLaunchBatches; ++b) {
-        m.uend[b] = 0xffffffffu;
+        mt.m.uend[b] = 0xffffffffu;
         if (b >= n_batches) continue;
-        if (channels[b] == 0 || channels[b] > 0x7fffffffull) return hipErrorInvalidValue;  // (empty blocks are dropped by the caller)
-        {
-            // Only blocks that launch_mel_c1024 would give the twelve-wave build on their own share a launch: the eight-wave build
-            // rounds a few FMAs differently in the last bit, and the results of a call must not depend on how its blocks were grouped
-            const unsigned long long per_cu = (static_cast<unsigned long long>(channels[b]) * pairs + cus - 1) / cus;
-            const double r8 = static_cast<double>((per_cu + 7) / 8), r12 = 1.29 * static_cast<double>((per_cu + 11) / 12);
-            if (!(r12 < r8)) return hipErrorInvalidValue;
-        }
+        // Only blocks that launch_mel_c1024 would give the twelve-wave build on their own share a launch (empty ones are dropped by
+        // the caller): the eight-wave build rounds a few FMAs differently in the last bit, and the results of a call must not depend
+        // on how its blocks were grouped
+        if (channels[b] == 0 || channels[b] > 0x7fffffffull || !twelve_waves_win(static_cast<unsigned long long>(channels[b]) * pairs, num_cus))
+            return hipErrorInvalidValue;
         units += static_cast<unsigned long long>(channels[b]) * pairs;
         if (units >= 0xffffffffull) return hipErrorInvalidValue;
-        m.x[b] = d_x[b];
-        m.out[b] = d_out[b];
-        m.uend[b] = static_cast<uint32_t>(units);
-        m.total[b] = static_cast<uint32_t>(channels[b]);
+        mt.m.x[b] = d_x[b];
+        mt.m.out[b] = d_out[b];
+        mt.m.uend[b] = static_cast<uint32_t>(units);
+        mt.m.total[b] = static_cast<uint32_t>(channels[b]);
     }
-    if (units == 0) return hipErrorInvalidValue;
     a.x = d_x[0];
     a.out = d_out[0];
     a.batch = static_cast<uint32_t>(units);  // MULTI: the launch's unit count (the kernel takes the blocks from the table)
-    const unsigned cap = static_cast<unsigned>(num_cus > 0 ? num_cus : 256);
-    const unsigned long long blocks = (units + kWavesM - 1) / kWavesM;
-    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : cap);
-    auto kern = ss_mel_c1024_w12<true, false, true>;
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    if (info) *info = LaunchInfo{"ss_mel_c1024m<w12,mel6321>", grid, static_cast<unsigned>(kWavesM * 64), lds};
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesM * 64), lds, stream, a, MultiArg<true>{m});
-    return hipGetLastError();
+    return mel_go(ss_mel_c1024_w12<true, false, true>, "ss_mel_c1024m<w12,mel6321>", mel_grid(units, 12, num_cus), 12, lds, stream, info, a, mt);
 }
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info)
 {
     const unsigned long long units = static_cast<unsigned long long>(a.batch) * (a.out_stft ? (a.rows + 1) / 2 : mel_work_pairs(a.rows, a.real_rows));
-    const unsigned long long cus = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256);
 #if SS_LAB
     // lab library: ss_debug_mel_tile(2) asks for the eight-wave builds only -- the retired whole-line tile
     // (tools/experiments/ss_mel2048_tile.hip) where the shape has one, else eight waves with direct stores
@@ -752,17 +740,9 @@ hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cu
         }
         return launch_mel_w<8>(a, stream, num_cus, info);
     }
-    // Eight waves per CU or twelve?  A unit (two rows) takes a wave 1.29 x as long with three waves on its SIMD as with two (cfg3,
-    // one box: 8.0 us against 6.2), and a CU's units go round in ceil(units / waves) rounds: twelve waves win unless the CU's
-    // share of units fits eight waves much better (cfg3: 64 units per CU, 8 rounds of 8 against 5.3 -> 6 of 12: 46.5 us
-    // against 49.7).
-    if (!a.out_stft && !a.fullp && dbg_mel_build() != 1 && dbg_mel_build() != 2) {
-        const unsigned long long per_cu = (units + cus - 1) / cus;
-        const double r8 = static_cast<double>((per_cu + 7) / 8), r12 = 1.29 * static_cast<double>((per_cu + 11) / 12);
-        if (r12 < r8 || dbg_mel_build() == 3) {
-            const hipError_t e = launch_mel_w12(a, stream, num_cus, info);
-            if (e != hipErrorInvalidValue) return e;
-        }
+    if (!a.out_stft && !a.fullp && dbg_mel_build() != 1 && dbg_mel_build() != 2 && (twelve_waves_win(units, num_cus) || dbg_mel_build() == 3)) {
+        const hipError_t e = launch_mel_w12(a, stream, num_cus, info);
+        if (e != hipErrorInvalidValue) return e;
     }
     return launch_mel_w<8>(a, stream, num_cus, info);
 }
