@@ -68,11 +68,7 @@ constexpr int kExSlots = 2 * 16 * 34;        // float2 in the wave's exchange re
 constexpr int kWaveFloatsM = kExSlots * 2;  // one exchange region; the two P rows (2 x 520 floats) reuse it after the exchange
 
 // Row pairs of a clip a mel build spends a unit on: every pair, the trailing all-zero ones (functions.rs:121) included.
-__host__ __device__ inline unsigned mel_work_pairs(unsigned rows, unsigned real_rows)
-{
-    (void)real_rows;
-    return (rows + 1) / 2;
-}
+__host__ __device__ inline unsigned mel_work_pairs(unsigned rows, unsigned /*real_rows*/) { return (rows + 1) / 2; }
 
 template <int kWavesM, bool STFT, bool FULLP = false>
 __global__ __launch_bounds__(kWavesM * 64) void ss_mel_c1024(const Mel2048Args a)
