@@ -80,14 +80,15 @@ WORKLOADS = {
 #   cfg2_x4 / cfg3_x4 / cfg5_x4: four independent batches of the workload per ss_mfcc_batches_device /
 #     ss_mel_spectrogram_batches_device call (ONE persistent launch): what the start-up + tail of a launch cost, recovered without
 #     streams.  Per-batch figures; never `value`.
-#   cfg3 / cfg5: 1000 steps, 50 - 60 ms each (regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt)
+#   cfg3 / cfg5: 1000 steps, 50 - 60 ms each (regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt),
+#     run inside the library like cfg2 (their twelve-wave builds stamp every wave's lifetime too: time and clock from the same launches)
 #   cfg4: the whole 360 000-clip corpus in one launch, 5 steps
 LEGS = {
     "cfg2": ("cfg2", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
     "cfg2_x4": ("cfg2", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
-    "cfg3": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+    "cfg3": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
     "cfg3_x4": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
-    "cfg5": ("cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0)),
+    "cfg5": ("cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
     "cfg5_x4": ("cfg5", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
     "cfg4": ("cfg4", dict(steps=5, warmup=1, prewarm_ms=300.0)),
 }
@@ -388,14 +389,15 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         step(i)
     torch.cuda.synchronize()
     clock_ghz = clock_source = None
-    if stamped and kind == "mfcc" and streams == 1 and group == 1:
+    if stamped and streams == 1 and group == 1:
         # the library runs the region: the same launches (input ring, output blocks), events on the launch stream, per-wave stamps
         # of the last `stamped` of them
         px = (C.c_void_p * n_buf)(*[x.data_ptr() for x in xs])
         po = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         ms, ghz, wall = C.c_float(0.0), C.c_float(0.0), C.c_float(0.0)
-        rc = lib.ss_mfcc_timed_region(cfg.handle, px, n_buf, clips, n_samples, n_samples, po, len(outs), sptrs[0], steps, stamped,
-                                      C.byref(ms), C.byref(ghz), C.byref(wall))
+        region = lib.ss_mfcc_timed_region if kind == "mfcc" else lib.ss_mel_spectrogram_timed_region
+        rc = region(cfg.handle, px, n_buf, clips, n_samples, n_samples, po, len(outs), sptrs[0], steps, stamped,
+                    C.byref(ms), C.byref(ghz), C.byref(wall))
         torch.cuda.synchronize()
         if rc:
             _lib.check(rc)
@@ -404,7 +406,7 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
         if ghz.value > 0:
             clock_ghz = float(ghz.value)
             clock_source = (f"in-kernel stamps of {'all' if stamped >= steps else 'the last ' + str(stamped) + ' of'} the {steps} timed launches themselves "
-                            "(ss_mfcc_timed_region)")
+                            f"(ss_{'mfcc' if kind == 'mfcc' else 'mel_spectrogram'}_timed_region)")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(main)

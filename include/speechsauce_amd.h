@@ -307,8 +307,8 @@ int ss_time_mel_spectrogram_device(const ss_config *cfg, const float *d_x, size_
 int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, size_t n_samples, size_t ld, float *d_out,
                          void *stream, int launches, float *ghz);
 
-/* A timed region whose duration and shader clock come from the SAME launches (bench.py's secondary.cfg2): `launches` launches of
- * the MFCC batch kernel on `stream`, launch i reading d_x[i % n_x] and writing d_out[i % n_out] (host arrays of device pointers: a
+/* A timed region whose duration and shader clock come from the SAME launches (bench.py's secondary.cfg2 / cfg5): `launches`
+ * launches of the MFCC batch kernel on `stream`, launch i reading d_x[i % n_x] and writing d_out[i % n_out] (host arrays of device pointers: a
  * ring of inputs larger than the 256 MiB Infinity Cache keeps the samples coming from HBM), HIP events recorded on `stream` around
  * all of them, and the per-wave stamps of the LAST min(stamped, launches, 4096) launches kept, each launch in a slot of its own of
  * a buffer this call owns.  *avg_ms = region / launches; *ghz = (sum of the waves' shader cycles) / (sum of their lifetimes on
@@ -318,6 +318,13 @@ int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, s
 int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t batch, size_t n_samples, size_t ld,
                          float *const *d_out, size_t n_out, void *stream, int launches, int stamped, float *avg_ms, float *ghz,
                          float *wall_ms);
+
+/* The same for the mel-spectrogram path.  The wave stamps exist in the 512-point MFCC kernel and in the twelve-wave builds of the
+ * 4096-point MFCC kernel (default shape) and of the 2048-point mel kernel (the builds of BASELINE configurations 2 / 4, 5 and 3):
+ * with stamped > 0 on any other kernel both functions time the region and then return SS_ERR_UNSUPPORTED. */
+int ss_mel_spectrogram_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t channels, size_t n_samples,
+                                    size_t ld, float *const *d_out, size_t n_out, void *stream, int launches, int stamped,
+                                    float *avg_ms, float *ghz, float *wall_ms);
 
 /* Shader clock (GHz) of the device while WHATEVER ELSE runs on it: one wave on `stream` sleeps through a lead-in (a tenth of
  * `micros`, at most 200 us), reads the shader-cycle counter and the constant 100 MHz counter, sleeps (no memory traffic, no LDS,

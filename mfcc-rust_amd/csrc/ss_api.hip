@@ -108,6 +108,9 @@ thread_local const char *g_last_kernel = "";
 // per-wave stamps of the 512-point MFCC kernel: the buffer of the CURRENT call on this thread (ss_mfcc_shader_clock sets it
 // around its own launches; nothing process-wide in the product build)
 thread_local unsigned long long *g_call_stamps = nullptr;
+// the same for the kernels that write two words per wave (cycles lived, 100 MHz ticks lived): the twelve-wave builds of the
+// 4096-point MFCC and the 2048-point mel kernel (the *_timed_region diagnostics set it around their own launches)
+thread_local unsigned long long *g_call_stamps2 = nullptr;
 #if SS_LAB
 std::atomic<unsigned long long *> g_stamp_buffer{nullptr};  // ss_debug_stamp_buffer
 // test aids of include/speechsauce_amd_debug.h (process-wide)
@@ -394,6 +397,7 @@ int launch_frames(const ss_config *cfg, int out_kind, const float *d_x, size_t b
         f.out_energy = out1;
         f.out_mfe = out_kind == ss::OUT_MFE;
         f.window = a.window;
+        f.stamps = g_call_stamps2;
     };
     if (multi) {
         if (!force_generic && cfg->mfcc4096.ok && out_kind == ss::OUT_MFCC && a.frame_mode == ss::FRAME_NORMAL) {
@@ -618,6 +622,7 @@ int launch_stft(const ss_config *cfg, int out_kind, const float *d_x, size_t cha
         m.out = out0;
         m.out_stft = out_kind == ss::OUT_STFT;
         m.ctl = cfg->d_err;
+        m.stamps = g_call_stamps2;
         {
             // the poll bound lives behind the table block in device memory; it changes only when the test aid is toggled
             const unsigned lim = ss::dbg_tile_spin_limit();
@@ -1759,19 +1764,31 @@ int ss_mfcc_shader_clock(const ss_config *cfg, const float *d_x, size_t batch, s
     return SS_OK;
 }
 
+extern "C++" {  // (a template: C++ linkage inside the extern "C" block)
 namespace {
-// Sums of the per-wave stamps of ss_mfcc_timed_region's launches: sums[0] += shader cycles lived, sums[1] += 100 MHz ticks lived,
-// sums[2] += waves counted, over the `n` six-word wave records that carry a lifetime (the two table waves of a workgroup report
-// something else in word 5 and are skipped, as are records of waves that never ran).
-static __global__ __launch_bounds__(256) void stamp_sums_kernel(const unsigned long long *w, unsigned long long n, unsigned long long *sums)
+// Sums of the per-wave stamps of a timed region's launches: sums[0] += shader cycles lived, sums[1] += 100 MHz ticks lived,
+// sums[2] += waves counted.  `slots` launches, each with `slot_words` words of records for `nwaves` waves.  Format 0 (512-point
+// MFCC kernel): six words per wave -- start / end on the 100 MHz clock in words 0 / 2, cycles lived flagged 1 in bits 40..41 of
+// word 5 (the two table waves of a workgroup report something else there and are skipped).  Format 1 (twelve-wave 4096-point MFCC
+// and 2048-point mel builds): two words per wave -- cycles lived, ticks lived.  Records of waves that never ran are zero.
+static __global__ __launch_bounds__(256) void stamp_sums_kernel(const unsigned long long *w, unsigned long long slots, unsigned long long slot_words,
+                                                                unsigned long long nwaves, int format, unsigned long long *sums)
 {
     unsigned long long cyc = 0, ticks = 0, cnt = 0;
+    const unsigned long long n = slots * nwaves;
     for (unsigned long long k = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; k < n;
          k += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
-        const unsigned long long t0 = w[6 * k], t1 = w[6 * k + 2], c = w[6 * k + 5];
-        if (t1 <= t0 || (c >> 40) != 1) continue;
-        cyc += c & ((1ull << 40) - 1);
-        ticks += t1 - t0;
+        const unsigned long long *r = w + (k / nwaves) * slot_words + (k % nwaves) * (format == 0 ? 6ull : 2ull);
+        if (format == 0) {
+            const unsigned long long t0 = r[0], t1 = r[2], c = r[5];
+            if (t1 <= t0 || (c >> 40) != 1) continue;
+            cyc += c & ((1ull << 40) - 1);
+            ticks += t1 - t0;
+        } else {
+            if (r[1] == 0) continue;
+            cyc += r[0];
+            ticks += r[1];
+        }
         ++cnt;
     }
     for (int m = 32; m > 0; m >>= 1) {
@@ -1785,19 +1802,13 @@ static __global__ __launch_bounds__(256) void stamp_sums_kernel(const unsigned l
         atomicAdd(&sums[2], cnt);
     }
 }
-}  // namespace
 
-// A timed region whose duration AND shader clock come from the same launches: `launches` launches of the MFCC batch kernel on
-// `stream`, launch i reading d_x[i % n_x] and writing d_out[i % n_out] (a ring of inputs larger than the Infinity Cache keeps the
-// samples coming from HBM), HIP events on `stream` around all of them, and the per-wave stamps of the LAST `stamped` launches kept,
-// each launch in a slot of its own of a buffer this call owns.  *avg_ms = region / launches; *ghz = sum of the waves' shader
-// cycles / sum of their lifetimes on the 100 MHz clock over every stamped launch.
-int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t batch, size_t n_samples, size_t ld,
-                         float *const *d_out, size_t n_out, void *stream, int launches, int stamped, float *avg_ms, float *ghz,
-                         float *wall_ms)
+// The timed region behind ss_mfcc_timed_region / ss_mel_spectrogram_timed_region: `launches` launches through `launch(i)` on
+// `stream` between two HIP events, the per-wave stamps of the last `stamped` of them kept (each launch in a slot of its own of a
+// buffer this call owns) and summed on the device.
+template <typename Launch>
+int timed_region(const ss_config *cfg, void *stream, int launches, int stamped, float *avg_ms, float *ghz, float *wall_ms, Launch launch)
 {
-    if (!cfg || !d_x || !d_out || n_x == 0 || n_out == 0 || launches <= 0 || stamped < 0 || !avg_ms || !ghz)
-        return ss::fail(SS_ERR_ARG, "bad timed-region request");
     *avg_ms = 0.f;
     *ghz = 0.f;
     if (wall_ms) *wall_ms = 0.f;
@@ -1818,17 +1829,28 @@ int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n
             return hip_fail(ec, "hipEventCreate");
         }
     }
-    SS_HIP(hipStreamSynchronize(s));  // the region starts on an idle stream (the memset above is not part of it)
+    {
+        const hipError_t es = hipStreamSynchronize(s);  // the region starts on an idle stream (the memset above is not part of it)
+        if (es != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return hip_fail(es, "hipStreamSynchronize");
+        }
+    }
     const auto w0 = std::chrono::steady_clock::now();
     (void)hipEventRecord(e0, s);
-    bool all_stamped = true;
+    int format = -1;  // which record format the stamped launches wrote (-2: a kernel without stamps, or not always the same one)
     for (int i = 0; i < launches && rc == SS_OK; ++i) {
         const int slot = i - (launches - stamped);
-        g_call_stamps = slot >= 0 ? db.as<unsigned long long>() + static_cast<size_t>(slot) * words : nullptr;
-        rc = ss_mfcc_batch_device(cfg, d_x[static_cast<size_t>(i) % n_x], batch, n_samples, ld, d_out[static_cast<size_t>(i) % n_out], stream);
-        if (slot >= 0 && std::strncmp(g_last_kernel, "ss_mfcc_c256<", 13) != 0) all_stamped = false;
+        g_call_stamps = g_call_stamps2 = slot >= 0 ? db.as<unsigned long long>() + static_cast<size_t>(slot) * words : nullptr;
+        rc = launch(i);
+        if (slot >= 0) {
+            const int f = std::strncmp(g_last_kernel, "ss_mfcc_c256<", 13) == 0 ? 0
+                          : (std::strncmp(g_last_kernel, "ss_mfcc_c2048<exact,mel8321,w12>", 32) == 0 || std::strncmp(g_last_kernel, "ss_mel_c1024<w12", 16) == 0) ? 1 : -2;
+            format = (format == -1 || format == f) ? f : -2;
+        }
     }
-    g_call_stamps = nullptr;
+    g_call_stamps = g_call_stamps2 = nullptr;
     (void)hipEventRecord(e1, s);
     hipError_t e = hipSuccess;
     while ((e = hipEventQuery(e1)) == hipErrorNotReady) {  // polled: a blocking wait's wake-up latency is several launches long
@@ -1842,14 +1864,14 @@ int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n
     if (e != hipSuccess) return hip_fail(e, "event timing");
     *avg_ms = ms / static_cast<float>(launches);
     if (stamped == 0) return SS_OK;
-    if (!all_stamped) return ss::fail(SS_ERR_UNSUPPORTED, "the shader-clock stamps exist in the 512-point MFCC kernel only");
+    if (format < 0) return ss::fail(SS_ERR_UNSUPPORTED, "the wave stamps exist in the 512-point MFCC kernel and in the twelve-wave builds of the 4096-point MFCC and 2048-point mel kernels only");
     // the records are summed on the device (1000 stamped launches are 196 MB of them): three words come back
     DeviceBuf sums;
     rc = sums.alloc(3 * sizeof(unsigned long long));
     if (rc) return rc;
     SS_HIP(hipMemsetAsync(sums.p, 0, 3 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(stamp_sums_kernel, dim3(1024), dim3(256), 0, s, db.as<unsigned long long>(),
-                       static_cast<unsigned long long>(stamped) * nwaves, sums.as<unsigned long long>());
+    hipLaunchKernelGGL(stamp_sums_kernel, dim3(1024), dim3(256), 0, s, db.as<unsigned long long>(), static_cast<unsigned long long>(stamped),
+                       static_cast<unsigned long long>(words), static_cast<unsigned long long>(nwaves), format, sums.as<unsigned long long>());
     SS_HIP(hipGetLastError());
     unsigned long long hs[3] = {0, 0, 0};
     SS_HIP(hipMemcpyAsync(hs, sums.p, sizeof hs, hipMemcpyDeviceToHost, s));
@@ -1857,6 +1879,36 @@ int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n
     if (hs[1] == 0 || hs[2] == 0) return ss::fail(SS_ERR_DEVICE, "no wave reported its lifetime");
     *ghz = static_cast<float>(static_cast<double>(hs[0]) / (static_cast<double>(hs[1]) * 10.0));  // cycles per ns
     return SS_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+// A timed region whose duration AND shader clock come from the same launches: `launches` launches of the MFCC batch kernel on
+// `stream`, launch i reading d_x[i % n_x] and writing d_out[i % n_out] (a ring of inputs larger than the Infinity Cache keeps the
+// samples coming from HBM), HIP events on `stream` around all of them, and the per-wave stamps of the LAST `stamped` launches kept,
+// each launch in a slot of its own of a buffer this call owns.  *avg_ms = region / launches; *ghz = sum of the waves' shader
+// cycles / sum of their lifetimes on the 100 MHz clock over every stamped launch.
+int ss_mfcc_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t batch, size_t n_samples, size_t ld,
+                         float *const *d_out, size_t n_out, void *stream, int launches, int stamped, float *avg_ms, float *ghz,
+                         float *wall_ms)
+{
+    if (!cfg || !d_x || !d_out || n_x == 0 || n_out == 0 || launches <= 0 || stamped < 0 || !avg_ms || !ghz)
+        return ss::fail(SS_ERR_ARG, "bad timed-region request");
+    return timed_region(cfg, stream, launches, stamped, avg_ms, ghz, wall_ms, [&](int i) {
+        return ss_mfcc_batch_device(cfg, d_x[static_cast<size_t>(i) % n_x], batch, n_samples, ld, d_out[static_cast<size_t>(i) % n_out], stream);
+    });
+}
+
+// the same for the mel-spectrogram path (2048-point kernel, twelve-wave builds)
+int ss_mel_spectrogram_timed_region(const ss_config *cfg, const float *const *d_x, size_t n_x, size_t channels, size_t n_samples, size_t ld,
+                                    float *const *d_out, size_t n_out, void *stream, int launches, int stamped, float *avg_ms, float *ghz,
+                                    float *wall_ms)
+{
+    if (!cfg || !d_x || !d_out || n_x == 0 || n_out == 0 || launches <= 0 || stamped < 0 || !avg_ms || !ghz)
+        return ss::fail(SS_ERR_ARG, "bad timed-region request");
+    return timed_region(cfg, stream, launches, stamped, avg_ms, ghz, wall_ms, [&](int i) {
+        return ss_mel_spectrogram_device(cfg, d_x[static_cast<size_t>(i) % n_x], channels, n_samples, ld, d_out[static_cast<size_t>(i) % n_out], stream);
+    });
 }
 
 namespace {

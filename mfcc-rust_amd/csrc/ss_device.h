@@ -191,6 +191,9 @@ struct Mel2048Args {
     // when a tile hand-off never came (the host turns it into SS_ERR_DEVICE).  Touched on the cold path only; how long a wave
     // polls before it gives up is the word behind the table block.
     unsigned *ctl;
+    // twelve-wave builds, diagnostic (ss_mel_spectrogram_timed_region): two words per wave -- shader cycles lived, 100 MHz ticks
+    // lived -- or null
+    unsigned long long *stamps;
 };
 
 hipError_t launch_mel_c1024(const Mel2048Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);
@@ -307,6 +310,9 @@ struct Mfcc4096Args {
     int32_t out_mfe;     // 1: stop after the mel stage and write mfe's (features, energy) (feature.rs:200-233)
     const float *window; // optional frame window [flen] in device memory (mfcc_window switch), or null
     float *dbg;  // diagnostic (SS_DEBUG_ROWS): frame 0's P row [1028] + ln(mel) row [256], or null
+    // twelve-wave default-shape build, diagnostic (ss_mfcc_timed_region): two words per wave -- shader cycles lived, 100 MHz ticks
+    // lived -- or null
+    unsigned long long *stamps;
 };
 
 hipError_t launch_mfcc_c2048(const Mfcc4096Args &a, hipStream_t stream, int num_cus, LaunchInfo *info);

@@ -334,6 +334,7 @@ template <bool FIXMEL, bool STFT = false, bool MULTI = false>
 __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args a, const MultiArg<MULTI> mt)
 {
     static_assert(!(MULTI && STFT), "the batch-table build is a mel-output build");
+    const LifeStamp life = life_begin(a.stamps);  // (diagnostic: null in every ordinary launch)
     constexpr int kWavesM = 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(12 * 64, 3) void ss_mel_c1024_w12(const Mel2048Args
 #endif
         item = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(next_v));
     }
+    life_end(a.stamps, life, blockIdx.x * kWavesM + (threadIdx.x >> 6));
 #if SS_LAB && defined(SS_PROF3)
     if ((threadIdx.x & 63) == 0) p3[0] = p3n | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20)) << 32);
 #endif

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
+    const LifeStamp life = life_begin(WAVES > 8 ? a.stamps : nullptr);  // (diagnostic, twelve-wave build: null in every ordinary launch)
     // LEAN: twelve waves per CU (three per SIMD) at <= 168 VGPRs.  Every table read comes in batches of at most eight float4s
     // (a third wave on the SIMD hides the round trips the 8-wave build has to avoid) and what depends on the lane number only
     // is derived again in every iteration instead of living in registers: twelve exchange regions + the tables are 163 584 of
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void ss_mfcc_c2048(const Mfc
         wave_order();
         frame = __builtin_amdgcn_readfirstlane(next_v);
     }
+    if (WAVES > 8) life_end(a.stamps, life, blockIdx.x * WAVES + wave);
 #if SS_PROF5
     if (a.dbg && (threadIdx.x & 63) == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg) + 16ull * (blockIdx.x * WAVES + wave);

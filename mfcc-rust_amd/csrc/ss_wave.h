@@ -87,6 +87,29 @@ __device__ __forceinline__ Seg seg_of(const BatchTable &m, unsigned g)  // g: un
     return r;
 }
 
+// Wave-lifetime stamps (the *_timed_region diagnostics): a wave notes the shader-cycle counter and the constant 100 MHz counter
+// as it starts and writes the two differences into its record as it ends -- scalar work outside the main loop, nothing when the
+// pointer is null (every ordinary launch).
+struct LifeStamp {
+    unsigned long long c0, t0;
+};
+__device__ __forceinline__ LifeStamp life_begin(const unsigned long long *stamps)
+{
+    LifeStamp s{0ull, 0ull};
+    if (stamps) {
+        s.c0 = __builtin_amdgcn_s_memtime();
+        s.t0 = __builtin_amdgcn_s_memrealtime();
+    }
+    return s;
+}
+__device__ __forceinline__ void life_end(unsigned long long *stamps, const LifeStamp &s, unsigned wave_index)
+{
+    if (stamps && (threadIdx.x & 63) == 0) {
+        stamps[2ull * wave_index] = __builtin_amdgcn_s_memtime() - s.c0;
+        stamps[2ull * wave_index + 1] = __builtin_amdgcn_s_memrealtime() - s.t0;
+    }
+}
+
 // ds_bpermute_b32: every lane reads `v` of the lane whose number is addr / 4 (LDS crossbar, no memory round trip)
 __device__ __forceinline__ float bperm(int addr, float v)
 {

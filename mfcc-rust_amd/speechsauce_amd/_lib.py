@@ -99,6 +99,8 @@ PROTOTYPES = {
     "ss_mel_spectrogram_batches_device": (C.c_int, [_cfg, C.c_size_t, _P(C.c_void_p), _P(C.c_size_t), C.c_size_t, C.c_size_t, _P(C.c_void_p), C.c_void_p]),
     "ss_mfcc_timed_region": (C.c_int, [_cfg, _P(C.c_void_p), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P(C.c_void_p), C.c_size_t, C.c_void_p,
                                        C.c_int, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
+    "ss_mel_spectrogram_timed_region": (C.c_int, [_cfg, _P(C.c_void_p), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P(C.c_void_p), C.c_size_t,
+                                                  C.c_void_p, C.c_int, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "ss_mel_spectrogram_device": (C.c_int, [_cfg, _fp, C.c_size_t, C.c_size_t, C.c_size_t, _fp, C.c_void_p]),
     "ss_preemphasis_device": (C.c_int, [_fp, C.c_size_t, C.c_long, C.c_float, _fp, C.c_void_p]),
     "ss_lmfe": (C.c_int, [_cfg, _fp, C.c_size_t, _fp]),

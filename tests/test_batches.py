@@ -327,9 +327,30 @@ def test_timed_region_times_and_clocks_the_same_launches(ss, sslib):
     assert 0.015 < ms.value < 0.08 and 1.0 < ghz.value < 2.6, (ms.value, ghz.value)
     assert 200 * ms.value <= wall.value < 200 * ms.value + 2.0, (ms.value, wall.value)  # the host saw the same region, plus its own latency
     assert all(torch.equal(o, w) for o, w in zip(outs, want))
-    # timing only; and a configuration whose kernel has no stamps
+    # timing only
     assert sslib.ss_mfcc_timed_region(cfg.handle, px, 5, 1024, 16000, 16000, po, 5, None, 20, 0, C.byref(ms), C.byref(ghz), None) == 0
     assert ms.value > 0 and ghz.value == 0
+    # the 4096-point MFCC kernel's and the 2048-point mel kernel's twelve-wave builds stamp their waves too (secondary.cfg5 / cfg3)
+    c5 = SpeechConfig(make_params(sample_rate=44100, fft_points=4096, frame_length=4096 / 44100, frame_stride=1024 / 44100, num_cepstral=40,
+                                  num_filters=256, high_frequency=22050.0))
+    x5 = _batches(torch, [512, 512], 44100, 341)
+    w5 = _separate(torch, sslib, c5, x5, (39, 40), 44100)
+    g5 = [torch.full((512, 39, 40), float("nan"), device="cuda") for _ in range(2)]
+    px5, _, po5 = _tables(x5, g5)
+    assert sslib.ss_mfcc_timed_region(c5.handle, px5, 2, 512, 44100, 44100, po5, 2, None, 60, 60, C.byref(ms), C.byref(ghz), C.byref(wall)) == 0, sslib.ss_last_error_string()
+    assert sslib.ss_last_kernel_name() == BENCH_KERNELS["cfg5"] and 0.03 < ms.value < 0.15 and 1.0 < ghz.value < 2.6, (ms.value, ghz.value)
+    assert all(torch.equal(o, w) for o, w in zip(g5, w5))
+    c3 = SpeechConfig(make_params(sample_rate=16000, fft_points=2048, frame_length=0.032, frame_stride=0.032, num_filters=128, high_frequency=8000.0))
+    R = c3.stft_rows(16000)[0]
+    g3 = [torch.full((1024, 128, R), float("nan"), device="cuda") for _ in range(2)]
+    po3 = (C.c_void_p * 2)(*[o.data_ptr() for o in g3])
+    assert sslib.ss_mel_spectrogram_timed_region(c3.handle, px, 5, 1024, 16000, 16000, po3, 2, None, 60, 60, C.byref(ms), C.byref(ghz), C.byref(wall)) == 0, sslib.ss_last_error_string()
+    assert sslib.ss_last_kernel_name() == BENCH_KERNELS["cfg3"] and 0.02 < ms.value < 0.12 and 1.0 < ghz.value < 2.6, (ms.value, ghz.value)
+    w3 = torch.empty((1024, 128, R), device="cuda")
+    assert sslib.ss_mel_spectrogram_device(c3.handle, xs[59 % 5].data_ptr(), 1024, 16000, 16000, w3.data_ptr(), None) == 0
+    assert torch.equal(g3[59 % 2], w3)  # launch 59 read batch 59 % 5 and wrote block 59 % 2
+    assert sslib.ss_mel_spectrogram_timed_region(c3.handle, px, 0, 1024, 16000, 16000, po3, 2, None, 6, 0, C.byref(ms), C.byref(ghz), None) == 3
+    # a kernel without stamps: timed, then SS_ERR_UNSUPPORTED
     cfg5 = SpeechConfig(make_params(sample_rate=16000, fft_points=1024))
     o5 = torch.empty((8, cfg5.num_frames(16000), 13), device="cuda")
     p5, q5 = (C.c_void_p * 1)(xs[0].data_ptr()), (C.c_void_p * 1)(o5.data_ptr())

@@ -1049,6 +1049,8 @@ def test_bench_default_line_carries_the_contract_and_the_secondary_configs():
         assert 0.05 < e["frac"] < 0.6
         if e.get("clock_ghz_measured"):
             assert 1.0 < e["clock_ghz_measured"] < 2.6 and abs(e["cycles_per_launch"] - e["avg_launch_us"] * 1e3 * e["clock_ghz_measured"]) < 1.0
+        if wl in ("cfg3", "cfg5"):  # round 6: their cycle counts share launches with their times, like secondary.cfg2's
+            assert "timed launches themselves" in e["clock_source"] and 1.0 < e["clock_ghz_measured"] < 2.6
 
 
 def test_cpp_mirror_parity(tmp_path, oracle):
