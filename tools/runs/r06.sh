@@ -55,7 +55,7 @@ for w in cfg2 cfg3 cfg5; do
   cp gpurun_out/prof_r06_${w}_x4/trace/*/*kernel_stats.csv $O/${w}_x4_kernel_stats.csv; cp gpurun_out/prof_r06_${w}_x4/summary.json $O/${w}_x4_pmc_summary.json
 done
 rm -rf gpurun_out/prof_r06_*  # raw traces: more than gpurun copies back; the summaries above are what is kept
-for f in $O/bench_cfg*.json; do python -c "
+for f in $O/bench_cfg?.json; do python -c "
 import json,sys;d=json.load(open('$f'));r=d['roofline'];print('$f', r['kernel'], round(r['avg_launch_us'],2), 'us frac', round(r['frac'],4), 'clk', r.get('clock_ghz_measured'), 'valu', r.get('valu_floor_frac'))"; done
 grep real $O/bench_default.err; summ $O/bench_default.json
 for w in cfg2 cfg3 cfg5; do head -2 $O/${w}_kernel_stats.csv | cut -c1-220; head -2 $O/${w}_x4_kernel_stats.csv | cut -c1-220; done
