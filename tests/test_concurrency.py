@@ -217,6 +217,48 @@ def test_four_host_threads_share_the_handles(works, sslib, oracle):
         w.check_against_oracle(oracle, w.conc)
 
 
+def test_batch_table_launches_from_four_threads(works, sslib):
+    """ss_mfcc_batches_device (several batches in one launch of the batch-table build) from four host threads on one handle, each on a
+    stream of its own: the kernel-argument table is per launch, so concurrent calls cannot see each other's blocks -- every block
+    equals the serial single-batch run bit for bit."""
+    import torch
+
+    w = works[0]  # cfg2
+    for o in w.conc:
+        o.fill_(float("nan"))
+    torch.cuda.synchronize()
+    dev = torch.cuda.current_device()
+    streams = [torch.cuda.Stream() for _ in range(STREAMS)]
+    problems = []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(dev)
+            sp = C.c_void_p(streams[t].cuda_stream)
+            for g in range(t, STEPS // 4, STREAMS):  # group g = steps 4g .. 4g + 3
+                idx = list(range(4 * g, 4 * g + 4))
+                px = (C.c_void_p * 4)(*[w.xs[i % DISTINCT].data_ptr() for i in idx])
+                po = (C.c_void_p * 4)(*[w.conc[i].data_ptr() for i in idx])
+                nb = (C.c_size_t * 4)(*([w.clips] * 4))
+                rc = sslib.ss_mfcc_batches_device(w.cfg.handle, 4, px, nb, w.n, w.n, po, sp)
+                if rc != 0 or sslib.ss_last_kernel_name() != b"ss_mfcc_c256m<10,exact,bank421,sym>":
+                    problems.append((t, g, rc, sslib.ss_last_error_string(), sslib.ss_last_kernel_name()))
+            streams[t].synchronize()
+        except Exception as e:  # noqa: BLE001
+            problems.append((t, "exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(STREAMS)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not problems, problems[:5]
+    w.cfg.device_status()
+    for i in range(STEPS):
+        assert torch.equal(w.conc[i], w.serial[i]), i
+
+
 def test_host_pointer_calls_from_threads_on_one_handle(ss, sslib, oracle):
     """The synchronous host-pointer entry points (ss_mfcc: H2D + kernel + D2H on the handle's private streams) from four threads on
     one handle: serialised by the handle's mutex, every result equals the single-threaded one bit for bit."""
