@@ -339,7 +339,13 @@ def measure_simple(torch, ss_mod, workload, device, steps, warmup, prewarm_ms=30
     out_elems = out_shape[0] * out_shape[1] * out_shape[2]
     bytes_per_launch = 4 * clips * n_samples + 4 * out_elems
     big = 4 * clips * n_samples > ring_mib * 2**20  # cfg4: one 23 GB batch is its own ring
-    n_buf = 1 if big else max(2, -(-ring_mib * 2**20 // (4 * clips * n_samples)))
+    # With several batches in flight at once (`group` per launch, or `streams` launches side by side) the ring grows by that factor:
+    # a 300 MiB ring is five 65 MB batches, and a launch of four of them re-reads three that its predecessor read ~260 MB ago -- at the
+    # edge of the 256 MiB Infinity Cache, which then serves part of the input (cfg2, one box, four batches per launch: 25.2 - 25.8 us
+    # per batch on a 300 MiB ring, 26.4 - 26.8 on 1200 or 2400 MiB; four streams 26.5 against 27.6 - 28.6; one batch per launch reads
+    # 28.4 - 28.9 on every ring: profiles/r06/ring_check.txt).  Round 5's `value_pipelined` was measured on the small ring.
+    in_flight = max(1, group, streams)
+    n_buf = 1 if big else max(2, -(-ring_mib * in_flight * 2**20 // (4 * clips * n_samples)))
     xs = [synth_batch(torch, clips, n_samples, 7001 + i, device) for i in range(n_buf)]
     main = torch.cuda.current_stream()
     sts = [main] + [torch.cuda.Stream(device=device) for _ in range(max(0, streams - 1))]
@@ -636,7 +642,7 @@ def main():
     frames_per_launch = clips * rows
 
     # distinct input batches totalling > 256 MiB so the Infinity Cache cannot hold the stream
-    ring_mib = args.ring_mib
+    ring_mib = args.ring_mib * max(1, args.streams)  # (several launches side by side: see measure_simple)
     n_buf = max(1 if strong else 2, -(-ring_mib * 1024 * 1024 // (4 * clips * n_samples)))
     xs = [synth_batch(torch, clips, n_samples, 1 + rank * 100 + i, device) for i in range(n_buf)]
     stream = torch.cuda.current_stream()

@@ -82,8 +82,11 @@ sweeps)  # robustness: random configurations against the oracle (every third on 
 SS_SWEEP_SEED=10000 timeout 1500 python tools/bigsweep.py 2>&1 | grep -v "$FILT" | tail -6 | tee gpurun_out/r06/bigsweep.txt
 SS_SWEEP_SEED=10000 timeout 1500 python tools/melsweep.py 2>&1 | grep -v "$FILT" | tail -6 | tee gpurun_out/r06/melsweep.txt
 ;;
+groups)  # 1 / 2 / 4 / 8 batches per launch
+python tools/group_sweep.py 2>&1 | grep -v "$FILT" | tee gpurun_out/r06/group_sweep.txt
+;;
 *)
-echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4|sweeps}" >&2
+echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4|sweeps|groups}" >&2
 exit 2
 ;;
 esac
