@@ -77,15 +77,17 @@ WORKLOADS = {
 #     cycles_per_launch whose time and clock share launches -- stamping only the region's last quarter spreads 1.2 % between regions
 #     on one box, stamping all of it 0.3 % (profiles/r06/stamp_cost.txt) --, and the figure rounds are compared on (a 20-step headline
 #     region is 0.6 ms: the same binary reads 26 - 30 us there, profiles/r05/box_spread.txt).
-#   cfg2_x4 / cfg3_x4 / cfg5_x4: four independent batches of the workload per ss_mfcc_batches_device /
+#   cfg2_x4 / cfg2_x8 / cfg3_x4 / cfg5_x4: four (eight) independent batches of the workload per ss_mfcc_batches_device /
 #     ss_mel_spectrogram_batches_device call (ONE persistent launch): what the start-up + tail of a launch cost, recovered without
-#     streams.  Per-batch figures; never `value`.
+#     streams; eight batches reach the one-launch corpus rate of cfg4.  Per-batch figures; never `value`.  The input ring grows
+#     with the batches in flight (measure_simple), so that the Infinity Cache serves none of it.
 #   cfg3 / cfg5: 1000 steps, 50 - 60 ms each (regions of 200 steps read 5 - 10 % slower on the same box, profiles/r05/secondary_probe.txt),
 #     run inside the library like cfg2 (their twelve-wave builds stamp every wave's lifetime too: time and clock from the same launches)
 #   cfg4: the whole 360 000-clip corpus in one launch, 5 steps
 LEGS = {
     "cfg2": ("cfg2", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
     "cfg2_x4": ("cfg2", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
+    "cfg2_x8": ("cfg2", dict(steps=1000, warmup=96, prewarm_ms=100.0, group=8, probe_board=False)),
     "cfg3": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),
     "cfg3_x4": ("cfg3", dict(steps=1000, warmup=100, prewarm_ms=100.0, group=4, probe_board=False)),
     "cfg5": ("cfg5", dict(steps=1000, warmup=100, prewarm_ms=300.0, stamped=1000)),

@@ -1034,6 +1034,8 @@ def test_bench_default_line_carries_the_contract_and_the_secondary_configs():
     assert x4["kernel"] == "ss_mfcc_c256m<10,exact,bank421,sym>" and x4["batches_per_launch"] == 4
     assert x4["algorithmic_bytes_per_launch"] == 70754304 and abs(x4["launch_us"] - 4 * x4["avg_launch_us"]) < 1e-6
     assert 0.9 * s2["frac"] < x4["frac"] < 0.6
+    x8 = sec["cfg2_x8"]  # eight batches per launch: the one-launch corpus rate
+    assert "error" not in x8 and x8["kernel"] == x4["kernel"] and x8["batches_per_launch"] == 8 and 0.95 * x4["frac"] < x8["frac"] < 0.6
     for wl, kern, bytes_ in (("cfg3", "ss_mel_c1024m<w12,mel6321>", 82313216), ("cfg5", "ss_mfcc_c2048m<exact,mel8321,w12>", 93511680)):
         y4 = sec[wl + "_x4"]
         assert "error" not in y4, y4
