@@ -533,7 +533,7 @@ def main():
     ap.add_argument("--kind", default="", choices=["", "mfcc", "mel"], help="run the workload's clips through the other path (mfcc / mel_spectrogram); not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="single-thread CPU baseline budget (the all-cores run takes half of it)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (cfg2 over 1000 steps, cfg2_x4, cfg3, cfg5, cfg4) and value_pipelined that a default N = 1 run appends")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (cfg2 over 1000 steps, the batch-table legs, cfg3, cfg5, cfg4) and value_pipelined that a default N = 1 run appends")
     ap.add_argument("--corpus-clips", type=int, default=0, help="cfg4: size of the corpus that is split over the ranks (default 360 000); keeps strong scaling, unlike --clips")
     ap.add_argument("--gather-chunks", type=int, default=8, help="cfg4 with a gather: a rank's shard is computed and gathered in this many chunks, "
                     "chunk i's collective under chunk i+1's kernel")
@@ -978,8 +978,6 @@ def main():
             # the other BASELINE configurations and the pipelined headline, after and outside the headline's timed region
             del xs[:], outs[:]
             torch.cuda.empty_cache()
-            # (four streams reach the one-launch corpus rate: 2 / 3 / 4 streams +3 / +8 / +12 % over one on a 2000-step run,
-            # profiles/r05/streams.txt)
             # Everything below is extra: none of it may take the measured headline down with it (each leg reports {"error": ...}).
             res["secondary"] = {}
             for name, (wl, kw) in LEGS.items():
@@ -989,8 +987,8 @@ def main():
                     res["secondary"][name] = {"error": repr(e)}
             # value_pipelined: the headline workload once more with successive steps going round four HIP streams, 1000 steps with the
             # settings of secondary.cfg2 -- `value_one_stream` beside it is that leg's value (same steps, same ring, one stream), so the
-            # ratio of the two is streams and nothing else.  (four streams reach the one-launch corpus rate: 2 / 3 / 4 streams +3 / +8 /
-            # +12 % over one on a 2000-step run, profiles/r05/streams.txt)
+            # ratio of the two is streams and nothing else (+8 - 11 % on input rings that grow with the batches in flight; round 5's
+            # +10 - 16 %, profiles/r05/streams.txt, came from the fixed 300 MiB ring).
             try:
                 pl = measure_simple(torch, ss, "cfg2", device, steps=1000, warmup=100, prewarm_ms=100.0, streams=4, probe_board=False)
                 res["value_pipelined"] = pl["value"]
@@ -999,8 +997,8 @@ def main():
                                     "value_one_stream": one, "over_one_stream": (pl["value"] / one) if one else None,
                                     "note": "same workload, successive steps go round four HIP streams (independent batches): a launch's one-unit tail "
                                             "and the next ones' wait for their first samples overlap; wall time per step over 1000 steps, not a kernel "
-                                            "duration, not part of `roofline`; value_one_stream = secondary.cfg2 (same step count and input ring, one "
-                                            "stream): compare with THAT, not with the 20-step headline; outputs of this concurrent use are checked bit for "
+                                            "duration, not part of `roofline`; value_one_stream = secondary.cfg2 (same step count, one stream; the input "
+                                            "ring is 300 MiB per batch in flight in both): compare with THAT, not with the 20-step headline; outputs of this concurrent use are checked bit for "
                                             "bit against serial launches in tests/test_concurrency.py"}
             except Exception as e:
                 res["value_pipelined"] = None
