@@ -85,8 +85,15 @@ SS_SWEEP_SEED=10000 timeout 1500 python tools/melsweep.py 2>&1 | grep -v "$FILT"
 groups)  # 1 / 2 / 4 / 8 batches per launch
 python tools/group_sweep.py 2>&1 | grep -v "$FILT" | tee gpurun_out/r06/group_sweep.txt
 ;;
+trace_default)  # rocprofv3 kernel trace of the driver's own command: every kernel of the default line in one trace
+R=$PWD
+( cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/prof_default && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r06/bench_default_traced.json 2>/dev/null )
+cp gpurun_out/prof_default/*/*kernel_stats.csv gpurun_out/r06/default_run_kernel_stats.csv
+rm -rf gpurun_out/prof_default
+grep "ss::" gpurun_out/r06/default_run_kernel_stats.csv | cut -d, -f1-4 | cut -c1-220
+;;
 *)
-echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4|sweeps|groups}" >&2
+echo "usage: $0 {first|tests|spread|stampcost|profile|profile_x4|sweeps|groups|trace_default}" >&2
 exit 2
 ;;
 esac
