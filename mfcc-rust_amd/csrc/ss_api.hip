@@ -1070,6 +1070,13 @@ int ss_mfcc_batches_device(const ss_config *cfg, size_t n_batches, const float *
     std::vector<const float *> xs;
     std::vector<float *> outs;
     std::vector<size_t> clips;
+    try {  // (nothing unwinds across the boundary: a failed allocation of the three small tables is an error code)
+        xs.reserve(n_batches);
+        outs.reserve(n_batches);
+        clips.reserve(n_batches);
+    } catch (const std::exception &) {
+        return ss::fail(SS_ERR_ARG, "n_batches too large for this host's memory");
+    }
     for (size_t b = 0; b < n_batches; ++b) {
         if (batch[b] == 0) continue;  // an empty batch has no buffers
         if (!d_x[b] || !d_out[b]) return ss::fail(SS_ERR_ARG, "null buffer in batch " + std::to_string(b));
@@ -1562,6 +1569,13 @@ int ss_mel_spectrogram_batches_device(const ss_config *cfg, size_t n_batches, co
     std::vector<const float *> xs;
     std::vector<float *> outs;
     std::vector<size_t> chans;
+    try {
+        xs.reserve(n_batches);
+        outs.reserve(n_batches);
+        chans.reserve(n_batches);
+    } catch (const std::exception &) {
+        return ss::fail(SS_ERR_ARG, "n_batches too large for this host's memory");
+    }
     for (size_t b = 0; b < n_batches; ++b) {
         if (channels[b] == 0) continue;  // an empty block has no buffers
         if (!d_x[b] || !d_out[b]) return ss::fail(SS_ERR_ARG, "null buffer in batch " + std::to_string(b));
