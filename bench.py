@@ -120,9 +120,10 @@ class BoardProbe:
             hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
             self.pw = [p for h in hw for n in ("power1_average", "power1_input") for p in glob.glob(f"{h}/{n}")]
             self.fq = [p for h in hw for p in glob.glob(f"{h}/freq1_input")]
+            self.fq2 = [p for h in hw for p in glob.glob(f"{h}/freq2_input")]  # memory clock, where the driver exposes it
             self.cap = self._read([p for h in hw for p in glob.glob(f"{h}/power1_cap")])
         except Exception:
-            self.pw, self.fq, self.cap = [], [], None
+            self.pw, self.fq, self.fq2, self.cap = [], [], [], None
         if self.pw or self.fq:
             self.thread = threading.Thread(target=self._run, daemon=True)
             self.thread.start()
@@ -136,7 +137,7 @@ class BoardProbe:
 
     def _run(self):
         while not self.done:
-            self.samples.append((self._read(self.pw), self._read(self.fq)))
+            self.samples.append((self._read(self.pw), self._read(self.fq), self._read(self.fq2) if self.fq2 else None))
             time.sleep(0.01)
 
     def stop(self):
@@ -145,13 +146,15 @@ class BoardProbe:
             return None
         self.thread.join()
         tail = self.samples[len(self.samples) // 2:]  # the second half: the sensors lag the load by tens of milliseconds
-        p = [a / 1e6 for a, _ in tail if a]
-        f = [b / 1e6 for _, b in tail if b]
+        p = [a / 1e6 for a, _, _ in tail if a]
+        f = [b / 1e6 for _, b, _ in tail if b]
+        m = [c / 1e6 for _, _, c in tail if c]
         if not p and not f:
             return None
         return {"power_w_mean": round(sum(p) / len(p)) if p else None, "power_w_max": round(max(p)) if p else None,
                 "power_cap_w": round(self.cap / 1e6) if self.cap else None,
                 "sclk_mhz_mean": round(sum(f) / len(f)) if f else None, "sclk_mhz_min": round(min(f)) if f else None,
+                "mclk_mhz_mean": round(sum(m) / len(m)) if m else None, "mclk_mhz_min": round(min(m)) if m else None,
                 "samples": len(tail), "when": "second half of the untimed pre-roll of the same launches (hwmon, 10 ms period)"}
 
 
